@@ -1,0 +1,165 @@
+/*
+ * vibo_hip.h -- C ABI of the MI355X-native VIBO ELBO engine (libvibo_hip.so).
+ *
+ * The reference (mhw32/variational-item-response-theory-public) is pure Python
+ * and has no FFI of its own; the seam this library plugs into is the method
+ * surface of VIBO_1PL/2PL/3PL that src/torch_core/vibo.py calls (SURVEY.md
+ * §8b).  Each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless it
+ *     says "host"; the caller owns every buffer including the workspace; the
+ *     library allocates nothing and keeps no state between calls;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no host
+ *     synchronisation inside; safe to capture into a hipGraph;
+ *   - outputs are fully overwritten (never accumulated into);
+ *   - return value: 0 ok; <0 invalid argument / unsupported combination (see
+ *     vibo_last_error_string); >0 a hipError_t from the launch.  No C++
+ *     exception crosses the boundary.
+ *   - all floating point is IEEE fp32 (the reference computes in fp32).
+ */
+#ifndef VIBO_HIP_H
+#define VIBO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIBO_ABI_VERSION 1
+
+enum { VIBO_IRT_1PL = 1, VIBO_IRT_2PL = 2, VIBO_IRT_3PL = 3 };
+enum { VIBO_POSTERIOR_UNCONDITIONAL = 0, VIBO_POSTERIOR_CONDITIONAL = 1 };
+enum { VIBO_MISSING_PRIOR = 0,   /* missing cell -> N(0,1) prior expert (models.py:613-620) */
+       VIBO_MISSING_DROP = 1 };  /* --drop-missing: expert removed      (vibo.py:217)       */
+enum { VIBO_MASK_U8 = 0,         /* torch.bool / uint8, 1 byte per cell (datasets.py:938)   */
+       VIBO_MASK_I64 = 1,        /* mask.long() as the reference train loop passes it (vibo.py:240) */
+       VIBO_MASK_NONE = 2 };     /* mask == NULL: every cell observed                        */
+enum { VIBO_REG_KL = 0,          /* elbo(use_kl_divergence=True): analytic KL (models.py:427-430) */
+       VIBO_REG_SAMPLED = 1 };   /* use_kl_divergence=False / flows: log q - log p at the sample
+                                    (models.py:406-424, 432-441)                             */
+
+#define VIBO_MAX_ABILITY_DIM 8
+#define VIBO_MAX_FLOWS 8
+#define VIBO_NUM_SCALARS 8
+/* indices into out_scalars */
+enum { VIBO_S_LL = 0,        /* sum_{p,i} mask * log Bernoulli(response | p_pi)   (utils.py:46-49)   */
+       VIBO_S_REG = 1,       /* KL mode: sum_p KL(q(theta_p) || N(0,1))            (utils.py:85-88)
+                                sampled:  sum_p [log q0(theta_0) - ladj - log p(theta_K)]            */
+       VIBO_S_KL = 2,        /* sum_p KL, always                                                    */
+       VIBO_S_LOGQ0 = 3,     /* sum_p log N(theta_0; mu_p, var_p)                 (utils.py:59-61)   */
+       VIBO_S_LOGP = 4,      /* sum_p log N(theta_K; 0, 1)                        (utils.py:64-67)   */
+       VIBO_S_LADJ = 5,      /* sum_p sum_k log|det J_k|                          (flows.py:39)      */
+       VIBO_S_NOBS = 6,      /* number of observed cells                                             */
+       VIBO_S_RESERVED = 7 };
+
+/* Problem descriptor (host memory, POD).  B persons of this call x I items. */
+typedef struct vibo_desc {
+    int32_t abi_version;      /* VIBO_ABI_VERSION */
+    int32_t num_person;       /* B: rows processed by this call */
+    int32_t num_item;         /* I */
+    int32_t ability_dim;      /* A, 1..VIBO_MAX_ABILITY_DIM                         */
+    int32_t irt_model;        /* VIBO_IRT_*; item_feat_dim D = 1 | A+1 | A+2        */
+    int32_t posterior;        /* VIBO_POSTERIOR_*                                    */
+    int32_t missing_mode;     /* VIBO_MISSING_*                                      */
+    int32_t mask_dtype;       /* VIBO_MASK_*                                         */
+    int32_t reg_mode;         /* VIBO_REG_* (must be SAMPLED when n_flows > 0)       */
+    int32_t n_flows;          /* planar flows on the ability sample, 0..VIBO_MAX_FLOWS */
+    int32_t want_grad;        /* 0: forward heads only; 1: also gradients            */
+    int32_t deterministic;    /* 1: fixed-order reductions (bitwise reproducible)    */
+    int64_t response_row_stride; /* elements between consecutive rows of `response`  */
+    int64_t mask_row_stride;     /* elements between consecutive rows of `mask`      */
+} vibo_desc;
+
+/* Library / ABI version (VIBO_ABI_VERSION of the build). */
+int vibo_version(void);
+
+/* Message for the last non-zero return on this thread (host pointer, static storage). */
+const char* vibo_last_error_string(void);
+
+/* Workspace bytes vibo_elbo_fwd_bwd / vibo_encode need for `d` (0 on bad desc). */
+size_t vibo_workspace_bytes(const vibo_desc* d);
+
+/*
+ * Fused ELBO step over a minibatch of B persons: product-of-experts ability
+ * posterior, reparameterised sample (+ planar flows), 1PL/2PL/3PL link, masked
+ * Bernoulli log-likelihood and the ability-side regulariser, with the full
+ * backward pass in the same sweep (each response row is read from HBM once).
+ *
+ * Replaces, on the reference hot path (vibo.py:237-268):
+ *   AbilityInferenceNetwork / ConditionalAbilityInferenceNetwork.forward
+ *                                   (models.py:596-629, 652-661, 695-710)
+ *   product_of_experts              (utils.py:105-113)
+ *   reparameterize_gaussian         (models.py:506-510; eps supplied by caller)
+ *   NormalizingFlows.forward on the ability sample (flows.py:21-41, 58-66)
+ *   irt_model_1pl/2pl/3pl, decode   (models.py:729-766, 373-378)
+ *   masked_bernoulli_log_pdf(...).sum(), kl_divergence_standard_normal_prior,
+ *   normal_log_pdf / standard_normal_log_pdf of the ability
+ *                                   (models.py:399, 412-418, 428, 433-435)
+ *   and autograd's backward of all of the above (vibo.py:267).
+ *
+ * The per-(person,item) encoder MLP is NOT evaluated per cell: Bernoulli
+ * responses take two observed values, so the caller passes the encoder's
+ * outputs for inputs 0 and 1 as `table` and receives d/d table; the (tiny) MLP,
+ * the item-side reparameterisation / flows / KL and the optimizer stay with the
+ * caller.
+ *
+ *  response   [B rows x I] fp32, 1.0 = correct, 0.0 = wrong (missing cells: any value)
+ *  mask       [B rows x I] u8 or i64 per d->mask_dtype, nonzero = observed; NULL iff MASK_NONE
+ *  row_index  [B] int64 rows of response/mask to process, or NULL for rows 0..B-1
+ *  table      unconditional: [2][2A]    (row c = encoder([c]):      mu[0..A) | logvar[A..2A))
+ *             conditional:   [2][I][2A] (entry = encoder([c, item_i]))
+ *  item       [I][D] item sample d_i (after item flows if any): 2PL/3PL cols 0..A-1
+ *             discrimination, col A difficulty, col A+1 guess logit (3PL); 1PL col 0 difficulty
+ *  eps        [B][A] standard-normal draws for the ability reparameterisation
+ *  flow       [n_flows][2A+1]: uhat[A] | w[A] | b  (uhat = flows.py:23-25, computed by caller); NULL if none
+ *
+ *  out_scalars    [VIBO_NUM_SCALARS] fp32, see VIBO_S_*
+ *  ability_mu     [B][A]   posterior mean          (models.py:364-366)
+ *  ability_logvar [B][A]   posterior log-variance
+ *  ability        [B][A]   theta_0 = mu + exp(.5 logvar) * eps
+ *  ability_k      [B][A]   theta after flows (NULL allowed when n_flows == 0)
+ *  ability_ladj   [B]      sum_k log|det J_k|  (NULL allowed when n_flows == 0)
+ *  grad_table     [2] x table-shape: [0] = d LL / d table, [1] = d REG / d table
+ *  grad_item      [I][D]   d LL / d item
+ *  grad_flow      [2][n_flows][2A+1]: d LL / d flow, d REG / d flow (NULL if no flows)
+ *                 (grad_* may be NULL when d->want_grad == 0)
+ *
+ * The caller composes  loss = -LL + beta * REG + (item-side terms)  and the
+ * parameter gradients  -grad[0] + beta * grad[1]  (models.py:427-443).
+ */
+int vibo_elbo_fwd_bwd(const vibo_desc* d,
+                      const float* response, const void* mask, const int64_t* row_index,
+                      const float* table, const float* item, const float* eps,
+                      const float* flow,
+                      float* out_scalars,
+                      float* ability_mu, float* ability_logvar, float* ability,
+                      float* ability_k, float* ability_ladj,
+                      float* grad_table, float* grad_item, float* grad_flow,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Forward-only ability posterior q(theta | responses[, items]) for B persons
+ * (model.encode under no_grad: vibo.py:363-364, 406-407, 434-435; models.py:356-371).
+ * Arguments as above; writes ability_mu / ability_logvar [B][A].
+ */
+int vibo_encode(const vibo_desc* d,
+                const float* response, const void* mask, const int64_t* row_index,
+                const float* table,
+                float* ability_mu, float* ability_logvar,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * decode(): P(response = 1) for every (person, item) -> response_mu [B][I]
+ * (models.py:373-378, 529-533, 544-548; callers vibo.py:379, 409).
+ *  ability [B][A], item [I][D].
+ */
+int vibo_decode(const vibo_desc* d, const float* ability, const float* item,
+                float* response_mu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIBO_HIP_H */

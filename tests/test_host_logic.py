@@ -1,0 +1,162 @@
+"""Host logic of the drop-in modules on CPU: state_dict compatibility with the
+reference, loss / gradient composition around the fused op, the reference call
+pattern ``model.elbo(*model(response, mask))`` -- with the native entry points
+replaced by the CPU analytic restatement (oracle/cpu_backend.py).  The same
+assertions run against the real HIP kernel in tests/test_gpu_parity.py."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import cpu_backend
+from oracle import vibo_oracle as O
+from oracle import vibo_table_ref as T
+from vibo_amd import ops
+from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL, DeferredResponseMu
+
+CLS = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}
+
+
+@pytest.fixture()
+def cpu_ops():
+    restore = cpu_backend.install(ops)
+    yield
+    restore()
+
+
+def build_model(golden):
+    m = golden.meta
+    model = CLS[m['irt_model']](m['ability_dim'], m['num_item'], hidden_dim=m['hidden_dim'],
+                                ability_merge='product', conditional_posterior=m['conditional_posterior'],
+                                replace_missing_with_prior=m['replace_missing_with_prior'],
+                                n_norm_flows=m['n_norm_flows'])
+    model.load_state_dict(golden.sd, strict=True)      # same keys and shapes as the reference
+    return model
+
+
+def run_reference_pattern(model, golden, mask_dtype=torch.int64):
+    """vibo.py:239-267 call pattern with the golden's eps replayed."""
+    m = golden.meta
+    response = golden.response.unsqueeze(2)
+    mask = golden.mask.to(mask_dtype).unsqueeze(2)
+    outs = model(response, mask, eps_item=golden.eps_item, eps_ability=golden.eps_ability)
+    if m['n_norm_flows'] > 0:
+        (r, k, rmu, ak, a0, amu, alv, aladj, ik, i0, imu, ilv, iladj) = outs
+        loss = model.elbo(r, k, rmu, a0, amu, alv, i0, imu, ilv, annealing_factor=m['annealing_factor'],
+                          use_kl_divergence=False, ability_k=ak, item_feat_k=ik,
+                          ability_logabsdetjac=aladj, item_logabsdetjac=iladj)
+    else:
+        loss = model.elbo(*outs, annealing_factor=m['annealing_factor'],
+                          use_kl_divergence=m['use_kl_divergence'])
+    return outs, loss
+
+
+def check_against_golden(model, golden, outs, loss, tol_loss=1e-4, tol_grad=3e-4):
+    m = golden.meta
+    assert rel_err(loss.detach(), golden.out['loss']) < tol_loss
+    flows = m['n_norm_flows'] > 0
+    amu, alv, a0 = (outs[5], outs[6], outs[4]) if flows else (outs[4], outs[5], outs[3])
+    assert (amu.cpu() - golden.out['ability_mu']).abs().max() < 2e-5 * max(1.0, float(golden.out['ability_mu'].abs().max()))
+    assert (alv.cpu() - golden.out['ability_logvar']).abs().max() < 2e-5 * max(1.0, float(golden.out['ability_logvar'].abs().max()))
+    assert (a0.cpu() - golden.out['ability']).abs().max() < 5e-5 * max(1.0, float(golden.out['ability'].abs().max()))
+    if flows:
+        assert (outs[3].cpu() - golden.out['ability_k']).abs().max() < 1e-4
+        assert (outs[7].cpu() - golden.out['ability_logabsdetjac']).abs().max() < 1e-4
+    loss.backward()
+    for name, p in model.named_parameters():
+        g_ref = golden.grad[name]
+        g = p.grad.cpu() if p.grad is not None else torch.zeros_like(g_ref)
+        scale = float(g_ref.abs().max())
+        if scale == 0.0:
+            assert float(g.abs().max()) < 1e-6, name
+        else:
+            assert rel_err(g, g_ref) < tol_grad, name
+
+
+def test_state_dict_keys_match_reference(golden):
+    model = build_model(golden)
+    assert list(model.state_dict().keys()) == list(golden.sd.keys())
+
+
+def test_reference_call_pattern_matches_golden(cpu_ops, golden):
+    model = build_model(golden)
+    outs, loss = run_reference_pattern(model, golden)
+    assert isinstance(outs[2], DeferredResponseMu)
+    check_against_golden(model, golden, outs, loss)
+
+
+def test_mask_dtypes_equivalent(cpu_ops, golden):
+    model = build_model(golden)
+    _, l_i64 = run_reference_pattern(model, golden, torch.int64)
+    _, l_bool = run_reference_pattern(model, golden, torch.bool)
+    _, l_u8 = run_reference_pattern(model, golden, torch.uint8)
+    assert float(l_i64.detach()) == float(l_bool.detach()) == float(l_u8.detach())
+
+
+def test_decode_and_deferred_response_mu(cpu_ops, golden):
+    model = build_model(golden)
+    outs, _ = run_reference_pattern(model, golden)
+    rmu = outs[2].materialize()
+    assert rmu.shape == (golden.meta['num_person'], golden.meta['num_item'], 1)
+    assert (rmu.squeeze(2) - golden.out['response_mu']).abs().max() < 1e-5
+
+
+def test_table_ref_matches_autograd_oracle(golden):
+    """The analytic backward the kernel implements == autograd through the naive oracle."""
+    cfg = golden.cfg
+    if cfg['n_norm_flows'] > 0:
+        mode = 'sampled'
+    else:
+        mode = 'kl' if cfg['use_kl_divergence'] else 'sampled'
+    sd = {k: v.double() for k, v in golden.sd.items()}
+    A = cfg['ability_dim']
+    item_mu, item_lv = sd['item_encoder.mu_lookup.weight'], sd['item_encoder.logvar_lookup.weight']
+    item_feat = golden.eps_item.double() * torch.exp(0.5 * item_lv) + item_mu
+    flows = None
+    item_k = item_feat
+    if cfg['n_norm_flows'] > 0:
+        flows = [(T.flow_uhat(sd[f'ability_norm_flows.flows.{k}.u'], sd[f'ability_norm_flows.flows.{k}.w']),
+                  sd[f'ability_norm_flows.flows.{k}.w'], sd[f'ability_norm_flows.flows.{k}.b'])
+                 for k in range(cfg['n_norm_flows'])]
+        item_k, _ = O.planar_flows(sd, 'item_norm_flows', item_feat, cfg['n_norm_flows'])
+    table = T.encoder_table(sd, item_feat, cfg['conditional_posterior']).detach().requires_grad_(True)
+    item_leaf = item_k.detach().requires_grad_(True)
+    out = T.fused_elbo_ref(table.detach(), item_leaf.detach(), golden.response.double(), golden.mask,
+                           golden.eps_ability.double(), irt_model=cfg['irt_model'], ability_dim=A,
+                           conditional_posterior=cfg['conditional_posterior'],
+                           replace_missing_with_prior=cfg['replace_missing_with_prior'], mode=mode,
+                           flow_uhat_w_b=flows, exact_saturation=False)
+
+    # autograd version of the same heads from the op-by-op oracle pieces
+    B, I = golden.response.shape
+    resp, mask = golden.response.double(), golden.mask
+    x = (resp == 1).long()
+    k = (mask != 0).double().unsqueeze(2)
+    if cfg['conditional_posterior']:
+        idx = torch.arange(I).unsqueeze(0).expand(B, I)
+        m, s = table[x, idx, :A], table[x, idx, A:]
+    else:
+        m, s = table[x][..., :A], table[x][..., A:]
+    if cfg['replace_missing_with_prior']:
+        amu, alv = O.product_of_experts((m * k).permute(1, 0, 2), (s * k).permute(1, 0, 2))
+    else:
+        amu, alv = O.product_of_experts(m.permute(1, 0, 2), s.permute(1, 0, 2), weight=k.permute(1, 0, 2))
+    theta0 = golden.eps_ability.double() * torch.exp(0.5 * alv) + amu
+    theta, ladj = theta0, torch.zeros(B, dtype=torch.float64)
+    if flows:
+        for (uhat, w, b) in flows:
+            t = torch.tanh(theta @ w + b)
+            ladj = ladj + torch.log(torch.abs(1 + (1 - t * t) * torch.dot(w, uhat)) + 1e-8)
+            theta = theta + uhat.unsqueeze(0) * t.unsqueeze(1)
+    probs = O.irt_link(cfg['irt_model'], theta, item_leaf)
+    ll = O.masked_bernoulli_ll(resp, mask, probs).sum()
+    if mode == 'kl':
+        reg = O.kl_std_normal(amu, alv).sum()
+    else:
+        reg = O.normal_logpdf(theta0, amu, alv).sum() - ladj.sum() - O.std_normal_logpdf(theta).sum()
+    assert rel_err(out['ll'], ll.detach()) < 1e-9
+    assert rel_err(out['reg'], reg.detach()) < 1e-9
+    g_t0, g_i0 = torch.autograd.grad(ll, [table, item_leaf], retain_graph=True)
+    g_t1, = torch.autograd.grad(reg, [table], retain_graph=True)
+    assert rel_err(out['g_table'][0], g_t0) < 1e-8
+    assert rel_err(out['g_table'][1], g_t1) < 1e-8
+    assert rel_err(out['g_item'], g_i0) < 1e-8

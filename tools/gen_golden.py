@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (imported from
+/root/reference, build container only) on small seeded inputs.
+
+Only the resulting vectors (inputs + expected outputs) are committed; the
+reference source never enters this repo and this script is never run on the
+GPU box.  Shims needed to import/run the reference here:
+  * stub module ``nltk`` (imported, unused, not installed)
+  * ``Distribution.set_default_validate_args(False)`` (x = -1 under mask 0)
+  * PYTHONDONTWRITEBYTECODE so nothing is written under /root/reference
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+
+
+def import_reference():
+    sys.modules.setdefault('nltk', types.SimpleNamespace(word_tokenize=None))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    torch.distributions.Distribution.set_default_validate_args(False)
+    from src.torch_core import models as ref_models  # noqa
+    from src import utils as ref_utils  # noqa
+    return ref_models, ref_utils
+
+
+def make_data(irt, B, I, A, missing, seed):
+    """Synthetic 0/1 responses (-1 = missing) from a random IRT model."""
+    g = torch.Generator().manual_seed(seed)
+    D = {1: 1, 2: A + 1, 3: A + 2}[irt]
+    theta = torch.randn(B, A, generator=g)
+    item = torch.randn(I, D, generator=g)
+    if irt == 1:
+        logit = theta.sum(1, keepdim=True) + item.t()
+    else:
+        logit = theta @ (-item[:, :A].t()) + item[:, A:A + 1].t()
+    p = torch.sigmoid(logit)
+    if irt == 3:
+        gs = torch.sigmoid(item[:, A + 1:A + 2]).t()
+        p = gs + (1 - gs) * p
+    resp = torch.bernoulli(p, generator=g)
+    mask = torch.ones(B, I, dtype=torch.bool)
+    if missing > 0:
+        drop = torch.rand(B, I, generator=g) < missing
+        # make sure at least one row is fully observed and one row is nearly empty
+        drop[0] = False
+        if B > 2:
+            drop[1] = True
+            drop[1, I // 2] = False
+        resp = torch.where(drop, torch.full_like(resp, -1.0), resp)
+        mask = ~drop
+    return resp, mask
+
+
+CASES = [
+    # name, irt, A, B, I, cond, missing, drop, flows, beta, use_kl
+    ('2pl_a1_uncond',            2, 1, 16, 20, False, 0.0, False, 0, 1.0, True),
+    ('2pl_a1_uncond_beta05',     2, 1, 37, 95, False, 0.0, False, 0, 0.5, True),
+    ('2pl_a8_uncond',            2, 8, 37, 130, False, 0.0, False, 0, 1.0, True),
+    ('2pl_a2_uncond_miss_prior', 2, 2, 37, 95, False, 0.2, False, 0, 1.0, True),
+    ('2pl_a1_uncond_miss_drop',  2, 1, 37, 95, False, 0.2, True, 0, 1.0, True),
+    ('2pl_a8_uncond_miss_prior', 2, 8, 16, 130, False, 0.2, False, 0, 0.5, True),
+    ('2pl_a3_uncond_nokl',       2, 3, 16, 20, False, 0.0, False, 0, 1.0, False),
+    ('2pl_a1_uncond_miss_nokl',  2, 1, 16, 95, False, 0.2, False, 0, 1.0, False),
+    ('1pl_a1_uncond',            1, 1, 16, 20, False, 0.0, False, 0, 1.0, True),
+    ('1pl_a2_uncond_miss_prior', 1, 2, 37, 95, False, 0.2, False, 0, 1.0, True),
+    ('3pl_a1_uncond',            3, 1, 37, 95, False, 0.0, False, 0, 1.0, True),
+    ('3pl_a2_uncond_miss_drop',  3, 2, 16, 130, False, 0.2, True, 0, 0.5, True),
+    ('3pl_a8_uncond_miss_prior', 3, 8, 16, 20, False, 0.2, False, 0, 1.0, True),
+    ('2pl_a1_cond',              2, 1, 16, 20, True, 0.0, False, 0, 1.0, True),
+    ('2pl_a2_cond_miss_prior',   2, 2, 37, 95, True, 0.2, False, 0, 1.0, True),
+    ('3pl_a1_cond_miss_drop',    3, 1, 16, 130, True, 0.2, True, 0, 0.5, True),
+    ('1pl_a1_cond',              1, 1, 16, 20, True, 0.0, False, 0, 1.0, True),
+    ('2pl_a1_uncond_flows4',     2, 1, 16, 20, False, 0.0, False, 4, 1.0, False),
+    ('2pl_a2_uncond_flows2_miss', 2, 2, 37, 95, False, 0.2, False, 2, 1.0, False),
+    ('3pl_a1_cond_flows4',       3, 1, 16, 130, True, 0.0, False, 4, 1.0, False),
+    ('3pl_a1_cond_flows4_miss',  3, 1, 37, 95, True, 0.2, False, 4, 1.0, False),
+    ('2pl_a8_cond_miss_prior',   2, 8, 16, 20, True, 0.2, False, 0, 1.0, True),
+]
+
+
+def run_case(ref_models, case, out_dir):
+    name, irt, A, B, I, cond, missing, drop, flows, beta, use_kl = case
+    seed = 1000 + sum(ord(c) for c in name)
+    resp, mask = make_data(irt, B, I, A, missing, seed)
+    cls = {1: ref_models.VIBO_1PL, 2: ref_models.VIBO_2PL, 3: ref_models.VIBO_3PL}[irt]
+    torch.manual_seed(seed)
+    model = cls(A, I, hidden_dim=64, ability_merge='product', conditional_posterior=cond,
+                generative_model='irt', response_dist='bernoulli',
+                replace_missing_with_prior=not drop, n_norm_flows=flows)
+    D = model.item_feat_dim
+
+    # eps in the reference's draw order: item [I,D] first, then ability [B,A]
+    torch.manual_seed(seed + 1)
+    eps_item = torch.randn(I, D)
+    eps_ability = torch.randn(B, A)
+    torch.manual_seed(seed + 1)
+
+    r3 = resp.unsqueeze(2)
+    m3 = mask.long().unsqueeze(2)
+    model.zero_grad()
+    outs = model(r3, m3)
+    if flows > 0:
+        (_, _, response_mu, ability_k, ability, ability_mu, ability_logvar, a_ladj,
+         item_k, item_feat, item_mu, item_lv, i_ladj) = outs
+        loss = model.elbo(r3, m3, response_mu, ability, ability_mu, ability_logvar,
+                          item_feat, item_mu, item_lv, annealing_factor=beta,
+                          use_kl_divergence=False, ability_k=ability_k, item_feat_k=item_k,
+                          ability_logabsdetjac=a_ladj, item_logabsdetjac=i_ladj)
+    else:
+        (_, _, response_mu, ability, ability_mu, ability_logvar,
+         item_feat, item_mu, item_lv) = outs
+        loss = model.elbo(*outs, annealing_factor=beta, use_kl_divergence=use_kl)
+    loss.backward()
+
+    # sanity: the eps replay really is what the reference drew
+    chk = eps_ability * torch.exp(0.5 * ability_logvar) + ability_mu
+    assert torch.allclose(chk, ability, atol=1e-6), name
+    chk = eps_item * torch.exp(0.5 * item_lv) + item_mu
+    assert torch.allclose(chk, item_feat, atol=1e-6), name
+
+    rec = {
+        'meta': json.dumps(dict(name=name, irt_model=irt, ability_dim=A, num_person=B, num_item=I,
+                                conditional_posterior=cond, missing_frac=missing,
+                                replace_missing_with_prior=not drop, n_norm_flows=flows,
+                                annealing_factor=beta, use_kl_divergence=use_kl,
+                                hidden_dim=64, torch=torch.__version__)),
+        'response': resp.numpy().astype(np.int8),
+        'mask': mask.numpy().astype(np.uint8),
+        'eps_item': eps_item.numpy(),
+        'eps_ability': eps_ability.numpy(),
+        'out.loss': loss.detach().numpy(),
+        'out.ability': ability.detach().numpy(),
+        'out.ability_mu': ability_mu.detach().numpy(),
+        'out.ability_logvar': ability_logvar.detach().numpy(),
+        'out.item_feat': item_feat.detach().numpy(),
+        'out.response_mu': response_mu.detach().squeeze(2).numpy(),
+    }
+    if flows > 0:
+        rec['out.ability_k'] = ability_k.detach().numpy()
+        rec['out.ability_logabsdetjac'] = a_ladj.detach().numpy()
+        rec['out.item_feat_k'] = item_k.detach().numpy()
+        rec['out.item_feat_logabsdetjac'] = i_ladj.detach().numpy()
+    for k, v in model.state_dict().items():
+        rec['sd.' + k] = v.detach().numpy().copy()
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        rec['grad.' + k] = g.detach().numpy().copy()
+
+    # parameters after 1 and 3 Adam steps (vibo.py:221, 243-268) re-using the same batch/eps
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    for step in range(3):
+        torch.manual_seed(seed + 1)
+        opt.zero_grad()
+        outs = model(r3, m3)
+        if flows > 0:
+            (_, _, rmu, ak, a0, amu, alv, aladj, ik, i0, imu, ilv, iladj) = outs
+            l = model.elbo(r3, m3, rmu, a0, amu, alv, i0, imu, ilv, annealing_factor=beta,
+                           use_kl_divergence=False, ability_k=ak, item_feat_k=ik,
+                           ability_logabsdetjac=aladj, item_logabsdetjac=iladj)
+        else:
+            l = model.elbo(*outs, annealing_factor=beta, use_kl_divergence=use_kl)
+        l.backward()
+        opt.step()
+        if step in (0, 2):
+            for k, v in model.state_dict().items():
+                rec[f'adam{step + 1}.' + k] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, f'case_{name}.npz'), **rec)
+    return float(loss.detach())
+
+
+def saturation_case(ref_utils, out_dir):
+    """masked_bernoulli_log_pdf(sigmoid(l)) and its gradient for l in [-30, 30]
+    plus dense sweeps around the clamp thresholds (utils.py:46-49)."""
+    l = torch.cat([
+        torch.linspace(-30, 30, 2401, dtype=torch.float64),
+        torch.linspace(-15.96, -15.92, 801, dtype=torch.float64),
+        torch.linspace(16.60, 16.66, 1201, dtype=torch.float64),
+    ]).float()
+    rec = {'logit': l.numpy()}
+    for x in (0.0, 1.0):
+        lv = l.clone().requires_grad_(True)
+        ll = ref_utils.masked_bernoulli_log_pdf(torch.full_like(lv, x), torch.ones_like(lv),
+                                                torch.sigmoid(lv))
+        g, = torch.autograd.grad(ll.sum(), lv)
+        rec[f'll_x{int(x)}'] = ll.detach().numpy()
+        rec[f'dll_dlogit_x{int(x)}'] = g.numpy()
+    np.savez_compressed(os.path.join(out_dir, 'saturation.npz'), **rec)
+
+
+def log_marginal_case(ref_models, out_dir):
+    """log_marginal (models.py:445-504) with S=8 under a fixed seed; the eps
+    sequence (item then ability, per sample) is stored so it can be replayed."""
+    for name, irt, A, B, I, cond, missing, flows in (
+            ('logmarg_2pl_a2', 2, 2, 16, 20, False, 0.2, 0),
+            ('logmarg_3pl_a1_cond_flows2', 3, 1, 16, 20, True, 0.0, 2)):
+        seed = 77 + len(name)
+        resp, mask = make_data(irt, B, I, A, missing, seed)
+        cls = {1: ref_models.VIBO_1PL, 2: ref_models.VIBO_2PL, 3: ref_models.VIBO_3PL}[irt]
+        torch.manual_seed(seed)
+        model = cls(A, I, ability_merge='product', conditional_posterior=cond, n_norm_flows=flows)
+        D = model.item_feat_dim
+        S = 8
+        torch.manual_seed(seed + 5)
+        ei, ea = [], []
+        for _ in range(S):
+            ei.append(torch.randn(I, D))
+            ea.append(torch.randn(B, A))
+        torch.manual_seed(seed + 5)
+        logp = model.log_marginal(resp.unsqueeze(2), mask.long().unsqueeze(2), num_samples=S)
+        rec = {
+            'meta': json.dumps(dict(name=name, irt_model=irt, ability_dim=A, num_person=B, num_item=I,
+                                    conditional_posterior=cond, missing_frac=missing,
+                                    replace_missing_with_prior=True, n_norm_flows=flows,
+                                    num_samples=S, hidden_dim=64)),
+            'response': resp.numpy().astype(np.int8), 'mask': mask.numpy().astype(np.uint8),
+            'eps_item': torch.stack(ei).numpy(), 'eps_ability': torch.stack(ea).numpy(),
+            'out.logp': logp.detach().numpy(),
+        }
+        for k, v in model.state_dict().items():
+            rec['sd.' + k] = v.detach().numpy()
+        np.savez_compressed(os.path.join(out_dir, f'{name}.npz'), **rec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    os.makedirs(out_dir, exist_ok=True)
+    ref_models, ref_utils = import_reference()
+    for case in CASES:
+        loss = run_case(ref_models, case, out_dir)
+        print(f'{case[0]:34s} loss={loss:.6f}')
+    saturation_case(ref_utils, out_dir)
+    log_marginal_case(ref_models, out_dir)
+    print('wrote', out_dir)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,395 @@
+// vibo_capi.hip -- C ABI of libvibo_hip.so (see include/vibo_hip.h) plus the small
+// helper kernels around the fused ELBO kernel: item prep, partial finalize,
+// forward-only encode, decode.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vibo_hip.h"
+#include "vibo_device.hpp"
+#include "vibo_launch.hpp"
+#include "vibo_params.hpp"
+
+namespace vibo {
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e > 0 ? (int)e : 999;
+}
+
+static int item_feat_dim(int irt, int A) { return irt == 1 ? 1 : (irt == 2 ? A + 1 : A + 2); }
+
+static int check_desc(const vibo_desc* d) {
+    if (!d) return fail(-1, "null descriptor");
+    if (d->abi_version != VIBO_ABI_VERSION) return fail(-2, "abi_version %d != %d", d->abi_version, VIBO_ABI_VERSION);
+    if (d->num_person < 1) return fail(-3, "num_person must be >= 1");
+    if (d->num_item < 1) return fail(-3, "num_item must be >= 1");
+    if (d->ability_dim < 1 || d->ability_dim > VIBO_MAX_ABILITY_DIM)
+        return fail(-3, "ability_dim %d outside 1..%d", d->ability_dim, VIBO_MAX_ABILITY_DIM);
+    if (d->irt_model < 1 || d->irt_model > 3) return fail(-3, "irt_model must be 1, 2 or 3");
+    if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL && d->posterior != VIBO_POSTERIOR_CONDITIONAL)
+        return fail(-3, "bad posterior");
+    if (d->missing_mode != VIBO_MISSING_PRIOR && d->missing_mode != VIBO_MISSING_DROP) return fail(-3, "bad missing_mode");
+    if (d->mask_dtype < 0 || d->mask_dtype > 2) return fail(-3, "bad mask_dtype");
+    if (d->reg_mode != VIBO_REG_KL && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "bad reg_mode");
+    if (d->n_flows < 0 || d->n_flows > VIBO_MAX_FLOWS) return fail(-3, "n_flows outside 0..%d", VIBO_MAX_FLOWS);
+    if (d->n_flows > 0 && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "flows need reg_mode SAMPLED");
+    return 0;
+}
+
+struct Plan {
+    int AT, D, DP, item_blocks, n_tiles, nblk;
+    LaunchGeom geom;
+    PartialLayout lay;
+    size_t off_item_prep, off_partial, total_bytes;
+};
+
+static int g_num_cu = 0;
+
+static int make_plan(const vibo_desc* d, Plan* pl) {
+    const int I = d->num_item, A = d->ability_dim;
+    pl->AT = padded_ability_dim(A);
+    pl->D = item_feat_dim(d->irt_model, A);
+    pl->DP = prepped_item_width(d->irt_model, pl->AT);
+    pl->item_blocks = (I + 63) / 64;
+    pl->n_tiles = (d->num_person + kTilePersons - 1) / kTilePersons;
+    if (I > 2048) return fail(-4, "num_item %d > 2048 is not supported by the fused kernel yet", I);
+    int stride = (I + 15) & ~15;
+    if (((stride / 16) & 1) == 0) stride += 16;   // odd multiple of 16 B: conflict-free ds_read_b128 across rows
+    int geo, waves;
+    if (I <= 512) { geo = 2; waves = 2; }
+    else if (I <= 1024) { geo = 0; waves = 8; }
+    else { geo = 1; waves = 8; }
+    size_t lds = (size_t)kTilePersons * stride + 2 * kTilePersons * 4 + 4 * 2 * pl->AT * 4;
+    const size_t red = (size_t)waves * (8 + 4 * pl->AT) * 4;
+    if (lds < red) lds = red;
+    lds = (lds + 255) & ~(size_t)255;
+    if (g_num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cu = n;
+        else
+            g_num_cu = 256;
+    }
+    const size_t lds_cu = 160 * 1024;
+    int per_cu = (int)(lds_cu / lds);
+    const int wave_cap = 16 / waves;             // 4 waves per SIMD (launch bound) = 16 per CU
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) per_cu = 1;
+    int nblk = g_num_cu * per_cu;
+    if (nblk > pl->n_tiles) nblk = pl->n_tiles;
+    pl->nblk = nblk;
+    pl->geom.geo = geo;
+    pl->geom.waves = waves;
+    pl->geom.grid = nblk;
+    pl->geom.lds_bytes = lds;
+    pl->lay = partial_layout(A, pl->D, I, d->n_flows);
+    pl->off_item_prep = 0;
+    size_t prep_bytes = ((size_t)I * pl->DP * 4 + 255) & ~(size_t)255;
+    pl->off_partial = prep_bytes;
+    pl->total_bytes = prep_bytes + (size_t)nblk * pl->lay.stride * 4 + 256;
+    return stride;
+}
+
+// ---------------------------------------------------------------------------
+// item prep: [I][D] item sample -> [I][DP] rows the fused kernel reads with scalar loads
+// ---------------------------------------------------------------------------
+__global__ void item_prep_kernel(const float* __restrict__ item, float* __restrict__ prep, int I, int A, int AT,
+                                 int D, int DP, int irt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    const float* src = item + (size_t)i * D;
+    float* dst = prep + (size_t)i * DP;
+    if (irt == 1) {
+        dst[0] = src[0];
+        return;
+    }
+    for (int a = 0; a < DP; ++a) dst[a] = 0.f;
+    for (int a = 0; a < A; ++a) dst[a] = -src[a];   // logit = -a.theta + b   (models.py:744,759)
+    dst[AT] = src[A];
+    if (irt == 3) {
+        const float g = 1.0f / (1.0f + expf(-src[A + 1]));   // guess = sigmoid(guess logit) (models.py:758)
+        dst[AT + 1] = g;
+        dst[AT + 2] = 1.0f - g;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// finalize: fixed-order sum of the per-block partial records (fp64 accumulate)
+// ---------------------------------------------------------------------------
+__global__ void finalize_kernel(const FinalizeParams f) {
+    // element e of the logical output vector: [0,8) scalars | table grads | flow grads | item grads
+    const int n_tab = 8 * f.A;
+    const int n_flow = 2 * f.n_flows * (2 * f.A + 1);
+    const int n_item = f.I * f.D;
+    const int n_out = 8 + (f.want_grad ? n_tab + n_flow + n_item : 0);
+    // 64 outputs x 4 slices of blocks per workgroup
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    __shared__ double part[4][64];
+    double acc = 0.0;
+    int src = -1;
+    if (e < n_out) {
+        if (e < 8 + n_tab + n_flow) {
+            src = e;   // same offsets in the partial record (off_table = 8, off_flow = 8 + 8A)
+        } else {
+            const int k = e - (8 + n_tab + n_flow);
+            const int i = k / f.D, dd = k % f.D;
+            src = f.lay.off_item + dd * f.lay.i_pad + i;
+        }
+        for (int b = slice; b < f.nblk; b += 4) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
+    }
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && e < n_out) {
+        const double t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        if (e < 8) {
+            // partial scalars: 0 ll, 1 kl, 2 logq0, 3 logp, 4 ladj, 5 nobs
+            part[0][lane] = t;
+        } else if (e < 8 + n_tab) {
+            f.grad_table[e - 8] = (float)t;
+        } else if (e < 8 + n_tab + n_flow) {
+            f.grad_flow[e - 8 - n_tab] = (float)t;
+        } else {
+            f.grad_item[e - 8 - n_tab - n_flow] = (float)t;
+        }
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double ll = part[0][0], kl = part[0][1], logq0 = part[0][2], logp = part[0][3], ladj = part[0][4];
+            f.out_scalars[VIBO_S_LL] = (float)ll;
+            f.out_scalars[VIBO_S_REG] = (float)(f.reg_mode == VIBO_REG_KL ? kl : (logq0 - ladj - logp));
+            f.out_scalars[VIBO_S_KL] = (float)kl;
+            f.out_scalars[VIBO_S_LOGQ0] = (float)logq0;
+            f.out_scalars[VIBO_S_LOGP] = (float)logp;
+            f.out_scalars[VIBO_S_LADJ] = (float)ladj;
+            f.out_scalars[VIBO_S_NOBS] = (float)part[0][5];
+            f.out_scalars[VIBO_S_RESERVED] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward-only encode: one wave per person (models.py:356-371 under no_grad)
+// ---------------------------------------------------------------------------
+struct EncodeParams {
+    const float* response;
+    const void* mask;
+    const int64_t* row_index;
+    const float* table;
+    float* ability_mu;
+    float* ability_logvar;
+    long long resp_stride, mask_stride;
+    int B, I, A, mask_dtype, missing_mode, conditional;
+};
+
+__global__ __launch_bounds__(256) void encode_kernel(const EncodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B) return;
+    const long long src = p.row_index ? p.row_index[row] : row;
+    const float* rp = p.response + src * p.resp_stride;
+    const int A = p.A, I = p.I;
+    float lam[VIBO_MAX_ABILITY_DIM], smu[VIBO_MAX_ABILITY_DIM];
+#pragma unroll
+    for (int a = 0; a < VIBO_MAX_ABILITY_DIM; ++a) lam[a] = smu[a] = 0.f;
+    const float tau_prior = 1.0f / (1.0f + kPoeEps);
+    for (int i = lane; i < I; i += 64) {
+        bool k;
+        if (p.mask_dtype == VIBO_MASK_U8) k = static_cast<const uint8_t*>(p.mask)[src * p.mask_stride + i] != 0;
+        else if (p.mask_dtype == VIBO_MASK_I64) k = static_cast<const int64_t*>(p.mask)[src * p.mask_stride + i] != 0;
+        else k = true;
+        const int c = (rp[i] == 1.0f) ? 1 : 0;
+        const float* te = p.conditional ? p.table + ((size_t)c * I + i) * 2 * A : p.table + (size_t)c * 2 * A;
+#pragma unroll
+        for (int a = 0; a < VIBO_MAX_ABILITY_DIM; ++a) {
+            if (a < A) {
+                if (k) {
+                    const float tau = 1.0f / (__expf(te[A + a]) + kPoeEps);
+                    lam[a] += tau;
+                    smu[a] = fmaf(te[a], tau, smu[a]);
+                } else if (p.missing_mode == VIBO_MISSING_PRIOR) {
+                    lam[a] += tau_prior;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < VIBO_MAX_ABILITY_DIM; ++a) {
+        if (a < A) {
+            const float L = wave_total(lam[a]);
+            const float S = wave_total(smu[a]);
+            if (lane == 0) {
+                p.ability_mu[row * A + a] = S / L;
+                p.ability_logvar[row * A + a] = logf(1.0f / L);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// decode: response_mu[B][I] (models.py:729-766)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ ability, const float* __restrict__ item,
+                                                     float* __restrict__ out, int B, int I, int A, int D, int irt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = blockIdx.y;
+    if (i >= I) return;
+    const float* th = ability + b * A;
+    const float* it = item + (size_t)i * D;
+    float logit;
+    if (irt == 1) {
+        logit = it[0];
+        for (int a = 0; a < A; ++a) logit += th[a];
+    } else {
+        logit = it[A];
+        for (int a = 0; a < A; ++a) logit = fmaf(-it[a], th[a], logit);
+    }
+    float pr = 1.0f / (1.0f + expf(-logit));
+    if (irt == 3) {
+        const float g = 1.0f / (1.0f + expf(-it[A + 1]));
+        pr = g + (1.0f - g) * pr;
+    }
+    out[b * I + i] = pr;
+}
+
+}  // namespace vibo
+
+using namespace vibo;
+
+extern "C" {
+
+int vibo_version(void) { return VIBO_ABI_VERSION; }
+
+const char* vibo_last_error_string(void) { return g_err; }
+
+size_t vibo_workspace_bytes(const vibo_desc* d) {
+    if (check_desc(d) != 0) return 0;
+    Plan pl;
+    if (make_plan(d, &pl) < 0) return 0;
+    return pl.total_bytes;
+}
+
+int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index,
+                      const float* table, const float* item, const float* eps, const float* flow,
+                      float* out_scalars, float* ability_mu, float* ability_logvar, float* ability,
+                      float* ability_k, float* ability_ladj, float* grad_table, float* grad_item,
+                      float* grad_flow, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!response || !table || !item || !eps || !out_scalars || !ability_mu || !ability_logvar || !ability)
+        return fail(-5, "null required pointer");
+    if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
+    if (d->want_grad && (!grad_table || !grad_item)) return fail(-5, "want_grad needs grad_table and grad_item");
+    if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL)
+        return fail(-6, "conditional posterior is not implemented in the fused kernel yet");
+    if (d->n_flows != 0) return fail(-6, "planar flows are not implemented in the fused kernel yet");
+    (void)flow; (void)ability_k; (void)ability_ladj; (void)grad_flow;
+    Plan pl;
+    const int stride = make_plan(d, &pl);
+    if (stride < 0) return stride;
+    if (!workspace || workspace_bytes < pl.total_bytes)
+        return fail(-7, "workspace too small: %zu < %zu", workspace_bytes, pl.total_bytes);
+    if ((uintptr_t)workspace & 255) return fail(-7, "workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int I = d->num_item, A = d->ability_dim;
+
+    float* item_prep = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_item_prep);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_partial);
+    hipLaunchKernelGGL(item_prep_kernel, dim3((I + 255) / 256), dim3(256), 0, s, item, item_prep, I, A, pl.AT, pl.D,
+                       pl.DP, d->irt_model);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "item_prep launch");
+
+    ElboParams p;
+    memset(&p, 0, sizeof(p));
+    p.response = response; p.mask = mask; p.row_index = row_index;
+    p.table = table; p.item_prep = item_prep; p.eps = eps;
+    p.ability_mu = ability_mu; p.ability_logvar = ability_logvar; p.ability = ability;
+    p.partial = partial;
+    p.resp_stride = d->response_row_stride; p.mask_stride = d->mask_row_stride;
+    p.B = d->num_person; p.I = I; p.A = A; p.D = pl.D; p.DP = pl.DP;
+    p.n_tiles = pl.n_tiles; p.item_blocks = pl.item_blocks; p.lds_stride = stride;
+    p.mask_dtype = d->mask_dtype; p.missing_mode = d->missing_mode; p.reg_mode = d->reg_mode;
+    p.lay = pl.lay;
+    bool vec = (I % 4 == 0) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
+    if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
+    if (d->mask_dtype == VIBO_MASK_I64) vec = vec && (d->mask_row_stride % 2 == 0) && (((uintptr_t)mask & 15) == 0);
+    p.vec_ok = vec ? 1 : 0;
+
+    const bool grad = d->want_grad != 0;
+    switch (pl.AT) {
+        case 1: e = launch_elbo_a1(p, d->irt_model, grad, pl.geom, s); break;
+        case 2: e = launch_elbo_a2(p, d->irt_model, grad, pl.geom, s); break;
+        case 4: e = launch_elbo_a4(p, d->irt_model, grad, pl.geom, s); break;
+        default: e = launch_elbo_a8(p, d->irt_model, grad, pl.geom, s); break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "elbo kernel launch");
+
+    FinalizeParams f;
+    memset(&f, 0, sizeof(f));
+    f.partial = partial; f.out_scalars = out_scalars; f.grad_table = grad_table; f.grad_item = grad_item;
+    f.grad_flow = grad_flow;
+    f.nblk = pl.nblk; f.I = I; f.A = A; f.D = pl.D; f.n_flows = d->n_flows; f.reg_mode = d->reg_mode;
+    f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
+    const int n_out = 8 + (grad ? 8 * A + 2 * d->n_flows * (2 * A + 1) + I * pl.D : 0);
+    hipLaunchKernelGGL(finalize_kernel, dim3((n_out + 63) / 64), dim3(256), 0, s, f);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "finalize launch");
+    return 0;
+}
+
+int vibo_encode(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index,
+                const float* table, float* ability_mu, float* ability_logvar, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!response || !table || !ability_mu || !ability_logvar) return fail(-5, "null required pointer");
+    if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
+    EncodeParams p;
+    memset(&p, 0, sizeof(p));
+    p.response = response; p.mask = mask; p.row_index = row_index; p.table = table;
+    p.ability_mu = ability_mu; p.ability_logvar = ability_logvar;
+    p.resp_stride = d->response_row_stride; p.mask_stride = d->mask_row_stride;
+    p.B = d->num_person; p.I = d->num_item; p.A = d->ability_dim;
+    p.mask_dtype = d->mask_dtype; p.missing_mode = d->missing_mode;
+    p.conditional = d->posterior == VIBO_POSTERIOR_CONDITIONAL;
+    hipLaunchKernelGGL(encode_kernel, dim3((d->num_person + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "encode launch");
+    return 0;
+}
+
+int vibo_decode(const vibo_desc* d, const float* ability, const float* item, float* response_mu, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!ability || !item || !response_mu) return fail(-5, "null required pointer");
+    if (d->num_person > 65535 * 1024) return fail(-3, "num_person too large for decode grid");
+    const int I = d->num_item, A = d->ability_dim, D = item_feat_dim(d->irt_model, A);
+    // grid.y is limited to 65535: loop in chunks
+    const long long B = d->num_person;
+    for (long long b0 = 0; b0 < B; b0 += 65535) {
+        const int nb = (int)((B - b0 < 65535) ? (B - b0) : 65535);
+        hipLaunchKernelGGL(decode_kernel, dim3((I + 255) / 256, nb), dim3(256), 0, (hipStream_t)stream,
+                           ability + b0 * A, item, response_mu + b0 * I, nb, I, A, D, d->irt_model);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "decode launch");
+    return 0;
+}
+
+}  // extern "C"

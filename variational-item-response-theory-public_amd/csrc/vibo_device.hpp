@@ -1,0 +1,74 @@
+// vibo_device.hpp -- small device helpers shared by the VIBO kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vibo {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kLog2Pi = 1.8378770664093453f;
+// torch.distributions.Bernoulli clamps probs to [eps32, 1-eps32] (utils.py:46-49):
+constexpr float kEps32 = 1.1920928955078125e-07f;
+constexpr float kLogitLo = 15.942384719848633f;   // sigmoid(l) < eps32 below -kLogitLo
+constexpr float kLogitHi = 16.635532333438686f;   // 24 ln 2: 1/(1+exp(-l)) rounds to 1.0f above
+constexpr float kPoeEps = 1e-8f;                  // product_of_experts eps (utils.py:105)
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// Read-only, wave-uniform data (item parameters) is fetched through the scalar
+// cache: a pointer in the constant address space makes hipcc emit s_load_dword*
+// instead of per-lane vector loads.
+typedef const __attribute__((address_space(4))) float* const_f32_ptr;
+__device__ __forceinline__ const_f32_ptr as_constant(const float* p) {
+    return (const_f32_ptr)(uintptr_t)p;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// DPP move with the lanes a row_mask disables reading `old` (= 0 here).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (read lane 63).
+__device__ __forceinline__ float wave_sum63(float v) {
+    v += dpp_f<0xb1>(v);         // quad_perm [1,0,3,2]
+    v += dpp_f<0x4e>(v);         // quad_perm [2,3,0,1]
+    v += dpp_f<0x124>(v);        // row_ror 4
+    v += dpp_f<0x128>(v);        // row_ror 8
+    v += dpp_f<0x142, 0xa>(v);   // row_bcast 15 -> rows 1,3
+    v += dpp_f<0x143, 0xc>(v);   // row_bcast 31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ int wave_sum63(int v) {
+    v += dpp_i<0xb1>(v);
+    v += dpp_i<0x4e>(v);
+    v += dpp_i<0x124>(v);
+    v += dpp_i<0x128>(v);
+    v += dpp_i<0x142, 0xa>(v);
+    v += dpp_i<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ float lane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ float wave_total(float v) { return lane63(wave_sum63(v)); }
+
+// One fp8(e4m3) byte of a packed word -> f32.  Codes used: 0x38 = +1, 0xB8 = -1, 0x00 = 0.
+template <int SEL>
+__device__ __forceinline__ float code_to_f32(uint32_t word) {
+    return __builtin_amdgcn_cvt_f32_fp8((int)word, SEL);
+}
+
+}  // namespace vibo

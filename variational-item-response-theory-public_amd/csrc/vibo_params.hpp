@@ -1,0 +1,72 @@
+// vibo_params.hpp -- host/device shared launch parameters and workspace layout.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vibo {
+
+constexpr int kTilePersons = 64;   // persons per tile = lanes per wave
+constexpr int kMaxSlots = 4;       // 64-item blocks one wave owns (registers for item grads)
+
+// template ability width for a runtime ability_dim (1,2,4,8)
+inline int padded_ability_dim(int a) { return a <= 1 ? 1 : a <= 2 ? 2 : a <= 4 ? 4 : 8; }
+
+// floats per prepped item row (see item_prep_kernel):
+//   1PL: [b]                       2PL: [-a_0..-a_{AT-1}, b, 0..]
+//   3PL: [-a_0..-a_{AT-1}, b, guess, 1-guess, 0..]
+inline int prepped_item_width(int irt, int at) {
+    if (irt == 1) return 1;
+    if (at == 1) return irt == 2 ? 2 : 4;
+    if (at == 2) return irt == 2 ? 4 : 8;
+    if (at == 4) return 8;
+    return 12;
+}
+
+// per-block partial record, in floats:
+//   [0,8)  scalars: ll, kl, logq0, logp, ladj, nobs, 0, 0
+//   table grads  [set 2][c 2][2*A]          (unconditional posterior)
+//   flow grads   [set 2][n_flows][2*A+1]
+//   item grads   [D][I_pad]  (structure of arrays; I_pad = 64 * item blocks)
+struct PartialLayout {
+    int off_table, off_flow, off_item, stride, i_pad;
+};
+inline PartialLayout partial_layout(int A, int D, int I, int n_flows) {
+    PartialLayout L;
+    L.i_pad = ((I + 63) / 64) * 64;
+    L.off_table = 8;
+    L.off_flow = L.off_table + 8 * A;
+    L.off_item = L.off_flow + 2 * n_flows * (2 * A + 1);
+    L.stride = L.off_item + D * L.i_pad;
+    L.stride = (L.stride + 3) & ~3;
+    return L;
+}
+
+struct ElboParams {
+    const float* response;
+    const void* mask;
+    const int64_t* row_index;
+    const float* table;       // [2][2A]
+    const float* item_prep;   // [I][DP] prepped item rows (workspace)
+    const float* eps;         // [B][A]
+    float* ability_mu;
+    float* ability_logvar;
+    float* ability;
+    float* partial;           // [nblk][stride]
+    long long resp_stride, mask_stride;
+    int B, I, A, D, DP;
+    int n_tiles, item_blocks, lds_stride;
+    int mask_dtype, missing_mode, reg_mode, vec_ok;
+    PartialLayout lay;
+};
+
+struct FinalizeParams {
+    const float* partial;
+    float* out_scalars;
+    float* grad_table;
+    float* grad_item;
+    float* grad_flow;
+    int nblk, I, A, D, n_flows, reg_mode, irt, want_grad;
+    PartialLayout lay;
+};
+
+}  // namespace vibo

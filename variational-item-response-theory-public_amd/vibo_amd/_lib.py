@@ -1,0 +1,92 @@
+"""ctypes binding of libvibo_hip.so (C ABI declared in include/vibo_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the HIP library is
+missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+ABI_VERSION = 1
+NUM_SCALARS = 8
+S_LL, S_REG, S_KL, S_LOGQ0, S_LOGP, S_LADJ, S_NOBS = 0, 1, 2, 3, 4, 5, 6
+
+IRT_1PL, IRT_2PL, IRT_3PL = 1, 2, 3
+POSTERIOR_UNCONDITIONAL, POSTERIOR_CONDITIONAL = 0, 1
+MISSING_PRIOR, MISSING_DROP = 0, 1
+MASK_U8, MASK_I64, MASK_NONE = 0, 1, 2
+REG_KL, REG_SAMPLED = 0, 1
+MAX_ABILITY_DIM = 8
+MAX_FLOWS = 8
+
+LIB_NAME = 'libvibo_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+class ViboDesc(ctypes.Structure):
+    """struct vibo_desc (include/vibo_hip.h)."""
+    _fields_ = [
+        ('abi_version', ctypes.c_int32),
+        ('num_person', ctypes.c_int32),
+        ('num_item', ctypes.c_int32),
+        ('ability_dim', ctypes.c_int32),
+        ('irt_model', ctypes.c_int32),
+        ('posterior', ctypes.c_int32),
+        ('missing_mode', ctypes.c_int32),
+        ('mask_dtype', ctypes.c_int32),
+        ('reg_mode', ctypes.c_int32),
+        ('n_flows', ctypes.c_int32),
+        ('want_grad', ctypes.c_int32),
+        ('deterministic', ctypes.c_int32),
+        ('response_row_stride', ctypes.c_int64),
+        ('mask_row_stride', ctypes.c_int64),
+    ]
+
+
+EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
+                    'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode')
+
+_lib = None
+
+
+class ViboLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ViboLibraryError(
+            f'{LIB_PATH} not found: build the HIP extension first '
+            f'(python __graft_entry__.py, or make -C variational-item-response-theory-public_amd/csrc). '
+            f'There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64p, fp = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
+    dp = ctypes.POINTER(ViboDesc)
+    lib.vibo_version.restype = ctypes.c_int
+    lib.vibo_version.argtypes = []
+    lib.vibo_last_error_string.restype = ctypes.c_char_p
+    lib.vibo_last_error_string.argtypes = []
+    lib.vibo_workspace_bytes.restype = ctypes.c_size_t
+    lib.vibo_workspace_bytes.argtypes = [dp]
+    lib.vibo_elbo_fwd_bwd.restype = ctypes.c_int
+    lib.vibo_elbo_fwd_bwd.argtypes = [dp, fp, vp, i64p, fp, fp, fp, fp,      # inputs
+                                      fp, fp, fp, fp, fp, fp,                # scalars + posterior outputs
+                                      fp, fp, fp,                            # grads
+                                      vp, ctypes.c_size_t, vp]               # workspace, stream
+    lib.vibo_encode.restype = ctypes.c_int
+    lib.vibo_encode.argtypes = [dp, fp, vp, i64p, fp, fp, fp, vp, ctypes.c_size_t, vp]
+    lib.vibo_decode.restype = ctypes.c_int
+    lib.vibo_decode.argtypes = [dp, fp, fp, fp, vp]
+    if lib.vibo_version() != ABI_VERSION:
+        raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vibo_last_error_string().decode('utf-8', 'replace')
+        raise ViboLibraryError(f'{what} failed (rc={rc}): {msg}')

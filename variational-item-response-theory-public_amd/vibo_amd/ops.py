@@ -1,0 +1,287 @@
+"""Host side of the fused ELBO op: launches libvibo_hip.so through the C ABI and
+wires its outputs into torch.autograd.
+
+Reference seam: VIBO_*PL.forward/encode/decode/elbo of
+src/torch_core/models.py:337-443 as called from src/torch_core/vibo.py:237-268.
+
+What stays in PyTorch (tiny, O(I) work): the 2-row (or 2xI-row) encoder MLP that
+produces the expert table, the item-side reparameterisation / flows / KL, the
+optimizer.  Everything O(B x I) is inside the HIP kernel.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def item_feat_dim(irt_model, ability_dim):
+    """models.py:331-332, 523-524, 538-539."""
+    return {1: 1, 2: ability_dim + 1, 3: ability_dim + 2}[int(irt_model)]
+
+
+@dataclass(frozen=True)
+class ElboSpec:
+    """Static configuration of one fused-ELBO problem family."""
+    irt_model: int
+    ability_dim: int
+    conditional: bool = False
+    drop_missing: bool = False       # --drop-missing (vibo.py:52,217)
+    n_flows: int = 0
+
+    @property
+    def item_dim(self):
+        return item_feat_dim(self.irt_model, self.ability_dim)
+
+    def table_shape(self, num_item):
+        A = self.ability_dim
+        return (2, num_item, 2 * A) if self.conditional else (2, 2 * A)
+
+    def check_supported(self, num_item):
+        if not (1 <= self.ability_dim <= _lib.MAX_ABILITY_DIM):
+            raise NotImplementedError(
+                f'ability_dim={self.ability_dim}: the HIP kernel supports 1..{_lib.MAX_ABILITY_DIM}')
+        if not (0 <= self.n_flows <= _lib.MAX_FLOWS):
+            raise NotImplementedError(f'n_norm_flows={self.n_flows}: supported 0..{_lib.MAX_FLOWS}')
+
+
+@dataclass
+class RawElbo:
+    """Everything one kernel call produces (device tensors)."""
+    flat: torch.Tensor              # [8 scalars | grad_table(2*T) | grad_item(I*D) | grad_flow(2*F)]
+    n_table: int
+    n_item: int
+    n_flow: int
+    table_shape: tuple
+    ability_mu: torch.Tensor
+    ability_logvar: torch.Tensor
+    ability: torch.Tensor
+    ability_k: Optional[torch.Tensor]
+    ability_ladj: Optional[torch.Tensor]
+
+    @property
+    def scalars(self):
+        return self.flat[:_lib.NUM_SCALARS]
+
+    def grad_table(self, s):
+        o = _lib.NUM_SCALARS + s * self.n_table
+        return self.flat[o:o + self.n_table].view(self.table_shape)
+
+    def grad_item(self, shape):
+        o = _lib.NUM_SCALARS + 2 * self.n_table
+        return self.flat[o:o + self.n_item].view(shape)
+
+    def grad_flow(self, s):
+        o = _lib.NUM_SCALARS + 2 * self.n_table + self.n_item + s * self.n_flow
+        return self.flat[o:o + self.n_flow]
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def prepare_mask(mask):
+    """-> (2-D mask tensor the kernel can read, VIBO_MASK_* code).  bool / int64
+    masks are read in place (datasets.py:938 yields bool, vibo.py:240 converts to
+    int64); other dtypes are normalised to bool once."""
+    if mask is None:
+        return None, _lib.MASK_NONE
+    if mask.dim() == 3:
+        mask = mask.squeeze(2)
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8), _lib.MASK_U8
+    if mask.dtype == torch.int64:
+        return mask.contiguous(), _lib.MASK_I64
+    return (mask != 0).contiguous().view(torch.uint8), _lib.MASK_U8
+
+
+def prepare_response(response):
+    if response.dim() == 3:
+        response = response.squeeze(2)
+    if response.dtype != torch.float32:
+        response = response.float()
+    if response.stride(-1) != 1:
+        response = response.contiguous()
+    return response
+
+
+def _make_desc(spec, B, I, mask_code, reg_mode, want_grad, resp_stride, mask_stride):
+    d = _lib.ViboDesc()
+    d.abi_version = _lib.ABI_VERSION
+    d.num_person = B
+    d.num_item = I
+    d.ability_dim = spec.ability_dim
+    d.irt_model = spec.irt_model
+    d.posterior = _lib.POSTERIOR_CONDITIONAL if spec.conditional else _lib.POSTERIOR_UNCONDITIONAL
+    d.missing_mode = _lib.MISSING_DROP if spec.drop_missing else _lib.MISSING_PRIOR
+    d.mask_dtype = mask_code
+    d.reg_mode = reg_mode
+    d.n_flows = spec.n_flows
+    d.want_grad = 1 if want_grad else 0
+    d.deterministic = 1
+    d.response_row_stride = resp_stride
+    d.mask_row_stride = mask_stride
+    return d
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('vibo_amd: the fused ELBO runs on the GPU only (tensor on %s); '
+                               'there is no CPU path' % t.device)
+
+
+def _hip_launch_elbo(spec, response, mask, mask_code, row_index, table, item, eps, flow, reg_mode,
+                     want_grad, num_person):
+    """Single call into vibo_elbo_fwd_bwd on the current stream."""
+    lib = _lib.load()
+    _require_device(response, mask, table, item, eps)
+    dev = response.device
+    I = response.shape[1]
+    B = int(num_person)
+    A, D = spec.ability_dim, spec.item_dim
+    n_table = table.numel()
+    n_flow = spec.n_flows * (2 * A + 1)
+    n_item = I * D
+    flat = torch.empty(_lib.NUM_SCALARS + 2 * n_table + n_item + 2 * n_flow, dtype=torch.float32, device=dev)
+    post = torch.empty(3, B, A, dtype=torch.float32, device=dev)
+    ability_k = torch.empty(B, A, dtype=torch.float32, device=dev) if spec.n_flows else None
+    ladj = torch.empty(B, dtype=torch.float32, device=dev) if spec.n_flows else None
+    d = _make_desc(spec, B, I, mask_code, reg_mode, want_grad, response.stride(0),
+                   mask.stride(0) if mask is not None else 0)
+    ws_bytes = lib.vibo_workspace_bytes(ctypes.byref(d))
+    if ws_bytes == 0:
+        _lib.check(-1, 'vibo_workspace_bytes')
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    fbase, esz = flat.data_ptr(), 4
+    o_tab = _lib.NUM_SCALARS
+    o_item = o_tab + 2 * n_table
+    o_flow = o_item + n_item
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.vibo_elbo_fwd_bwd(
+        ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(table), _ptr(item), _ptr(eps),
+        _ptr(flow),
+        ctypes.c_void_p(fbase), _ptr(post[0]), _ptr(post[1]), _ptr(post[2]), _ptr(ability_k), _ptr(ladj),
+        ctypes.c_void_p(fbase + esz * o_tab), ctypes.c_void_p(fbase + esz * o_item),
+        ctypes.c_void_p(fbase + esz * o_flow) if n_flow else ctypes.c_void_p(0),
+        _ptr(ws), ctypes.c_size_t(ws_bytes), stream)
+    _lib.check(rc, 'vibo_elbo_fwd_bwd')
+    return RawElbo(flat=flat, n_table=n_table, n_item=n_item, n_flow=n_flow, table_shape=tuple(table.shape),
+                   ability_mu=post[0], ability_logvar=post[1], ability=post[2],
+                   ability_k=ability_k, ability_ladj=ladj)
+
+
+def _hip_encode(spec, response, mask, mask_code, row_index, table, num_person):
+    lib = _lib.load()
+    _require_device(response, mask, table)
+    dev = response.device
+    B, I, A = int(num_person), response.shape[1], spec.ability_dim
+    out = torch.empty(2, B, A, dtype=torch.float32, device=dev)
+    d = _make_desc(spec, B, I, mask_code, _lib.REG_KL, False, response.stride(0),
+                   mask.stride(0) if mask is not None else 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.vibo_encode(ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(table),
+                         _ptr(out[0]), _ptr(out[1]), ctypes.c_void_p(0), ctypes.c_size_t(0), stream)
+    _lib.check(rc, 'vibo_encode')
+    return out[0], out[1]
+
+
+def _hip_decode(spec, ability, item):
+    lib = _lib.load()
+    _require_device(ability, item)
+    B, I = ability.shape[0], item.shape[0]
+    out = torch.empty(B, I, dtype=torch.float32, device=ability.device)
+    d = _make_desc(spec, B, I, _lib.MASK_NONE, _lib.REG_KL, False, I, 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(ability.device).cuda_stream)
+    rc = lib.vibo_decode(ctypes.byref(d), _ptr(ability), _ptr(item), _ptr(out), stream)
+    _lib.check(rc, 'vibo_decode')
+    return out
+
+
+# The three entry points of the native library.  tests/ swap these for the CPU
+# oracle to exercise the host logic without a GPU (never done by product code).
+_BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode}
+
+
+class FusedELBO(torch.autograd.Function):
+    """(table, item, flow) -> (LL, REG, scalars, ability_mu, ability_logvar,
+    ability, ability_k, ability_ladj).
+
+    LL  = sum of masked Bernoulli log-likelihoods (utils.py:46-49, models.py:399)
+    REG = sum_p KL(q(theta_p)||N(0,1))  (reg_mode KL,  models.py:428) or
+          sum_p [log q(theta_p) - log p(theta_p)] at the sample (SAMPLED, models.py:412-418,433-435)
+    The kernel has already produced d LL/d(.) and d REG/d(.); backward only scales
+    and adds them, so loss.backward() costs no second pass over the responses.
+    """
+
+    @staticmethod
+    def forward(ctx, table, item, flow, response, mask, mask_code, row_index, eps, spec, reg_mode,
+                num_person, reducer):
+        need_grad = any(ctx.needs_input_grad[:3])
+        table_c = table.detach().contiguous()
+        item_c = item.detach().contiguous()
+        flow_c = flow.detach().contiguous() if flow is not None else None
+        raw = _BACKEND['elbo'](spec, response, mask, mask_code, row_index, table_c, item_c,
+                               eps.contiguous(), flow_c, reg_mode, need_grad, num_person)
+        if reducer is not None:
+            reducer(raw.flat)        # person-sharded data parallelism: ONE all-reduce (RCCL) per step
+        ctx.raw = raw
+        ctx.item_shape = tuple(item.shape)
+        ctx.has_flow = flow is not None
+        ctx.need_grad = need_grad
+        sc = raw.scalars
+        outs = (sc[_lib.S_LL].clone(), sc[_lib.S_REG].clone(), sc.clone(),
+                raw.ability_mu, raw.ability_logvar, raw.ability,
+                raw.ability_k if raw.ability_k is not None else raw.ability,
+                raw.ability_ladj if raw.ability_ladj is not None else sc.new_zeros(()))
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_ll, g_reg, *_):
+        raw = ctx.raw
+        if not ctx.need_grad:
+            return (None,) * 12
+        g_table = g_item = g_flow = None
+        if ctx.needs_input_grad[0]:
+            g_table = g_ll * raw.grad_table(0) + g_reg * raw.grad_table(1)
+        if ctx.needs_input_grad[1]:
+            g_item = g_ll * raw.grad_item(ctx.item_shape)
+        if ctx.has_flow and ctx.needs_input_grad[2]:
+            g_flow = (g_ll * raw.grad_flow(0) + g_reg * raw.grad_flow(1)).view(-1, 2 * raw.ability_mu.shape[1] + 1)
+        return (g_table, g_item, g_flow) + (None,) * 9
+
+
+def fused_elbo(spec, table, item, flow, response, mask, eps, *, reg_mode=_lib.REG_KL, row_index=None,
+               reducer=None):
+    """Functional front end.  response [B,I(,1)] fp32, mask [B,I(,1)] bool/int64/None,
+    table per ElboSpec.table_shape, item [I,D], eps [B,A], flow [n_flows,2A+1] or None.
+    With row_index (int64 [B]) the rows response[row_index] / mask[row_index] are
+    gathered inside the kernel (device-resident dataset, shuffled minibatches)."""
+    response = prepare_response(response)
+    mask, code = prepare_mask(mask)
+    I = response.shape[1]
+    spec.check_supported(I)
+    B = int(row_index.numel()) if row_index is not None else response.shape[0]
+    if tuple(table.shape) != spec.table_shape(I):
+        raise ValueError(f'table shape {tuple(table.shape)} != {spec.table_shape(I)}')
+    if tuple(item.shape) != (I, spec.item_dim):
+        raise ValueError(f'item shape {tuple(item.shape)} != {(I, spec.item_dim)}')
+    if tuple(eps.shape) != (B, spec.ability_dim):
+        raise ValueError(f'eps shape {tuple(eps.shape)} != {(B, spec.ability_dim)}')
+    return FusedELBO.apply(table, item, flow, response, mask, code, row_index, eps, spec, reg_mode, B, reducer)
+
+
+def encode_posterior(spec, table, response, mask, row_index=None):
+    """Forward-only q(ability | responses): (mu, logvar) [B,A] (models.py:356-371 under no_grad)."""
+    response = prepare_response(response)
+    mask, code = prepare_mask(mask)
+    B = int(row_index.numel()) if row_index is not None else response.shape[0]
+    return _BACKEND['encode'](spec, response, mask, code, row_index, table.detach().contiguous(), B)
+
+
+def decode_probs(spec, ability, item):
+    """P(response = 1) [B,I] (models.py:729-766)."""
+    return _BACKEND['decode'](spec, ability.detach().contiguous().float(), item.detach().contiguous().float())

@@ -1,0 +1,371 @@
+"""Drop-in VIBO_1PL / VIBO_2PL / VIBO_3PL modules whose ELBO runs in the fused HIP kernel.
+
+Same constructor signature, ``state_dict`` keys, RNG draw order and method
+surface as the reference (src/torch_core/models.py:246-548):
+
+    model = VIBO_2PL(ability_dim, num_item, hidden_dim=64, ability_merge='product', ...)
+    outputs = model(response, mask)                       # models.py:337-354
+    loss = model.elbo(*outputs, annealing_factor=beta)    # models.py:380-443
+    loss.backward()
+
+``forward`` launches ONE fused kernel that already contains the backward pass;
+``elbo`` only combines its two heads (log-lik, regulariser) with the item-side
+terms, so ``loss.backward()`` never touches the response matrix again.
+
+The only piece of forward()'s tuple that is not materialised is ``response_mu``
+([B,I,1], as large as the input): it is a :class:`DeferredResponseMu` that
+``elbo`` recognises; call ``.materialize()`` (or ``model.decode``) for the values.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from ..ops import ElboSpec, decode_probs, encode_posterior, fused_elbo, item_feat_dim
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+# ---------------------------------------------------------------------------
+# parameter containers (state_dict-compatible with the reference)
+# ---------------------------------------------------------------------------
+
+def _encoder_mlp(in_dim, hidden_dim, out_dim):
+    return nn.Sequential(
+        nn.Linear(in_dim, hidden_dim), nn.ELU(inplace=True),
+        nn.Linear(hidden_dim, hidden_dim), nn.ELU(inplace=True),
+        nn.Linear(hidden_dim, out_dim),
+    )
+
+
+class AbilityEncoder(nn.Module):
+    """Holds ``mlp`` (keys ability_encoder.mlp.{0,2,4}.*; models.py:575-582).
+
+    The network is evaluated on the 2 (unconditional) or 2 x I (conditional)
+    distinct inputs a Bernoulli response can present, never per (person, item).
+    """
+
+    def __init__(self, ability_dim, item_dim, hidden_dim, conditional):
+        super().__init__()
+        self.ability_dim = ability_dim
+        self.conditional = conditional
+        if conditional:
+            # the reference builds (and discards) the unconditional net first
+            # (models.py:675-693); do the same so parameter init consumes the RNG identically
+            _encoder_mlp(1, hidden_dim, 2 * ability_dim)
+        self.mlp = _encoder_mlp(1 + (item_dim if conditional else 0), hidden_dim, 2 * ability_dim)
+
+    def expert_table(self, item_feat=None):
+        """[2,2A] (row c = mlp([c])) or [2,I,2A] (entry = mlp([c, item_i]))."""
+        w = self.mlp[0].weight
+        vals = torch.tensor([[0.0], [1.0]], dtype=w.dtype, device=w.device)
+        if not self.conditional:
+            return self.mlp(vals)
+        I = item_feat.shape[0]
+        x = torch.cat([vals.unsqueeze(1).expand(2, I, 1), item_feat.unsqueeze(0).expand(2, I, -1)], dim=2)
+        return self.mlp(x.reshape(2 * I, -1)).view(2, I, -1)
+
+
+class ItemEncoder(nn.Module):
+    """Per-item Gaussian posterior parameters (models.py:713-726)."""
+
+    def __init__(self, num_item, item_dim):
+        super().__init__()
+        self.mu_lookup = nn.Embedding(num_item, item_dim)
+        self.logvar_lookup = nn.Embedding(num_item, item_dim)
+
+    def forward(self, item_index=None):
+        if item_index is None:
+            return self.mu_lookup.weight, self.logvar_lookup.weight
+        idx = item_index.reshape(-1).long()
+        return self.mu_lookup(idx), self.logvar_lookup(idx)
+
+
+class PlanarFlowParams(nn.Module):
+    """u, w ~ N(0,1), b = 1 (flows.py:15-19)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.u = nn.Parameter(torch.randn(dim))
+        self.w = nn.Parameter(torch.randn(dim))
+        self.b = nn.Parameter(torch.ones(1))
+
+    def uhat(self):
+        uw = torch.dot(self.u, self.w)
+        return self.u + (F.softplus(uw) - 1.0 - uw) * self.w / torch.sum(self.w * self.w)
+
+    def forward(self, z):
+        """Planar step on rows of z (flows.py:21-41); used for the [I,D] item side."""
+        uhat = self.uhat()
+        t = torch.tanh(z @ self.w + self.b)
+        z_new = z + uhat.unsqueeze(0) * t.unsqueeze(1)
+        psi_u = (1.0 - t * t) * torch.dot(self.w, uhat)
+        return z_new, torch.log(torch.abs(1.0 + psi_u) + 1e-8)
+
+
+class FlowStack(nn.Module):
+    """keys <name>.flows.{k}.{u,w,b} (flows.py:44-66)."""
+
+    def __init__(self, dim, n_flows):
+        super().__init__()
+        self.flows = nn.ModuleList([PlanarFlowParams(dim) for _ in range(n_flows)])
+
+    def forward(self, z):
+        total = None
+        for f in self.flows:
+            z, ladj = f(z)
+            total = ladj if total is None else total + ladj
+        return z, total
+
+    def packed(self):
+        """[n_flows, 2*dim+1] = (uhat | w | b) rows for the kernel."""
+        return torch.stack([torch.cat([f.uhat(), f.w, f.b]) for f in self.flows])
+
+
+# ---------------------------------------------------------------------------
+# deferred pieces of forward()'s tuple
+# ---------------------------------------------------------------------------
+
+class FusedContext:
+    """What one fused kernel call produced, kept until elbo() consumes it."""
+
+    def __init__(self, model, response, mask, eps_ability, table, item_in, flow_packed, reg_mode, heads):
+        self.model = model
+        self.response, self.mask = response, mask
+        self.eps_ability = eps_ability
+        self.table, self.item_in, self.flow_packed = table, item_in, flow_packed
+        self.reg_mode = reg_mode
+        (self.ll, self.reg, self.scalars, self.ability_mu, self.ability_logvar, self.ability,
+         self.ability_k, self.ability_ladj) = heads
+
+
+class DeferredResponseMu:
+    """Stands in for response_mu [B,I,1] (models.py:345,351) in forward()'s tuple."""
+
+    def __init__(self, ctx, ability, item_feat):
+        self.ctx = ctx
+        self._ability, self._item = ability, item_feat
+
+    def materialize(self):
+        return self.ctx.model.decode(self._ability.detach(), self._item.detach())
+
+    def __repr__(self):
+        return 'DeferredResponseMu(call .materialize() for the [B,I,1] tensor)'
+
+
+# ---------------------------------------------------------------------------
+# the model
+# ---------------------------------------------------------------------------
+
+class VIBO_1PL(nn.Module):
+    IRT = 1
+
+    def __init__(self, latent_dim, num_item, hidden_dim=64, ability_merge='mean',
+                 conditional_posterior=False, generative_model='irt', response_dist='bernoulli',
+                 replace_missing_with_prior=True, n_norm_flows=0):
+        super().__init__()
+        if ability_merge not in ('mean', 'product'):
+            raise AssertionError('ability_merge must be mean|product')   # models.py:262
+        if generative_model not in ('irt', 'link', 'deep', 'residual'):
+            raise AssertionError('bad generative_model')
+        if response_dist not in ('bernoulli', 'gaussian'):
+            raise AssertionError('bad response_dist')
+        # the fused HIP path covers the 1PL/2PL/3PL logistic link with the product-of-experts
+        # encoder on Bernoulli responses (BASELINE.json north_star); nothing else is in scope
+        if ability_merge != 'product':
+            raise NotImplementedError("only --ability-merge product is implemented by the HIP engine")
+        if generative_model != 'irt':
+            raise NotImplementedError("only --generative-model irt is implemented by the HIP engine")
+        if response_dist != 'bernoulli':
+            raise NotImplementedError("only --response-dist bernoulli is implemented by the HIP engine")
+
+        self.latent_dim = self.ability_dim = latent_dim
+        self.response_dim = 1
+        self.hidden_dim = hidden_dim
+        self.num_item = num_item
+        self.ability_merge = ability_merge
+        self.conditional_posterior = conditional_posterior
+        self.generative_model = generative_model
+        self.response_dist = response_dist
+        self.replace_missing_with_prior = replace_missing_with_prior
+        self.n_norm_flows = n_norm_flows
+        self.irt_num = self.IRT
+        self.item_feat_dim = item_feat_dim(self.IRT, latent_dim)
+        self.spec = ElboSpec(irt_model=self.IRT, ability_dim=latent_dim, conditional=conditional_posterior,
+                             drop_missing=not replace_missing_with_prior, n_flows=n_norm_flows)
+        self.spec.check_supported(num_item)
+
+        # construction order = the reference's (models.py:281-309) so seeded init matches
+        self.ability_encoder = AbilityEncoder(latent_dim, self.item_feat_dim, hidden_dim, conditional_posterior)
+        self.item_encoder = ItemEncoder(num_item, self.item_feat_dim)
+        if n_norm_flows > 0:
+            self.ability_norm_flows = FlowStack(latent_dim, n_norm_flows)
+            self.item_norm_flows = FlowStack(self.item_feat_dim, n_norm_flows)
+        self.apply(self.weights_init)
+
+        self._reducer = None          # set by enable_person_sharding()
+        self._item_gen = None
+        self._ability_gen = None
+
+    # ---- init / RNG ---------------------------------------------------------
+    @staticmethod
+    def weights_init(m):
+        """xavier-normal(gain=sqrt 2) on linears, zero bias (models.py:512-518)."""
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_normal_(m.weight.data, gain=nn.init.calculate_gain('relu'))
+            nn.init.constant_(m.bias.data, 0)
+
+    def enable_person_sharding(self, reducer, seed, rank):
+        """Data parallelism over persons: `reducer(flat)` all-reduces (sum) the
+        kernel's flat [scalars | grads] buffer in place.  Item noise must be
+        identical on every rank, ability noise must differ: dedicated generators."""
+        self._reducer = reducer
+        dev = self.item_encoder.mu_lookup.weight.device
+        self._item_gen = torch.Generator(device=dev).manual_seed(int(seed))
+        self._ability_gen = torch.Generator(device=dev).manual_seed(int(seed) + 1 + int(rank))
+
+    def _randn(self, shape, ref, gen):
+        return torch.randn(shape, dtype=ref.dtype, device=ref.device, generator=gen)
+
+    @staticmethod
+    def reparameterize_gaussian(mean, logvar, eps=None):
+        """models.py:506-510."""
+        std = torch.exp(0.5 * logvar)
+        if eps is None:
+            eps = torch.randn_like(std)
+        return eps * std + mean
+
+    # ---- pieces -------------------------------------------------------------
+    def _item_side(self, eps_item=None):
+        item_mu, item_lv = self.item_encoder()
+        if eps_item is None:
+            eps_item = self._randn(item_mu.shape, item_mu, self._item_gen)
+        item_feat = eps_item * torch.exp(0.5 * item_lv) + item_mu
+        return item_feat, item_mu, item_lv
+
+    def _run_fused(self, response, mask, *, eps_item=None, eps_ability=None, reg_mode=None, row_index=None):
+        """Item sample -> expert table -> fused kernel.  Draw order: item eps, then
+        ability eps (models.py:361,368)."""
+        item_feat, item_mu, item_lv = self._item_side(eps_item)
+        if self.n_norm_flows > 0:
+            item_k, item_ladj = self.item_norm_flows(item_feat)
+            flow_packed = self.ability_norm_flows.packed()
+        else:
+            item_k, item_ladj, flow_packed = item_feat, None, None
+        table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
+        B = int(row_index.numel()) if row_index is not None else response.shape[0]
+        if eps_ability is None:
+            eps_ability = self._randn((B, self.ability_dim), item_mu, self._ability_gen)
+        if reg_mode is None:
+            reg_mode = _lib.REG_SAMPLED if self.n_norm_flows > 0 else _lib.REG_KL
+        heads = fused_elbo(self.spec, table, item_k, flow_packed, response, mask, eps_ability,
+                           reg_mode=reg_mode, row_index=row_index, reducer=self._reducer)
+        ctx = FusedContext(self, response, mask, eps_ability, table, item_k, flow_packed, reg_mode, heads)
+        ctx.item_feat, ctx.item_mu, ctx.item_lv = item_feat, item_mu, item_lv
+        ctx.item_k, ctx.item_ladj = item_k, item_ladj
+        ctx.eps_item = eps_item
+        return ctx
+
+    # ---- reference method surface --------------------------------------------
+    def forward(self, response, mask, eps_item=None, eps_ability=None, row_index=None):
+        ctx = self._run_fused(response, mask, eps_item=eps_item, eps_ability=eps_ability, row_index=row_index)
+        if self.n_norm_flows > 0:
+            rmu = DeferredResponseMu(ctx, ctx.ability_k, ctx.item_k)
+            return (response, mask, rmu, ctx.ability_k, ctx.ability, ctx.ability_mu, ctx.ability_logvar,
+                    ctx.ability_ladj, ctx.item_k, ctx.item_feat, ctx.item_mu, ctx.item_lv, ctx.item_ladj)
+        rmu = DeferredResponseMu(ctx, ctx.ability, ctx.item_feat)
+        return (response, mask, rmu, ctx.ability, ctx.ability_mu, ctx.ability_logvar,
+                ctx.item_feat, ctx.item_mu, ctx.item_lv)
+
+    def encode(self, response, mask, row_index=None):
+        """(ability, ability_mu, ability_logvar, item_feat, item_feat_mu, item_feat_logvar)
+        (models.py:356-371): forward-only kernel, no gradients through the ability side."""
+        item_feat, item_mu, item_lv = self._item_side()
+        with torch.no_grad():
+            table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
+            amu, alv = encode_posterior(self.spec, table, response, mask, row_index=row_index)
+            ability = self.reparameterize_gaussian(
+                amu, alv, self._randn(amu.shape, amu, self._ability_gen))
+        return ability, amu, alv, item_feat, item_mu, item_lv
+
+    def decode(self, ability, item_feat):
+        """response_mu [B,I,1] (models.py:373-378, 529-533, 544-548)."""
+        return decode_probs(self.spec, ability, item_feat).unsqueeze(2)
+
+    def elbo(self, response, mask, response_mu, ability, ability_mu, ability_logvar,
+             item_feat, item_feat_mu, item_feat_logvar, annealing_factor=1, use_kl_divergence=True,
+             ability_k=None, item_feat_k=None, ability_logabsdetjac=None, item_logabsdetjac=None):
+        """-ELBO summed over the minibatch (models.py:380-443)."""
+        if not isinstance(response_mu, DeferredResponseMu):
+            raise TypeError('elbo() expects the outputs of this model\'s forward(); a materialised '
+                            'response_mu tensor would need a second pass over the responses')
+        ctx = response_mu.ctx
+        want_mode = _lib.REG_SAMPLED if (self.n_norm_flows > 0 or not use_kl_divergence) else _lib.REG_KL
+        if want_mode != ctx.reg_mode:
+            if torch.is_grad_enabled() and ctx.ll.requires_grad:
+                # rare: use_kl_divergence=False asked of a KL-mode forward -> redo the step in SAMPLED mode
+                ctx = self._run_fused(ctx.response, ctx.mask, eps_item=ctx.eps_item,
+                                      eps_ability=ctx.eps_ability, reg_mode=want_mode)
+                item_feat, item_feat_mu, item_feat_logvar = ctx.item_feat, ctx.item_mu, ctx.item_lv
+                reg = ctx.reg
+            else:
+                sc = ctx.scalars
+                reg = (sc[_lib.S_LOGQ0] - sc[_lib.S_LADJ] - sc[_lib.S_LOGP]) if want_mode == _lib.REG_SAMPLED \
+                    else sc[_lib.S_KL]
+        else:
+            reg = ctx.reg
+        ll = ctx.ll
+        if self.n_norm_flows > 0:
+            assert item_feat_k is not None and item_logabsdetjac is not None
+            log_q_d = _normal_logpdf(item_feat, item_feat_mu, item_feat_logvar).sum() - item_logabsdetjac.sum()
+            log_p_d = _std_normal_logpdf(item_feat_k).sum()
+            return -(ll + log_p_d - reg - log_q_d)
+        if use_kl_divergence:
+            kl_d = (-0.5 * (1.0 + item_feat_logvar - item_feat_mu.pow(2) - item_feat_logvar.exp())).sum()
+            return -(ll - annealing_factor * reg - annealing_factor * kl_d)
+        log_q_d = _normal_logpdf(item_feat, item_feat_mu, item_feat_logvar).sum()
+        log_p_d = _std_normal_logpdf(item_feat).sum()
+        return -(ll + log_p_d - reg - log_q_d)
+
+    def log_marginal(self, response, mask, num_samples=100):
+        """Importance-weighted bound with batch-level weights (models.py:445-504)."""
+        with torch.no_grad():
+            log_w = []
+            for _ in range(num_samples):
+                ctx = self._run_fused(response, mask, reg_mode=_lib.REG_SAMPLED)
+                log_q_d = _normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum()
+                if ctx.item_ladj is not None:
+                    log_q_d = log_q_d - ctx.item_ladj.sum()
+                log_p_d = _std_normal_logpdf(ctx.item_k).sum()
+                log_w.append(ctx.ll + log_p_d - ctx.reg - log_q_d)
+            log_w = torch.stack(log_w)
+            return torch.logsumexp(log_w, 0) - math.log(num_samples)
+
+    # ---- fast path for training loops (no tuple round trip) -------------------
+    def elbo_step(self, response, mask, annealing_factor=1.0, row_index=None):
+        """loss = model.elbo(*model(response, mask), annealing_factor) in one call."""
+        out = self.forward(response, mask, row_index=row_index)
+        if self.n_norm_flows > 0:
+            (r, m, rmu, ak, a0, amu, alv, aladj, ik, i0, imu, ilv, iladj) = out
+            return self.elbo(r, m, rmu, a0, amu, alv, i0, imu, ilv, annealing_factor=annealing_factor,
+                             use_kl_divergence=False, ability_k=ak, item_feat_k=ik,
+                             ability_logabsdetjac=aladj, item_logabsdetjac=iladj)
+        return self.elbo(*out, annealing_factor=annealing_factor, use_kl_divergence=True)
+
+
+class VIBO_2PL(VIBO_1PL):
+    IRT = 2
+
+
+class VIBO_3PL(VIBO_2PL):
+    IRT = 3
+
+
+def _normal_logpdf(x, mu, logvar):
+    return -0.5 * LOG_2PI - 0.5 * logvar - 0.5 * (x - mu) ** 2 / logvar.exp()
+
+
+def _std_normal_logpdf(x):
+    return -0.5 * LOG_2PI - 0.5 * x * x
