@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- person x item ELBO terms/sec of the fused VIBO train step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json: "person x item ELBO terms/sec on 1M x 1k 2PL", configs[2]):
+2PL, 1 000 000 persons x 1 000 items per GPU, ability_dim 8, synthetic Bernoulli
+responses with 10 % missing cells, device-resident (inputs are in HBM before the
+timed region).  One step = one ELBO train step over the GPU's whole person shard:
+item sample + expert table (PyTorch, O(I)), fused HIP forward+backward over the
+[B,I] response matrix, ONE all-reduce of the flat [scalars|grads] buffer when
+N > 1 (persons are sharded, weak scaling), autograd of the O(I) part, Adam.
+
+Adds to the contract line:
+  roofline      the fused kernel's achieved HBM GB/s = algorithmic bytes
+                (5 + 12A/I per term) x terms per launch / its average
+                duration, measured with HIP events on the launch stream inside the
+                timed region; peak 8000 GB/s (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle port of the reference op sequence (per-term MLP ->
+                PoE -> link -> masked log-lik -> autograd -> Adam, oracle/vibo_oracle.py)
+                timed on this host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(ROOT, 'variational-item-response-theory-public_amd')
+for p in (ROOT, PKG_DIR):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--persons', type=int, default=1_000_000, help='persons per GPU (weak scaling)')
+    ap.add_argument('--items', type=int, default=1000)
+    ap.add_argument('--ability-dim', type=int, default=8)
+    ap.add_argument('--irt-model', type=str, default='2pl', choices=['1pl', '2pl', '3pl'])
+    ap.add_argument('--missing', type=float, default=0.1)
+    ap.add_argument('--lr', type=float, default=5e-3)
+    ap.add_argument('--seed', type=int, default=42)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2048)
+    ap.add_argument('--cpu-steps', type=int, default=8)
+    ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
+    return ap.parse_args()
+
+
+def synth_responses(irt, P, I, A, missing, device, seed):
+    """theta ~ N(0,1), item ~ N(0,1), r ~ Bernoulli(link) (src/pyro_core/models.py:68-110
+    semantics), generated on the device in chunks; -1 / mask 0 where missing."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    D = {1: 1, 2: A + 1, 3: A + 2}[irt]
+    item = torch.randn(I, D, device=device, generator=g)
+    resp = torch.empty(P, I, dtype=torch.float32, device=device)
+    mask = torch.empty(P, I, dtype=torch.bool, device=device)
+    chunk = 65536
+    for s in range(0, P, chunk):
+        n = min(chunk, P - s)
+        theta = torch.randn(n, A, device=device, generator=g)
+        if irt == 1:
+            logit = theta.sum(1, keepdim=True) + item[:, 0]
+        else:
+            logit = -(theta @ item[:, :A].t()) + item[:, A]
+        p = torch.sigmoid(logit)
+        if irt == 3:
+            gs = torch.sigmoid(item[:, A + 1])
+            p = gs + (1 - gs) * p
+        r = torch.bernoulli(p, generator=g)
+        m = torch.rand(n, I, device=device, generator=g) >= missing
+        resp[s:s + n] = torch.where(m, r, torch.full_like(r, -1.0))
+        mask[s:s + n] = m
+    return resp, mask
+
+
+def cpu_baseline(args, irt):
+    """Reference op sequence on the host cores (oracle port), train step, bounded sample."""
+    from oracle import vibo_oracle as O
+    A, I, B = args.ability_dim, args.items, args.cpu_batch
+    g = torch.Generator().manual_seed(args.seed)
+    resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=0.0)
+    params = {k: v.requires_grad_(True) for k, v in O.init_params(irt, A, I, generator=g).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=args.lr)
+
+    def step():
+        opt.zero_grad()
+        out = O.elbo_forward(params, resp, mask, torch.randn(I, O.item_feat_dim(irt, A)), torch.randn(B, A),
+                             irt_model=irt, ability_dim=A)
+        out['loss'].backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {
+        'value': B * I * args.cpu_steps / dt, 'unit': 'terms/s', 'cores': torch.get_num_threads(),
+        'kind': 'port',
+        'sample': f'{args.cpu_steps} train steps of {B} persons x {I} items (ability_dim {A}, no missing), '
+                  f'oracle/vibo_oracle.py = reference op sequence incl. per-term encoder MLP, autograd, Adam',
+    }
+
+
+def main():
+    args = parse()
+    irt = int(args.irt_model[0])
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from vibo_amd import ops
+    from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
+
+    P, I, A = args.persons, args.items, args.ability_dim
+    resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
+    torch.manual_seed(args.seed)
+    model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge='product').to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    if world > 1:
+        model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
+
+    # HIP events around the native call, on the stream it is launched on
+    events = []
+    native = ops._BACKEND['elbo']
+    recording = {'on': False}
+
+    def timed_native(*a, **k):
+        if not recording['on']:
+            return native(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = native(*a, **k)
+        e1.record()
+        events.append((e0, e1))
+        return out
+
+    ops._BACKEND['elbo'] = timed_native
+
+    def step():
+        if args.eval_only:
+            with torch.no_grad():
+                return model.elbo_step(resp, mask)
+        opt.zero_grad(set_to_none=True)
+        loss = model.elbo_step(resp, mask)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    recording['on'] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    recording['on'] = False
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss.detach())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+    bytes_per_term = 5.0 + 12.0 * A / I
+    achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    if rank == 0:
+        terms = float(P) * I * args.steps * world
+        line = {
+            'metric': 'person x item ELBO terms/sec (train step: fwd + bwd + all-reduce + Adam)'
+                      if not args.eval_only else 'person x item ELBO terms/sec (forward ELBO only)',
+            'value': terms / dt, 'unit': 'terms/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU, '
+                                   f'ability_dim={A}, {args.missing:.0%} missing, product-of-experts encoder, '
+                                   f'unconditional posterior, full-shard minibatch',
+                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}',
+                       'final_loss_per_term': final_loss / (P * I * world)},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': achieved / 8000.0, 'traffic': None,
+                         'kernel': 'vibo::elbo_kernel (+item_prep, finalize helpers inside the timed events)',
+                         'kernel_ms': kern_ms, 'bytes_per_term': bytes_per_term},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args, irt)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,48 @@
+"""The C-ABI library loads and exports every symbol include/vibo_hip.h declares
+(no compute: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+from vibo_amd import _lib
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'vibo_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(vibo_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_is_built():
+    assert os.path.exists(_lib.LIB_PATH), 'run python __graft_entry__.py (build()) first'
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_functions()
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_version_and_descriptor_validation():
+    lib = _lib.load()
+    assert lib.vibo_version() == _lib.ABI_VERSION
+    d = _lib.ViboDesc()
+    assert lib.vibo_workspace_bytes(ctypes.byref(d)) == 0          # abi_version 0 -> rejected
+    assert b'abi_version' in lib.vibo_last_error_string()
+    d.abi_version = _lib.ABI_VERSION
+    d.num_person, d.num_item, d.ability_dim, d.irt_model = 128, 100, 9, 2
+    assert lib.vibo_workspace_bytes(ctypes.byref(d)) == 0          # ability_dim 9 > 8
+    d.ability_dim = 8
+    assert lib.vibo_workspace_bytes(ctypes.byref(d)) > 0
+
+
+def test_desc_struct_matches_header():
+    """ctypes mirror has the header's field order."""
+    src = open(os.path.join(ROOT, 'include', 'vibo_hip.h')).read()
+    body = src[src.index('typedef struct vibo_desc {'):src.index('} vibo_desc;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = re.findall(r'int(?:32|64)_t\s+([a-z_]+)\s*;', body)
+    assert fields == [f[0] for f in _lib.ViboDesc._fields_]

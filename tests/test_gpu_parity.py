@@ -1,0 +1,324 @@
+"""GPU parity: the fused HIP kernel (called through the C ABI) against
+ (1) the committed golden vectors generated from the real reference,
+ (2) the CPU oracle on seeded random problems, incl. ragged / odd shapes, every
+     mask dtype, in-kernel row gather, all-missing rows, saturated logits,
+ (3) size-independent properties at BASELINE.json sizes (shard additivity,
+     person-permutation invariance, bitwise determinism).
+
+Tolerances (fp32): ELBO <= 1e-4 relative (north_star), posterior
+mean / log-variance <= 2e-5, gradients <= 3e-4 of the tensor's max-abs.
+"""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vibo_oracle as O
+from oracle import vibo_table_ref as T
+from test_host_logic import build_model, check_against_golden, run_reference_pattern
+from vibo_amd import _lib, ops
+from vibo_amd.ops import ElboSpec
+
+pytestmark = pytest.mark.gpu
+
+TOL_ELBO = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def kernel_supports(meta):
+    return not meta['conditional_posterior'] and meta['n_norm_flows'] == 0
+
+
+# ---------------------------------------------------------------------------
+# (1) goldens from the reference
+# ---------------------------------------------------------------------------
+def test_golden_through_module(golden):
+    if not kernel_supports(golden.meta):
+        pytest.skip('configuration not in the fused kernel yet')
+    d = dev()
+    model = build_model(golden).to(d)
+    golden.response, golden.mask = golden.response.to(d), golden.mask.to(d)
+    golden.eps_item, golden.eps_ability = golden.eps_item.to(d), golden.eps_ability.to(d)
+    outs, loss = run_reference_pattern(model, golden)
+    check_against_golden(model, golden, outs, loss, tol_loss=TOL_ELBO)
+
+
+def test_golden_adam_trajectory(golden):
+    """3 Adam steps through the HIP path land on the reference's parameters."""
+    if not kernel_supports(golden.meta):
+        pytest.skip('configuration not in the fused kernel yet')
+    d = dev()
+    model = build_model(golden).to(d)
+    golden.response, golden.mask = golden.response.to(d), golden.mask.to(d)
+    golden.eps_item, golden.eps_ability = golden.eps_item.to(d), golden.eps_ability.to(d)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    for step in range(3):
+        opt.zero_grad()
+        _, loss = run_reference_pattern(model, golden)
+        loss.backward()
+        opt.step()
+    for k, v in golden.adam3.items():
+        assert (model.state_dict()[k].cpu() - v).abs().max() < 5e-4, k
+
+
+# ---------------------------------------------------------------------------
+# (2) raw kernel outputs vs the CPU analytic oracle
+# ---------------------------------------------------------------------------
+def random_problem(irt, A, B, I, missing, seed, cond=False, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=missing)
+    D = O.item_feat_dim(irt, A)
+    table = torch.randn((2, I, 2 * A) if cond else (2, 2 * A), generator=g) * 0.7
+    item = torch.randn(I, D, generator=g) * scale
+    eps = torch.randn(B, A, generator=g)
+    return resp, mask, table, item, eps
+
+
+def run_kernel(spec, resp, mask, table, item, eps, reg_mode=_lib.REG_KL, mask_dtype=torch.bool,
+               row_index=None, want_grad=True):
+    d = dev()
+    r = ops.prepare_response(resp.to(d))
+    m, code = ops.prepare_mask(mask.to(d).to(mask_dtype) if mask is not None else None)
+    ri = row_index.to(d) if row_index is not None else None
+    B = int(ri.numel()) if ri is not None else r.shape[0]
+    raw = ops._hip_launch_elbo(spec, r, m, code, ri, table.to(d).contiguous(), item.to(d).contiguous(),
+                               eps.to(d).contiguous(), None, reg_mode, want_grad, B)
+    torch.cuda.synchronize()
+    return raw
+
+
+def compare_raw(raw, ref, item_shape, want_grad=True, tol=3e-4):
+    sc = raw.scalars.cpu()
+    assert rel_err(sc[_lib.S_LL], ref['ll']) < 2e-5
+    assert abs(float(sc[_lib.S_REG]) - float(ref['reg'])) < 2e-5 * max(1.0, abs(float(ref['reg'])))
+    assert abs(float(sc[_lib.S_KL]) - float(ref['kl_ability'])) < 2e-5 * max(1.0, abs(float(ref['kl_ability'])))
+    assert abs(float(sc[_lib.S_LOGQ0]) - float(ref['logq0'])) < 2e-5 * max(1.0, abs(float(ref['logq0'])))
+    assert abs(float(sc[_lib.S_LOGP]) - float(ref['logp'])) < 2e-5 * max(1.0, abs(float(ref['logp'])))
+    for k, t in (('ability_mu', raw.ability_mu), ('ability_logvar', raw.ability_logvar), ('ability', raw.ability)):
+        assert (t.cpu() - ref[k].float()).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
+    if want_grad:
+        for s in range(2):
+            scale = float(ref['g_table'][s].abs().max())
+            if scale > 0:
+                assert rel_err(raw.grad_table(s).cpu(), ref['g_table'][s]) < tol, f'g_table[{s}]'
+            else:
+                assert float(raw.grad_table(s).abs().max()) < 1e-6
+        assert rel_err(raw.grad_item(item_shape).cpu(), ref['g_item']) < tol
+
+
+SHAPES = [
+    # irt, A, B, I, missing
+    (2, 1, 64, 1000, 0.0),
+    (2, 1, 200, 1000, 0.2),
+    (2, 8, 130, 1000, 0.1),
+    (2, 8, 64, 1024, 0.0),
+    (2, 4, 70, 1500, 0.3),      # 8 waves x 4 slots geometry
+    (2, 2, 33, 2048, 0.1),
+    (2, 3, 257, 100, 0.2),      # 2-wave geometry, A padded 3 -> 4
+    (2, 5, 65, 512, 0.0),       # A padded 5 -> 8
+    (2, 1, 31, 95, 0.2),        # ragged rows (I % 4 != 0): scalar load path
+    (2, 7, 100, 130, 0.1),
+    (2, 1, 5, 1, 0.0),          # single item
+    (2, 2, 1, 7, 0.0),          # single person
+    (1, 1, 100, 1000, 0.1),
+    (1, 4, 77, 333, 0.2),
+    (3, 1, 100, 1000, 0.1),
+    (3, 8, 90, 640, 0.0),
+    (3, 2, 50, 95, 0.3),
+    (3, 6, 64, 1203, 0.1),
+]
+
+
+@pytest.mark.parametrize('irt,A,B,I,missing', SHAPES)
+@pytest.mark.parametrize('drop', [False, True])
+def test_raw_kernel_vs_oracle(irt, A, B, I, missing, drop):
+    spec = ElboSpec(irt_model=irt, ability_dim=A, drop_missing=drop)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, missing, seed=B * 131 + I + A)
+    if drop and missing > 0:
+        mask[:, 0] = 1          # --drop-missing needs >= 1 observed cell per person (else 0/0, as in the reference)
+        resp[:, 0] = resp[:, 0].clamp(min=0)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(),
+                           irt_model=irt, ability_dim=A, replace_missing_with_prior=not drop, mode='kl')
+    raw = run_kernel(spec, resp, mask, table, item, eps)
+    compare_raw(raw, ref, (I, spec.item_dim))
+
+
+@pytest.mark.parametrize('mask_dtype', [torch.bool, torch.int64, torch.uint8, None])
+@pytest.mark.parametrize('I', [1000, 95])
+def test_mask_dtypes(mask_dtype, I):
+    irt, A, B = 2, 2, 150
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.0 if mask_dtype is None else 0.25, seed=7)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(),
+                           irt_model=irt, ability_dim=A, mode='kl')
+    raw = run_kernel(spec, resp, None if mask_dtype is None else mask, table, item, eps,
+                     mask_dtype=mask_dtype or torch.bool)
+    compare_raw(raw, ref, (I, spec.item_dim))
+
+
+def test_sampled_regulariser_mode():
+    irt, A, B, I = 2, 3, 100, 200
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.2, seed=11)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(),
+                           irt_model=irt, ability_dim=A, mode='sampled')
+    raw = run_kernel(spec, resp, mask, table, item, eps, reg_mode=_lib.REG_SAMPLED)
+    compare_raw(raw, ref, (I, spec.item_dim))
+
+
+def test_row_index_gather_and_strided_rows():
+    irt, A, P, I = 2, 2, 500, 1000
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, _ = random_problem(irt, A, P, I, 0.2, seed=5)
+    idx = torch.randperm(P, generator=torch.Generator().manual_seed(1))[:130]
+    eps = torch.randn(130, A, generator=torch.Generator().manual_seed(2))
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp[idx].double(), mask[idx], eps.double(),
+                           irt_model=irt, ability_dim=A, mode='kl')
+    raw = run_kernel(spec, resp, mask, table, item, eps, row_index=idx)
+    compare_raw(raw, ref, (I, spec.item_dim))
+
+
+def test_forward_only_matches_forward_of_train():
+    irt, A, B, I = 3, 4, 129, 777
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.1, seed=3)
+    a = run_kernel(spec, resp, mask, table, item, eps, want_grad=True)
+    b = run_kernel(spec, resp, mask, table, item, eps, want_grad=False)
+    assert rel_err(b.scalars[:7].cpu(), a.scalars[:7].cpu()) < 1e-6
+    assert torch.equal(a.ability_mu, b.ability_mu)
+
+
+def test_all_missing_rows_and_saturated_logits():
+    """Rows with a single observed cell / none observed (prior mode), and item
+    parameters large enough to drive logits past the Bernoulli clamp."""
+    irt, A, B, I = 2, 1, 64, 400
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.3, seed=9, scale=12.0)
+    mask[0] = 0
+    resp[0] = -1
+    mask[1] = 0
+    mask[1, 17] = 1
+    resp[1] = -1
+    resp[1, 17] = 1
+    ref = T.fused_elbo_ref(table, item, resp, mask, eps, irt_model=irt, ability_dim=A, mode='kl',
+                           exact_saturation=True)
+    assert float((ref['logit'].abs() > 17).float().mean()) > 0.02      # the clamp really is exercised
+    raw = run_kernel(spec, resp, mask, table, item, eps)
+    compare_raw(raw, ref, (I, spec.item_dim), tol=1e-3)
+
+
+def test_saturation_golden_through_kernel():
+    """One person (theta = 0 => logit = b_i), items with difficulties on the
+    reference's saturation probe grid: per-item gradients must be exactly zero where
+    the reference's are."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'saturation.npz'))
+    logit = torch.from_numpy(z['logit'])[:2000]
+    I = logit.numel()
+    spec = ElboSpec(irt_model=2, ability_dim=1)
+    table = torch.zeros(2, 2)
+    item = torch.stack([torch.ones(I), logit], dim=1)      # a_i = 1, b_i = logit; theta forced to 0 below
+    for x in (0, 1):
+        resp = torch.full((1, I), float(x))
+        mask = torch.ones(1, I, dtype=torch.bool)
+        # table = 0 => tau = 1, mu = 0; eps = 0 => theta = 0 exactly
+        raw = run_kernel(spec, resp, mask, table, item, torch.zeros(1, 1))
+        g_b = raw.grad_item((I, 2))[:, 1].cpu()
+        ref_g = torch.from_numpy(z[f'dll_dlogit_x{x}'])[:I]
+        assert torch.equal(g_b == 0, ref_g == 0)
+        assert (g_b - ref_g).abs().max() < 2e-6
+        # value: exact (fp64) clamped log-likelihood to 1e-5; the reference's own fp32 sum sits up to
+        # ~3e-4 away from exact arithmetic on this adversarial grid (its log(1-p) loses bits for
+        # |logit| > 10), so it is only a loose bound here
+        lc = logit.double().clamp(-T.LOGIT_LO, T.LOGIT_LO)
+        ll_exact = float((x * lc - lc.clamp(min=0) - torch.log1p(torch.exp(-lc.abs()))).sum())
+        ll_ref = float(torch.from_numpy(z[f'll_x{x}'])[:I].double().sum())
+        assert abs(float(raw.scalars[_lib.S_LL]) - ll_exact) < 1e-5 * abs(ll_exact)
+        assert abs(float(raw.scalars[_lib.S_LL]) - ll_ref) < 5e-4 * abs(ll_ref)
+
+
+# ---------------------------------------------------------------------------
+# encode / decode entry points
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('cond', [False, True])
+@pytest.mark.parametrize('drop', [False, True])
+def test_encode_kernel(cond, drop):
+    irt, A, B, I = 2, 3, 101, 333
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, drop_missing=drop)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.2, seed=21, cond=cond)
+    mask[:, 0] = 1
+    resp[:, 0] = resp[:, 0].clamp(min=0)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt,
+                           ability_dim=A, conditional_posterior=cond, replace_missing_with_prior=not drop,
+                           mode='kl', want_grad=False)
+    d = dev()
+    mu, lv = ops.encode_posterior(spec, table.to(d), resp.to(d), mask.bool().to(d))
+    assert (mu.cpu() - ref['ability_mu'].float()).abs().max() < 2e-5
+    assert (lv.cpu() - ref['ability_logvar'].float()).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize('irt', [1, 2, 3])
+def test_decode_kernel(irt):
+    A, B, I = 3, 70, 211
+    g = torch.Generator().manual_seed(irt)
+    ability = torch.randn(B, A, generator=g)
+    item = torch.randn(I, O.item_feat_dim(irt, A), generator=g)
+    d = dev()
+    out = ops.decode_probs(ElboSpec(irt_model=irt, ability_dim=A), ability.to(d), item.to(d))
+    assert (out.cpu() - O.irt_link(irt, ability, item)).abs().max() < 2e-6
+
+
+# ---------------------------------------------------------------------------
+# (3) properties at BASELINE.json sizes
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('A,P', [(1, 100_000), (8, 100_000)])
+def test_full_size_shard_additivity_permutation_determinism(A, P):
+    """100k x 1k 2PL (BASELINE configs[1] shape; [2]'s ability_dim): the ELBO heads
+    and gradients of the whole batch equal the sum over two person shards (what
+    the 8-GPU person sharding relies on), are invariant to permuting persons,
+    and are bitwise reproducible."""
+    irt, I = 2, 1000
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(1234)
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    theta = torch.randn(P, A, device=d, generator=g)
+    item_true = torch.randn(I, A + 1, device=d, generator=g)
+    probs = torch.sigmoid(-(theta @ item_true[:, :A].t()) + item_true[:, A])
+    resp = torch.bernoulli(probs, generator=g)
+    mask = torch.rand(P, I, device=d, generator=g) > 0.1
+    table = (torch.randn(2, 2 * A, device=d, generator=g) * 0.5).contiguous()
+    item = torch.randn(I, A + 1, device=d, generator=g)
+    eps = torch.randn(P, A, device=d, generator=g)
+
+    def run(rows):
+        r, m = resp[rows].contiguous(), mask[rows].contiguous()
+        mm, code = ops.prepare_mask(m)
+        raw = ops._hip_launch_elbo(spec, r, mm, code, None, table, item, eps[rows].contiguous(), None,
+                                   _lib.REG_KL, True, r.shape[0])
+        return raw
+
+    allrows = torch.arange(P, device=d)
+    full = run(allrows)
+    again = run(allrows)
+    assert torch.equal(full.flat, again.flat), 'fused kernel must be bitwise deterministic'
+    h = P // 2 + 37
+    a, b = run(allrows[:h]), run(allrows[h:])
+    summed = a.flat + b.flat
+    assert rel_err(summed[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(summed[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    perm = torch.randperm(P, device=d, generator=g)
+    pf = run(perm)
+    assert rel_err(pf.flat[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(pf.flat[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    assert (pf.ability_mu - full.ability_mu[perm]).abs().max() < 1e-6
+
+    # and the full-size ELBO agrees with the CPU oracle on a 512-person slice
+    sl = allrows[:512]
+    ref = T.fused_elbo_ref(table.cpu().double(), item.cpu().double(), resp[sl].cpu().double(), mask[sl].cpu(),
+                           eps[sl].cpu().double(), irt_model=irt, ability_dim=A, mode='kl')
+    compare_raw(run(sl), ref, (I, A + 1))
