@@ -49,7 +49,7 @@ static int check_desc(const vibo_desc* d) {
 }
 
 struct Plan {
-    int AT, D, DP, item_blocks, n_tiles, nblk;
+    int AT, D, DP, n_tiles, nblk, lds_main;
     LaunchGeom geom;
     PartialLayout lay;
     size_t off_item_prep, off_partial, total_bytes;
@@ -62,18 +62,19 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->AT = padded_ability_dim(A);
     pl->D = item_feat_dim(d->irt_model, A);
     pl->DP = prepped_item_width(d->irt_model, pl->AT);
-    pl->item_blocks = (I + 63) / 64;
     pl->n_tiles = (d->num_person + kTilePersons - 1) / kTilePersons;
-    if (I > 2048) return fail(-4, "num_item %d > 2048 is not supported by the fused kernel yet", I);
+    if (I > 1024) return fail(-4, "num_item %d > 1024 is not supported by the fused kernel yet", I);
     int stride = (I + 15) & ~15;
     if (((stride / 16) & 1) == 0) stride += 16;   // odd multiple of 16 B: conflict-free ds_read_b128 across rows
-    int geo, waves;
-    if (I <= 512) { geo = 2; waves = 2; }
-    else if (I <= 1024) { geo = 0; waves = 8; }
-    else { geo = 1; waves = 8; }
-    size_t lds = (size_t)kTilePersons * stride + 2 * kTilePersons * 4 + 4 * 2 * pl->AT * 4;
-    const size_t red = (size_t)waves * (8 + 4 * pl->AT) * 4;
-    if (lds < red) lds = red;
+    // waves per workgroup (each wave owns <= SB 16-item blocks, see vibo_elbo_kernel.hpp geometry table);
+    // the code tile is double-buffered in LDS, 16/waves workgroups share a CU
+    const int waves = I <= 144 ? 2 : I <= 304 ? 4 : I <= 512 ? 8 : 16;
+    size_t main_b = (size_t)kTilePersons * stride;                    // one fp8 code tile
+    const size_t red = (size_t)waves * pl->AT * 64 * 4;               // per-wave dLL/dtheta partials (aliased)
+    if (main_b < red) main_b = red;
+    if (main_b < (size_t)waves * 32) main_b = (size_t)waves * 32;
+    main_b = (main_b + 15) & ~(size_t)15;
+    size_t lds = 2 * main_b + 2 * kTilePersons * 4 + 4 * 2 * pl->AT * 4;
     lds = (lds + 255) & ~(size_t)255;
     if (g_num_cu == 0) {
         int dev = 0, n = 0;
@@ -91,13 +92,13 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     int nblk = g_num_cu * per_cu;
     if (nblk > pl->n_tiles) nblk = pl->n_tiles;
     pl->nblk = nblk;
-    pl->geom.geo = geo;
+    pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
     pl->geom.grid = nblk;
     pl->geom.lds_bytes = lds;
     pl->lay = partial_layout(A, pl->D, I, d->n_flows);
     pl->off_item_prep = 0;
-    size_t prep_bytes = ((size_t)I * pl->DP * 4 + 255) & ~(size_t)255;
+    size_t prep_bytes = ((size_t)((I + 15) & ~15) * pl->DP * 4 + 255) & ~(size_t)255;
     pl->off_partial = prep_bytes;
     pl->total_bytes = prep_bytes + (size_t)nblk * pl->lay.stride * 4 + 256;
     return stride;
@@ -109,16 +110,22 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
 __global__ void item_prep_kernel(const float* __restrict__ item, float* __restrict__ prep, int I, int A, int AT,
                                  int D, int DP, int irt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= I) return;
-    const float* src = item + (size_t)i * D;
+    const int I16 = (I + 15) & ~15;
+    if (i >= I16) return;
     float* dst = prep + (size_t)i * DP;
+    if (i >= I) {            // zero rows pad the item axis to a multiple of 16
+        for (int a = 0; a < DP; ++a) dst[a] = 0.f;
+        return;
+    }
+    const float* src = item + (size_t)i * D;
+    // logits are carried in log2 units (x log2 e) so the kernel's exp2/log2 need no extra multiply
     if (irt == 1) {
-        dst[0] = src[0];
+        dst[0] = src[0] * kLog2e;
         return;
     }
     for (int a = 0; a < DP; ++a) dst[a] = 0.f;
-    for (int a = 0; a < A; ++a) dst[a] = -src[a];   // logit = -a.theta + b   (models.py:744,759)
-    dst[AT] = src[A];
+    for (int a = 0; a < A; ++a) dst[a] = -src[a] * kLog2e;   // logit = -a.theta + b   (models.py:744,759)
+    dst[AT] = src[A] * kLog2e;
     if (irt == 3) {
         const float g = 1.0f / (1.0f + expf(-src[A + 1]));   // guess = sigmoid(guess logit) (models.py:758)
         dst[AT + 1] = g;
@@ -309,7 +316,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
 
     float* item_prep = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_item_prep);
     float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_partial);
-    hipLaunchKernelGGL(item_prep_kernel, dim3((I + 255) / 256), dim3(256), 0, s, item, item_prep, I, A, pl.AT, pl.D,
+    hipLaunchKernelGGL(item_prep_kernel, dim3((I + 15 + 255) / 256), dim3(256), 0, s, item, item_prep, I, A, pl.AT, pl.D,
                        pl.DP, d->irt_model);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "item_prep launch");
@@ -322,7 +329,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     p.partial = partial;
     p.resp_stride = d->response_row_stride; p.mask_stride = d->mask_row_stride;
     p.B = d->num_person; p.I = I; p.A = A; p.D = pl.D; p.DP = pl.DP;
-    p.n_tiles = pl.n_tiles; p.item_blocks = pl.item_blocks; p.lds_stride = stride;
+    p.n_tiles = pl.n_tiles; p.lds_stride = stride; p.lds_main = pl.lds_main;
     p.mask_dtype = d->mask_dtype; p.missing_mode = d->missing_mode; p.reg_mode = d->reg_mode;
     p.lay = pl.lay;
     bool vec = (I % 4 == 0) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);

@@ -7,10 +7,9 @@
 
 namespace vibo {
 
-// geometry: 0 = 8 waves x 2 item slots (I <= 1024), 1 = 8 waves x 4 slots (I <= 2048),
-//           2 = 2 waves x 4 slots (I <= 512)
+// waves per workgroup: 2 (I <= 144), 4 (I <= 304), 8 (I <= 512), 16 (I <= 1024)
 struct LaunchGeom {
-    int geo, waves, grid;
+    int waves, grid;
     size_t lds_bytes;
 };
 

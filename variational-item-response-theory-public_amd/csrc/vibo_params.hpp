@@ -6,14 +6,13 @@
 namespace vibo {
 
 constexpr int kTilePersons = 64;   // persons per tile = lanes per wave
-constexpr int kMaxSlots = 4;       // 64-item blocks one wave owns (registers for item grads)
 
 // template ability width for a runtime ability_dim (1,2,4,8)
 inline int padded_ability_dim(int a) { return a <= 1 ? 1 : a <= 2 ? 2 : a <= 4 ? 4 : 8; }
 
 // floats per prepped item row (see item_prep_kernel):
-//   1PL: [b]                       2PL: [-a_0..-a_{AT-1}, b, 0..]
-//   3PL: [-a_0..-a_{AT-1}, b, guess, 1-guess, 0..]
+//   1PL: [b']                      2PL: [-a'_0..-a'_{AT-1}, b', 0..]
+//   3PL: [-a'_0..-a'_{AT-1}, b', guess, 1-guess, 0..]      (x' = x * log2(e): logits in log2 units)
 inline int prepped_item_width(int irt, int at) {
     if (irt == 1) return 1;
     if (at == 1) return irt == 2 ? 2 : 4;
@@ -54,7 +53,7 @@ struct ElboParams {
     float* partial;           // [nblk][stride]
     long long resp_stride, mask_stride;
     int B, I, A, D, DP;
-    int n_tiles, item_blocks, lds_stride;
+    int n_tiles, lds_stride, lds_main;
     int mask_dtype, missing_mode, reg_mode, vec_ok;
     PartialLayout lay;
 };
