@@ -42,4 +42,4 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 print(f'P={P} I={I} A={A} irt={a.irt} grad={not a.no_grad}: {ms:.3f} ms/call, {P*I/ms/1e9:.3f} T terms/s, '
-      f'{(5+12*A/I)*P*I/ms/1e9:.1f} GB/s algorithmic, ll={float(raw.scalars[0]):.1f}')
+      f'{(5+12*A/I)*P*I/ms/1e6:.0f} GB/s algorithmic, ll={float(raw.scalars[0]):.1f}')

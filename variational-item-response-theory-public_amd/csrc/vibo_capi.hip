@@ -70,11 +70,14 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     // the code tile is double-buffered in LDS, 16/waves workgroups share a CU
     const int waves = I <= 144 ? 2 : I <= 304 ? 4 : I <= 512 ? 8 : 16;
     size_t main_b = (size_t)kTilePersons * stride;                    // one fp8 code tile
-    const size_t red = (size_t)waves * pl->AT * 64 * 4;               // per-wave dLL/dtheta partials (aliased)
+    const size_t red = (size_t)waves * pl->AT * 65 * 4;               // per-wave dLL/dtheta partials (aliased)
     if (main_b < red) main_b = red;
     if (main_b < (size_t)waves * 32) main_b = (size_t)waves * 32;
     main_b = (main_b + 15) & ~(size_t)15;
-    size_t lds = 2 * main_b + 2 * kTilePersons * 4 + 4 * 2 * pl->AT * 4;
+    size_t lds = 2 * main_b                                            // double-buffered code tile
+                 + 2 * (size_t)(pl->AT + 1) * 65 * 4                   // [theta|valid] share, double-buffered
+                 + (size_t)waves * 16 * 20 * 4                         // per-wave G-tile transpose slab
+                 + 2 * kTilePersons * 4 + 4 * 2 * pl->AT * 4;          // counts, encoder-table constants
     lds = (lds + 255) & ~(size_t)255;
     if (g_num_cu == 0) {
         int dev = 0, n = 0;
@@ -119,11 +122,12 @@ __global__ void item_prep_kernel(const float* __restrict__ item, float* __restri
     }
     const float* src = item + (size_t)i * D;
     // logits are carried in log2 units (x log2 e) so the kernel's exp2/log2 need no extra multiply
-    if (irt == 1) {
-        dst[0] = src[0] * kLog2e;
+    for (int a = 0; a < DP; ++a) dst[a] = 0.f;
+    if (irt == 1) {          // logit = sum_a theta_a + b   (models.py:731)
+        for (int a = 0; a < A; ++a) dst[a] = kLog2e;
+        dst[AT] = src[0] * kLog2e;
         return;
     }
-    for (int a = 0; a < DP; ++a) dst[a] = 0.f;
     for (int a = 0; a < A; ++a) dst[a] = -src[a] * kLog2e;   // logit = -a.theta + b   (models.py:744,759)
     dst[AT] = src[A] * kLog2e;
     if (irt == 3) {

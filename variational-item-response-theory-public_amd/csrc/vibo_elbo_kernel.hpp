@@ -1,31 +1,29 @@
 // vibo_elbo_kernel.hpp -- fused VIBO ELBO forward+backward kernel for gfx950 (MI355X).
 //
-// One workgroup (NW waves) walks 64-person tiles of the response matrix:
+// One persistent workgroup (NW waves) per CU-slot walks 64-person tiles of the response matrix.
 //
-//  phase A  "load + pack"  (lane = item chunk, coalesced):  every wave streams its
-//           rows of the tile from HBM with 16-byte loads (float4 response + 4 mask
-//           bytes per lane), packs each cell into ONE fp8 byte  w = +1 (correct) /
-//           -1 (wrong) / 0 (missing)  in an LDS tile, and wave-reduces the per-row
-//           counts (n_correct, n_observed) the unconditional product of experts
-//           needs (models.py:596-629 collapses to those counts).
-//  phase B  "person per lane": lane p owns person p of the tile (theta and
-//           dLL/dtheta live in its registers); the NW waves split the items in
-//           16-item blocks; item parameters are wave-uniform and arrive through
-//           scalar loads.  Per term: logit -> masked Bernoulli log-lik (softplus
-//           form; the reference's probability clamp is a wave-uniform rare path)
-//           -> g = dLL/dlogit -> dLL/dtheta += g * dlogit/dtheta (in lane).
-//           dLL/ditem = G^T . [theta | 1] is a contraction over the 64 PERSONS of
-//           the tile, i.e. over lanes: the 16 g-registers of a block are transposed
-//           inside each row of 16 lanes (DPP butterfly) into the A-operand layout of
-//           v_mfma_f32_16x16x4_f32 and 16 MFMAs (exact fp32) accumulate the
-//           [16 items x (A+2)] gradient tile; the matrix pipe runs beside the VALU.
-//  epilogue per-wave partial dLL/dtheta -> LDS -> each wave owns ability dims
-//           a = wave (mod NW): backward through the reparameterised sample and the
-//           product of experts into per-lane table-gradient accumulators; KL /
-//           log q - log p side; [B,A] posterior outputs.
+//  loader   every wave owns 64/NW rows of each tile.  While it computes block s of the CURRENT tile it
+//           has one step (4 x 1 KB of 16-byte loads = 20 VGPRs) of the NEXT tile in flight, then packs
+//           it: each cell becomes ONE fp8 byte  w = +1 (correct) / -1 (wrong) / 0 (missing)  in the
+//           other half of a double-buffered LDS tile, and the per-row counts (n_correct, n_observed)
+//           the unconditional product of experts needs (models.py:596-629 collapses to those counts)
+//           are wave-reduced.  Each response row is read from HBM exactly once.
+//  phase B  the 1PL/2PL/3PL decode and its backward are three small GEMMs per (64 persons x 16 items)
+//           block, all on the matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32), so the VALU only does
+//           the elementwise logistic math:
+//             L  [16p x 16i] = [theta|1] . [-a|b]^T            (K = A+1)      logits, log2 units
+//             elementwise on the MFMA D layout (lane = (4 persons, 1 item)):
+//                 masked Bernoulli log-lik (softplus form, reference clamp semantics), g = dLL/dL
+//             dI [16i x 16c] += G^T . [theta|1]                (K = 64 persons) d LL / d item
+//                 -- the D-layout registers of G ARE the A operand of this product: no shuffle
+//             dT [16p x 16a] += G . [-a]                        (K = 16 items)  d LL / d theta
+//                 -- needs G transposed: 16x16 tile through a per-wave LDS staging slab
+//  epilogue per-wave partial dLL/dtheta -> LDS -> the wave that owns ability dim a pushes it through
+//           the reparameterised sample and the product of experts into table-gradient accumulators,
+//           adds the KL / (log q - log p) side, writes the [B,A] posterior outputs, and prepares
+//           [theta|1] of the NEXT tile in LDS for all waves.
 //
-// Each response row is read from HBM exactly once.  All reductions have a fixed
-// order for a fixed grid, so results are bitwise reproducible.
+// All reductions have a fixed order for a fixed grid, so results are bitwise reproducible.
 #pragma once
 #include "vibo_device.hpp"
 #include "vibo_params.hpp"
@@ -178,7 +176,7 @@ __device__ __forceinline__ void phase_a_scalar(const ElboParams& p, const int ti
 // ---------------------------------------------------------------------------
 template <int A>
 __device__ __forceinline__ PersonDim person_dim(const ElboParams& p, const float* ctab, const uint32_t cnt,
-                                                const long long grow, const bool valid, const int a) {
+                                                const float eps, const int a) {
     PersonDim d;
     d.n1 = (float)(cnt >> 16);
     const float nobs = (float)(cnt & 0xffffu);
@@ -193,64 +191,39 @@ __device__ __forceinline__ PersonDim person_dim(const ElboParams& p, const float
     d.inv_lam = 1.0f / lam;
     d.amu = s * d.inv_lam;
     d.sig = fast_rsq(lam);
-    d.eps = valid ? p.eps[grow * p.A + a] : 0.0f;
+    d.eps = eps;
     return d;
 }
 
 // ---------------------------------------------------------------------------
-// 16x16 transpose of a[16] inside every row of 16 lanes:  a'[t] @ pos m  =  a[m] @ pos t
-// (4 butterfly stages; stage S swaps bit S of the lane position with bit S of the register index)
-// ---------------------------------------------------------------------------
-template <int S>
-__device__ __forceinline__ float row_xor(float v) {
-    if constexpr (S == 1) return dpp_f<0xb1>(v);            // quad_perm [1,0,3,2]
-    else if constexpr (S == 2) return dpp_f<0x4e>(v);       // quad_perm [2,3,0,1]
-    else if constexpr (S == 8) return dpp_f<0x128>(v);      // row_ror 8
-    else return dpp_f<0x1b>(dpp_f<0x141>(v));               // row_half_mirror (^7) then quad_perm [3,2,1,0] (^3) = ^4
-}
-
-template <int S>
-__device__ __forceinline__ void transpose_stage(float (&a)[16], const bool bit) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if ((r & S) == 0) {
-            const float lo = a[r], hi = a[r | S];
-            const float recv = row_xor<S>(bit ? lo : hi);
-            a[r] = bit ? recv : lo;
-            a[r | S] = bit ? hi : recv;
-        }
-    }
-}
-
-__device__ __forceinline__ void transpose16(float (&a)[16], const int lane) {
-    transpose_stage<8>(a, (lane & 8) != 0);
-    transpose_stage<4>(a, (lane & 4) != 0);
-    transpose_stage<2>(a, (lane & 2) != 0);
-    transpose_stage<1>(a, (lane & 1) != 0);
-}
-
-// ---------------------------------------------------------------------------
 // the kernel
-// ---------------------------------------------------------------------------
 // geometry (NW waves, SB 16-item blocks per wave, CMAX 64-lane float4 chunks per row):
 //   (16,4,4) I <= 1024   (8,4,2) I <= 512   (4,8,2) I <= 304   (2,8,1) I <= 144
+// LDS: code tile [2][64][lds_stride] | share [2][A+1][64] ([theta|valid] of a tile) |
+//      stage [NW][16][20] (G-tile transpose) | counts [2][64] | ctab [4][2][A]
+// ---------------------------------------------------------------------------
 template <int A, int IRT, int NW, int SB, int CMAX, bool GRAD>
 __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
-    constexpr int AP = (A + 1) / 2;                       // float2 pairs
+    constexpr int KK = (A + 1 + 3) / 4;                   // K chunks of the logit GEMM ([theta|1] has A+1 columns)
     constexpr int DPW = (A + NW - 1) / NW;                // ability dims a wave owns in the epilogue
+    constexpr int SROW = 20;                              // staging row stride (floats): conflict-free b32 writes
+    constexpr int PS = 65;                                // person-row stride (floats) of share / red: spreads MFMA-layout reads over banks
     constexpr float kLoS = kLogitLo * kLog2e, kHiS = kLogitHi * kLog2e;   // clamp bounds in log2 units
 
-    // LDS: two code tiles [64][lds_stride] (double buffer) | counts [2][64] | ctab [4][2][A]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* counts_base = reinterpret_cast<uint32_t*>(smem + 2 * p.lds_main);
+    float* share_base = reinterpret_cast<float*>(smem + 2 * p.lds_main);
+    float* stage_base = share_base + 2 * (A + 1) * PS;
+    uint32_t* counts_base = reinterpret_cast<uint32_t*>(stage_base + NW * 16 * SROW);
     float* ctab = reinterpret_cast<float*>(counts_base + 2 * kTilePersons);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gq = lane >> 4, nq = lane & 15;             // MFMA lane coordinates
     const int I = p.I;
     const int Ar = p.A;
     const int stride = p.lds_stride;
+    float* stage = stage_base + wave * 16 * SROW;
 
     // ---- encoder-table constants -> LDS ------------------------------------
     if (tid < 2 * A) {
@@ -269,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
     }
 
     // ---- persistent per-lane accumulators -----------------------------------
-    float4v acc_item[SB];      // MFMA accumulators: lane (g,n), reg r  <->  item 16*blk + 4g + r, column n
+    float4v acc_item[SB];      // d LL/d item tiles: lane (g,c), reg r  <->  item 16*blk + 4g + r, column c
     float acc_t[DPW][8];       // table grads of the dims this wave owns: [set*4 + c*2 + {m,s}]
 #pragma unroll
     for (int s = 0; s < SB; ++s) acc_item[s] = float4v{0.f, 0.f, 0.f, 0.f};
@@ -279,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
         for (int j = 0; j < 8; ++j) acc_t[k][j] = 0.f;
     float s_log = 0.f, s_kl = 0.f, s_logq0 = 0.f, s_logp = 0.f, s_nobs = 0.f;
 
-    // ---- prologue: this block's first tile -> buffer 0 (no overlap) -----------
+    // ---- loaders ------------------------------------------------------------
     TileLoader<NW, CMAX> ld;
     auto load_issue = [&](int tl, int step) {
         if (p.mask_dtype == 0) ld.template issue<0>(p, tl, wave, lane, step);
@@ -294,7 +267,38 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
         else if (p.mask_dtype == 1) phase_a_scalar<NW, 1>(p, tl, wave, lane, cd, ct);
         else phase_a_scalar<NW, 2>(p, tl, wave, lane, cd, ct);
     };
+    // [theta | valid] of one tile -> share (each ability dim is produced by its owner wave; lane = person)
+    auto make_share = [&](int tl, const uint32_t* cnts, float* share, const float (&epsv)[DPW]) {
+        const long long grow = (long long)tl * kTilePersons + lane;
+        const bool valid = grow < p.B;
+        const uint32_t cnt = cnts[lane];
+#pragma unroll
+        for (int k = 0; k < DPW; ++k) {
+            const int a = wave + NW * k;
+            if (a < A) {
+                float th = 0.f;
+                if (a < Ar && valid) {
+                    const PersonDim d = person_dim<A>(p, ctab, cnt, epsv[k], a);
+                    th = d.amu + d.sig * d.eps;
+                }
+                share[a * PS + lane] = th;
+            }
+        }
+        if (wave == NW - 1) share[A * PS + lane] = valid ? 1.f : 0.f;
+    };
+    auto load_eps = [&](int tl, float (&epsv)[DPW]) {
+        const long long grow = (long long)tl * kTilePersons + lane;
+#pragma unroll
+        for (int k = 0; k < DPW; ++k) {
+            const int a = wave + NW * k;
+            epsv[k] = (a < Ar && grow < p.B) ? p.eps[grow * Ar + a] : 0.f;
+        }
+    };
+
+    // ---- prologue: this block's first tile -> buffer 0 (no overlap) -----------
     constexpr int NSTEP = TileLoader<NW, CMAX>::NSTEP;
+    float eps_cur[DPW], eps_nxt[DPW];
+    load_eps(blockIdx.x, eps_cur);
     if (p.vec_ok) {
 #pragma unroll 1
         for (int st = 0; st < NSTEP; ++st) {
@@ -304,6 +308,8 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
     } else {
         load_scalar(blockIdx.x, smem, counts_base);
     }
+    __syncthreads();
+    make_share(blockIdx.x, counts_base, share_base, eps_cur);
 
     int buf = 0;
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x, buf ^= 1) {
@@ -311,56 +317,19 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
         unsigned char* codes_nxt = smem + (buf ^ 1) * p.lds_main;       // being filled for the next tile
         uint32_t* counts = counts_base + buf * kTilePersons;
         uint32_t* counts_nxt = counts_base + (buf ^ 1) * kTilePersons;
+        const float* share = share_base + buf * (A + 1) * PS;
+        float* share_nxt = share_base + (buf ^ 1) * (A + 1) * PS;
         float* red = reinterpret_cast<float*>(codes);                   // aliases the current tile after S2
         const int next_tile = tile + gridDim.x;
         const bool has_next = next_tile < p.n_tiles;
-        __syncthreads();   // S1: current tile (codes + counts) complete; previous epilogue done with its buffer
+        __syncthreads();   // S1: codes / counts / share of the current tile complete
 
-        // ================= phase B ==========================================
-        const long long grow = (long long)tile * kTilePersons + lane;
-        const bool valid = grow < p.B;
-        const uint32_t cnt = counts[lane];
+        if (has_next) load_eps(next_tile, eps_nxt);   // latency hidden under the item loop
 
-        float th[2 * AP];
+        float4v acc_g[4];      // d LL/d theta tiles: lane (g,a), reg r <-> person 16pt+4g+r, dim a  (x log2e)
 #pragma unroll
-        for (int a = 0; a < 2 * AP; ++a) th[a] = 0.f;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-            if (a < Ar) {
-                const PersonDim d = person_dim<A>(p, ctab, cnt, grow, valid, a);
-                th[a] = valid ? (d.amu + d.sig * d.eps) : 0.f;
-            }
-        }
-        float th_sum = 0.f;   // 1PL: logit = sum_a theta_a + b (kept in log2 units like the prepped b)
-#pragma unroll
-        for (int a = 0; a < A; ++a) th_sum += th[a];
-        th_sum *= kLog2e;
-        float2v th2[AP];
-#pragma unroll
-        for (int j = 0; j < AP; ++j) th2[j] = float2v{th[2 * j], th[2 * j + 1]};
+        for (int pt = 0; pt < 4; ++pt) acc_g[pt] = float4v{0.f, 0.f, 0.f, 0.f};
 
-        // B operand of the item-gradient MFMAs: column n of [theta | 1], transposed so that in MFMA t
-        // lane (g,n) supplies column n of person 16g+t
-        float bt[16];
-        if constexpr (GRAD) {
-#pragma unroll
-            for (int n = 0; n < 16; ++n) bt[n] = 0.f;
-            if constexpr (IRT == 1) {
-                bt[0] = valid ? 1.f : 0.f;
-            } else {
-#pragma unroll
-                for (int a = 0; a < A; ++a) bt[a] = th[a];
-                bt[A] = valid ? 1.f : 0.f;
-            }
-            transpose16(bt, lane);
-        }
-
-        float2v gth2[AP];     // d LL / d theta of this wave's items, in units of log2e (2PL/3PL)
-#pragma unroll
-        for (int j = 0; j < AP; ++j) gth2[j] = float2v{0.f, 0.f};
-        float gth_sum = 0.f;  // 1PL
-
-        const unsigned char* my_codes = codes + lane * stride;
 #pragma unroll 1
         for (int s = 0; s < SB; ++s) {
             const int b16 = wave + NW * s;          // 16-item block index (round-robin over waves)
@@ -371,46 +340,46 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i0 < I) {
-            const uint4 cw = *reinterpret_cast<const uint4*>(my_codes + i0);
-            const uint32_t cwa[4] = {cw.x, cw.y, cw.z, cw.w};
-            float g[16], gg[16];
+                // ---- per-block operands from the prepped item rows (L2/L1 resident, zero padded) ----
+                const float* irow = p.item_prep + (size_t)(i0 + nq) * p.DP;          // item i0+n
+                float bop[KK];                        // B of the logit GEMM: lane (g,n) = row[item n][4kk+g]
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                g[j] = 0.f;
-                if constexpr (IRT == 3) gg[j] = 0.f;
-            }
+                for (int kk = 0; kk < KK; ++kk) bop[kk] = (4 * kk + gq < p.DP) ? irow[4 * kk + gq] : 0.f;
+                float gs = 0.f, om = 0.f;
+                if constexpr (IRT == 3) {
+                    gs = irow[A + 1];
+                    om = irow[A + 2];
+                }
+                float ai[4];                          // B of the d-theta GEMM: lane (g,a) = -a'[item 4g+r][a]
+                if constexpr (GRAD) {
 #pragma unroll
-            for (int wq = 0; wq < 4; ++wq) {
+                    for (int r = 0; r < 4; ++r)
+                        ai[r] = (nq < A) ? p.item_prep[(size_t)(i0 + 4 * gq + r) * p.DP + nq] : 0.f;
+                }
+                float4v cur = float4v{0.f, 0.f, 0.f, 0.f};
+                const unsigned char* cbase = codes + (4 * gq) * stride + i0 + nq;
+#pragma unroll 1
+                for (int pt = 0; pt < 4; ++pt) {
+                    // logits of persons 16pt+4g+r (r = 0..3) x item i0+n:
+                    //   A operand @ lane (g,i) = [theta|1][person 16pt+i][column 4kk+g]  (from the tile's share)
+                    float4v L = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = wq * 4 + jj;
-                    const int i = i0 + j;          // items >= I are zero-padded: code 0, item row 0
-                    {
-                        const uint32_t word = cwa[wq];
-                        float w;
-                        if (jj == 0) w = code_to_f32<0>(word);
-                        else if (jj == 1) w = code_to_f32<1>(word);
-                        else if (jj == 2) w = code_to_f32<2>(word);
-                        else w = code_to_f32<3>(word);
-                        const const_f32_ptr ip = as_constant(p.item_prep + (size_t)i * p.DP);   // uniform -> s_load
-                        // ---- logit, in log2 units (item rows are pre-scaled by log2 e) ----
-                        float l;
-                        if constexpr (IRT == 1) {
-                            l = ip[0] + th_sum;
-                        } else if constexpr (A == 1) {
-                            l = fmaf(ip[0], th[0], ip[1]);
-                        } else {
-                            float2v acc = float2v{ip[A], 0.f};
+                    for (int kk = 0; kk < KK; ++kk) {
+                        const int c = 4 * kk + gq;
+                        const float aop = (c <= A) ? share[c * PS + 16 * pt + nq] : 0.f;
+                        L = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, bop[kk], L, 0, 0, 0);
+                    }
+                    float G[4], GG[4];
 #pragma unroll
-                            for (int q = 0; q < AP; ++q) acc = float2v{ip[2 * q], ip[2 * q + 1]} * th2[q] + acc;
-                            l = acc.x + acc.y;
-                        }
-                        float gl = 0.f;   // d ll / d logit (natural units)
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t cb = cbase[(16 * pt + r) * stride];
+                        const float w = code_to_f32<0>(cb);
+                        const float l = L[r];
+                        float gl = 0.f;
                         if constexpr (IRT != 3) {
-                            // ll = log sigmoid(w*l) = -softplus(u), u = -w*l.  The reference clamps the
-                            // probability to [eps32, 1-eps32] (utils.py:46-49 -> torch Bernoulli): value
-                            // clamped at +-kLogitLo, gradient exactly zero outside [-kLogitLo, kLogitHi]
-                            // (branch-free: a rare-path branch here makes hipcc spill the item rows).
+                            // ll = log sigmoid(w*l) = -softplus(u), u = -w*l.  Reference clamp (utils.py:46-49
+                            // -> torch Bernoulli probs clamp): value clamped at +-kLogitLo, gradient exactly
+                            // zero outside [-kLogitLo, kLogitHi].
                             const float l2 = med3(l, -kLoS, kHiS);
                             const float lc = fminf(l2, kLoS);
                             const float wg = (l == l2) ? w : 0.f;
@@ -419,57 +388,54 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
                             s_log = fmaf(fabsf(w), fast_log2(t), s_log);      // softplus(u)/ln2, masked
                             if constexpr (GRAD) gl = wg * (eu * fast_rcp(t));  // w * sigmoid(u)
                         } else {
-                            const float guess = ip[A + 1], omg = ip[A + 2];
                             const float e = fast_exp2(-fabsf(l));
-                            const float r = fast_rcp(1.0f + e);
-                            const float er = e * r;
-                            const float sp = (l >= 0.f) ? r : er;          // sigmoid(l)
-                            const float sn = (l >= 0.f) ? er : r;          // sigmoid(-l)
-                            const float pr = fmaf(omg, sp, guess);         // P(correct)  (models.py:765)
-                            const float qr = omg * sn;                     // P(wrong)
+                            const float rr = fast_rcp(1.0f + e);
+                            const float er = e * rr;
+                            const float sp = (l >= 0.f) ? rr : er;         // sigmoid(l)
+                            const float sn = (l >= 0.f) ? er : rr;         // sigmoid(-l)
+                            const float pr = fmaf(om, sp, gs);             // P(correct)  (models.py:765)
+                            const float qr = om * sn;                      // P(wrong)
                             const float pc = med3(pr, kEps32, 1.0f - kEps32);
                             const float arg = (w > 0.f) ? pc : med3(qr, kEps32, 1.0f - kEps32);
                             s_log = fmaf(fabsf(w), fast_log2(arg), s_log);
                             if constexpr (GRAD) {
                                 const float wl = (pr == pc) ? w : 0.f;     // clamp kills the gradient
-                                const float common = wl * fast_rcp(arg) * omg * sn;   // (x/p-(1-x)/(1-p)) (1-g) sig(-l)
+                                const float common = wl * fast_rcp(arg) * om * sn;   // (x/p-(1-x)/(1-p)) (1-g) sig(-l)
                                 gl = common * sp;                          // * d p / d logit
-                                gg[j] = common * guess;                    // * d p / d guess-logit
+                                GG[r] = common * gs;                       // * d p / d guess-logit
                             }
                         }
-                        if constexpr (GRAD) {
-                            g[j] = gl;
-                            if constexpr (IRT == 1) {
-                                gth_sum += gl;
-                            } else if constexpr (A == 1) {
-                                gth2[0].x = fmaf(gl, ip[0], gth2[0].x);
-                            } else {
-                                const float2v g2 = float2v{gl, gl};
+                        G[r] = gl;
+                    }
+                    if constexpr (GRAD) {
+                        // d LL/d item: A = G (its D layout is already A[i=item n][k=g]), B = [theta|1] of person 16pt+4g+r
 #pragma unroll
-                                for (int q = 0; q < AP; ++q)
-                                    gth2[q] = g2 * float2v{ip[2 * q], ip[2 * q + 1]} + gth2[q];
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            const float bt = (nq <= A) ? share[nq * PS + 16 * pt + 4 * gq + r] : 0.f;
+                            cur = __builtin_amdgcn_mfma_f32_16x16x4f32(G[r], bt, cur, 0, 0, 0);
                         }
+                        if constexpr (IRT == 3) {
+                            const float bgc = (nq == A + 1) ? 1.f : 0.f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cur = __builtin_amdgcn_mfma_f32_16x16x4f32(GG[r], bgc, cur, 0, 0, 0);
+                        }
+                        // d LL/d theta: transpose the 16x16 G tile through the staging slab
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stage[(4 * gq + r) * SROW + nq] = G[r];
+                        const float4v GT = *reinterpret_cast<const float4v*>(stage + nq * SROW + 4 * gq);
+                        float4v ag = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ag = __builtin_amdgcn_mfma_f32_16x16x4f32(GT[r], ai[r], ag, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q == pt) acc_g[q] += ag;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);   // keep the scalar item-row loads of later groups below
-            }
-            if constexpr (GRAD) {
-                // dLL/ditem[16 x 16] += G^T[16 items x 64 persons] . [theta|1][64 persons x 16]
-                transpose16(g, lane);
-                float4v cur = float4v{0.f, 0.f, 0.f, 0.f};
+                if constexpr (GRAD) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) cur = __builtin_amdgcn_mfma_f32_16x16x4f32(g[t], bt[t], cur, 0, 0, 0);
-                if constexpr (IRT == 3) {
-                    transpose16(gg, lane);
-                    const float bg = ((lane & 15) == A + 1) ? 1.f : 0.f;   // guess-logit column
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) cur = __builtin_amdgcn_mfma_f32_16x16x4f32(gg[t], bg, cur, 0, 0, 0);
+                    for (int ss = 0; ss < SB; ++ss)
+                        if (ss == s) acc_item[ss] += cur;
                 }
-#pragma unroll
-                for (int ss = 0; ss < SB; ++ss)
-                    if (ss == s) acc_item[ss] += cur;
-            }
             }
             if (prefetch) load_commit(next_tile, s, codes_nxt, counts_nxt);
         }
@@ -486,24 +452,30 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
                 load_scalar(next_tile, codes_nxt, counts_nxt);
             }
         }
-        __syncthreads();   // S2: every wave is done reading the current code tile
+        __syncthreads();   // S2: current code tile is dead; counts of the next tile are complete
 
         // ================= epilogue =========================================
         if constexpr (GRAD) {
+            // partial d LL/d theta of this wave's items: lane (g,a), reg r <-> person 16pt+4g+r, dim a
+            if (nq < A) {
 #pragma unroll
-            for (int a = 0; a < A; ++a) {
-                float gv;
-                if constexpr (IRT == 1) gv = gth_sum;
-                else gv = ((a & 1) ? gth2[a >> 1].y : gth2[a >> 1].x) * kLn2;   // item rows carried log2 e
-                red[(wave * A + a) * 64 + lane] = gv;
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[(wave * A + nq) * PS + 16 * pt + 4 * gq + r] = acc_g[pt][r] * kLn2;   // rows carried log2 e
             }
-            __syncthreads();   // S3: partial dLL/dtheta of all waves visible
         }
+        if (has_next) make_share(next_tile, counts_nxt, share_nxt, eps_nxt);
+        __syncthreads();       // S3: partial dLL/dtheta of all waves visible
+
+        const long long grow = (long long)tile * kTilePersons + lane;
+        const bool valid = grow < p.B;
+        const uint32_t cnt = counts[lane];
 #pragma unroll
         for (int k = 0; k < DPW; ++k) {
             const int a = wave + NW * k;
             if (a < Ar && valid) {
-                const PersonDim d = person_dim<A>(p, ctab, cnt, grow, valid, a);
+                const PersonDim d = person_dim<A>(p, ctab, cnt, eps_cur[k], a);
                 const float alv = -kLn2 * fast_log2(d.lam);
                 const float theta0 = d.amu + d.sig * d.eps;
                 p.ability_mu[grow * Ar + a] = d.amu;
@@ -516,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
                 if constexpr (GRAD) {
                     float g0 = 0.f;                                  // d LL / d theta_0[a], all items
 #pragma unroll
-                    for (int w2 = 0; w2 < NW; ++w2) g0 += red[(w2 * A + a) * 64 + lane];
+                    for (int w2 = 0; w2 < NW; ++w2) g0 += red[(w2 * A + a) * PS + lane];
                     const float h = 0.5f * d.sig * d.eps;            // d theta / d logvar
                     float gmu[2], glv[2];
                     gmu[0] = g0;
@@ -546,6 +518,8 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
             }
         }
         if (wave == 0 && valid) s_nobs += (float)(cnt & 0xffffu);
+#pragma unroll
+        for (int k = 0; k < DPW; ++k) eps_cur[k] = eps_nxt[k];
     }
     __syncthreads();
 
@@ -582,16 +556,15 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
                 }
             }
         }
-        // item grads: MFMA tile of slot s: lane (g,n), reg r <-> item 16*(wave+NW*s) + 4g + r, column n
-        const int n = lane & 15, gq = lane >> 4;
+        // item grads: MFMA tile of slot s: lane (g,c), reg r <-> item 16*(wave+NW*s) + 4g + r, column c
         int col = -1;                       // output column of [I][D] this lane's MFMA column maps to
         bool neg = false;
         if constexpr (IRT == 1) {
-            if (n == 0) col = 0;
+            if (nq == A) col = 0;                       // d/d b_i = sum_p g
         } else {
-            if (n < Ar) { col = n; neg = true; }     // d/d a_ia = -sum_p g * theta_a
-            else if (n == A) col = Ar;               // d/d b_i  =  sum_p g
-            else if (IRT == 3 && n == A + 1) col = Ar + 1;
+            if (nq < Ar) { col = nq; neg = true; }      // d/d a_ia = -sum_p g * theta_a
+            else if (nq == A) col = Ar;                 // d/d b_i  =  sum_p g
+            else if (IRT == 3 && nq == A + 1) col = Ar + 1;
         }
 #pragma unroll
         for (int s = 0; s < SB; ++s) {

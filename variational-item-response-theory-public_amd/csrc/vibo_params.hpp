@@ -11,12 +11,12 @@ constexpr int kTilePersons = 64;   // persons per tile = lanes per wave
 inline int padded_ability_dim(int a) { return a <= 1 ? 1 : a <= 2 ? 2 : a <= 4 ? 4 : 8; }
 
 // floats per prepped item row (see item_prep_kernel):
-//   1PL: [b']                      2PL: [-a'_0..-a'_{AT-1}, b', 0..]
+//   1PL: [+1'.. (A times), b', 0..]  2PL: [-a'_0..-a'_{AT-1}, b', 0..]
 //   3PL: [-a'_0..-a'_{AT-1}, b', guess, 1-guess, 0..]      (x' = x * log2(e): logits in log2 units)
+// i.e. logit' = row[0..AT] . [theta_0..theta_{AT-1}, 1]  for every model
 inline int prepped_item_width(int irt, int at) {
-    if (irt == 1) return 1;
-    if (at == 1) return irt == 2 ? 2 : 4;
-    if (at == 2) return irt == 2 ? 4 : 8;
+    if (at == 1) return irt != 3 ? 2 : 4;
+    if (at == 2) return irt != 3 ? 4 : 8;
     if (at == 4) return 8;
     return 12;
 }
