@@ -8,6 +8,7 @@
 
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
+#include "vibo_general.hpp"
 #include "vibo_launch.hpp"
 #include "vibo_params.hpp"
 
@@ -49,6 +50,7 @@ static int check_desc(const vibo_desc* d) {
 }
 
 struct Plan {
+    bool general;             // wave-per-person kernel (conditional posterior / flows / > 1024 items)
     int AT, D, DP, n_tiles, nblk, lds_main;
     LaunchGeom geom;
     PartialLayout lay;
@@ -63,7 +65,16 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->D = item_feat_dim(d->irt_model, A);
     pl->DP = prepped_item_width(d->irt_model, pl->AT);
     pl->n_tiles = (d->num_person + kTilePersons - 1) / kTilePersons;
-    if (I > 1024) return fail(-4, "num_item %d > 1024 is not supported by the fused kernel yet", I);
+    pl->general = d->posterior == VIBO_POSTERIOR_CONDITIONAL || d->n_flows > 0 || I > 1024;
+    if (pl->general) {
+        pl->nblk = 0;
+        pl->lds_main = 0;
+        pl->lay = partial_layout(A, pl->D, I, d->n_flows);
+        pl->off_item_prep = 0;
+        pl->off_partial = 0;
+        pl->total_bytes = 256;            // 8 scalar accumulators
+        return 16;
+    }
     int stride = (I + 15) & ~15;
     if (((stride / 16) & 1) == 0) stride += 16;   // odd multiple of 16 B: conflict-free ds_read_b128 across rows
     // waves per workgroup (each wave owns <= SB 16-item blocks, see vibo_elbo_kernel.hpp geometry table);
@@ -305,10 +316,8 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
     if (d->want_grad && (!grad_table || !grad_item)) return fail(-5, "want_grad needs grad_table and grad_item");
-    if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL)
-        return fail(-6, "conditional posterior is not implemented in the fused kernel yet");
-    if (d->n_flows != 0) return fail(-6, "planar flows are not implemented in the fused kernel yet");
-    (void)flow; (void)ability_k; (void)ability_ladj; (void)grad_flow;
+    if (d->n_flows > 0 && (!flow || !ability_k || !ability_ladj)) return fail(-5, "flows need flow, ability_k, ability_ladj");
+    if (d->n_flows > 0 && d->want_grad && !grad_flow) return fail(-5, "want_grad with flows needs grad_flow");
     Plan pl;
     const int stride = make_plan(d, &pl);
     if (stride < 0) return stride;
@@ -317,6 +326,33 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     if ((uintptr_t)workspace & 255) return fail(-7, "workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int I = d->num_item, A = d->ability_dim;
+
+    if (pl.general) {
+        const size_t n_table = (size_t)(d->posterior == VIBO_POSTERIOR_CONDITIONAL ? 2 * I * 2 * A : 2 * 2 * A);
+        const size_t n_flow = (size_t)d->n_flows * (2 * A + 1);
+        hipError_t ge = hipMemsetAsync(workspace, 0, 256, s);
+        if (ge == hipSuccess && d->want_grad) {
+            ge = hipMemsetAsync(grad_table, 0, 2 * n_table * sizeof(float), s);
+            if (ge == hipSuccess) ge = hipMemsetAsync(grad_item, 0, (size_t)I * pl.D * sizeof(float), s);
+            if (ge == hipSuccess && n_flow) ge = hipMemsetAsync(grad_flow, 0, 2 * n_flow * sizeof(float), s);
+        }
+        if (ge != hipSuccess) return hip_fail(ge, "memset");
+        GeneralParams g;
+        memset(&g, 0, sizeof(g));
+        g.response = response; g.mask = mask; g.row_index = row_index; g.table = table; g.item = item; g.eps = eps;
+        g.flow = flow; g.ability_mu = ability_mu; g.ability_logvar = ability_logvar; g.ability = ability;
+        g.ability_k = ability_k; g.ability_ladj = ability_ladj;
+        g.grad_table = grad_table; g.grad_item = grad_item; g.grad_flow = grad_flow;
+        g.acc_scalars = static_cast<float*>(workspace); g.out_scalars = out_scalars;
+        g.resp_stride = d->response_row_stride; g.mask_stride = d->mask_row_stride;
+        g.B = d->num_person; g.I = I; g.A = A; g.D = pl.D; g.irt = d->irt_model;
+        g.conditional = d->posterior == VIBO_POSTERIOR_CONDITIONAL; g.missing_mode = d->missing_mode;
+        g.mask_dtype = d->mask_dtype; g.reg_mode = d->reg_mode; g.n_flows = d->n_flows; g.want_grad = d->want_grad;
+        if (g_num_cu == 0) g_num_cu = 256;
+        ge = launch_elbo_general(g, g_num_cu, s);
+        if (ge != hipSuccess) return hip_fail(ge, "general elbo kernel launch");
+        return 0;
+    }
 
     float* item_prep = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_item_prep);
     float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_partial);
