@@ -234,6 +234,22 @@ def log_marginal_case(ref_models, out_dir):
         np.savez_compressed(os.path.join(out_dir, f'{name}.npz'), **rec)
 
 
+def artificial_mask_case(out_dir):
+    """artificially_mask_dataset of the reference (datasets.py:46-78) on a 200 x 95 matrix, perc 0.2."""
+    from src.datasets import artificially_mask_dataset
+
+    class D:
+        pass
+    rs = np.random.RandomState(7)
+    d = D()
+    d.response = (rs.rand(200, 95) < 0.6).astype(np.int64)
+    d.mask = np.ones_like(d.response)
+    out = artificially_mask_dataset(d, 0.2)
+    np.savez_compressed(os.path.join(out_dir, 'artificial_mask.npz'), response=d.response, mask=d.mask,
+                        missing_indices=out.missing_indices, missing_labels=out.missing_labels,
+                        masked_mask=out.mask, masked_response=out.response)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -246,6 +262,7 @@ def main():
         print(f'{case[0]:34s} loss={loss:.6f}')
     saturation_case(ref_utils, out_dir)
     log_marginal_case(ref_models, out_dir)
+    artificial_mask_case(out_dir)
     print('wrote', out_dir)
 
 

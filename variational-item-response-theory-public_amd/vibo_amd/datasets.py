@@ -1,0 +1,172 @@
+"""Dataset loaders with the reference's contract (src/datasets.py).
+
+``load_dataset(name, train, num_person, num_item, ability_dim, max_num_person,
+max_num_item)`` returns a ``torch.utils.data.Dataset`` whose ``__getitem__``
+yields ``(index, response f32, item_id i64, mask bool)`` exactly like the
+reference (datasets.py:429-440, 928-940), and which additionally exposes the
+whole matrix (``.response`` / ``.mask`` numpy arrays, -1 = missing) so the
+trainer can keep it resident in HBM and gather minibatch rows inside the kernel
+instead of collating per sample on the host.
+
+In scope (BASELINE.json): the {1,2,3}pl simulation datasets and CritLangAcq.
+The Duolingo / WordBank / PISA loaders of the reference are not part of this
+path and raise NotImplementedError.
+"""
+import copy
+import os
+
+import numpy as np
+import torch
+import torch.utils.data
+
+from . import config
+from .simulate import generate, simulation_dir
+
+# the 95 grammar items of CritLangAcq's data.csv used by the reference (datasets.py:366-381),
+# in column order: "q<block>" or "q<block>_<k>"
+_CRITLANGACQ_ITEMS = {
+    1: None, 2: None, 3: None, 5: None, 6: None, 7: None, 9: (1, 4), 10: (2, 4), 11: (3, 4), 12: (1, 2, 4),
+    13: (3, 4), 14: (3, 4), 15: (1, 2, 3), 16: (3, 4), 17: (1, 3, 4), 18: (2, 3, 4), 19: (1, 2, 3, 4),
+    20: (1, 2, 3, 4), 21: (1, 2, 3, 4), 22: (1, 2, 3, 4), 23: (3, 4), 24: (1, 2, 3, 4), 25: (1, 2, 3, 4),
+    26: (1, 2, 3, 4), 27: (1, 2, 3, 4), 28: (1, 2), 29: (1, 2, 3, 4), 30: (1, 2, 3, 4), 31: (1, 4),
+    32: (5, 6, 8), 33: (4, 5, 6, 7), 34: (1, 2, 3, 4, 6, 8), 35: (1, 2, 4, 5, 7, 8),
+}
+
+
+def critlangacq_item_keys():
+    keys = []
+    for block, subs in _CRITLANGACQ_ITEMS.items():
+        keys += [f'q{block}'] if subs is None else [f'q{block}_{k}' for k in subs]
+    return keys
+
+
+def load_dataset(dataset_name, train=True, **kwargs):
+    sims = {'1pl_simulation': ('1pl', False), '2pl_simulation': ('2pl', False), '3pl_simulation': ('3pl', False),
+            '1pl_nonlinear': ('1pl', True), '2pl_nonlinear': ('2pl', True), '3pl_nonlinear': ('3pl', True)}
+    if dataset_name in sims:
+        irt, nonlinear = sims[dataset_name]
+        return IRTSimulation(train=train, irt_model=irt, nonlinear=nonlinear, **kwargs)
+    if dataset_name == 'critlangacq':
+        return Children_LanguageAcquisition(train=train, **kwargs)
+    if dataset_name in ('duolingo', 'wordbank', 'pisa2015_science'):
+        raise NotImplementedError(f'dataset {dataset_name}: loader not part of the MI355X ELBO path '
+                                  f'(any Dataset with .response/.mask [P,I] works with the trainer)')
+    raise Exception(f'Dataset {dataset_name} is not supported.')
+
+
+def artificially_mask_dataset(old_dataset, perc):
+    """Hide a fraction ``perc`` of the observed cells (datasets.py:46-78): the pool is the
+    row-major list of observed cells, ``RandomState(42).choice(.., replace=False)`` picks,
+    sorted; picked cells get mask 0 / response -1 and their labels are kept.
+    Vectorised, same selection as the reference's per-cell Python loop."""
+    assert 0 <= perc <= 1
+    dataset = copy.deepcopy(old_dataset)
+    response, mask = dataset.response, dataset.mask
+    m2 = mask if np.ndim(mask) == 2 else mask[:, :, 0]
+    rows, cols = np.where(m2 != 0)
+    num_all = rows.shape[0]
+    num = int(perc * num_all)
+    rs = np.random.RandomState(42)
+    picked = np.sort(rs.choice(np.arange(num_all), size=num, replace=False))
+    r, c = rows[picked], cols[picked]
+    labels = np.array(response[r, c], copy=True)
+    mask[r, c] = 0
+    response[r, c] = -1
+    dataset.response, dataset.mask = response, mask
+    dataset.missing_labels = labels
+    dataset.missing_indices = np.stack([r, c], axis=1)
+    return dataset
+
+
+class _MatrixDataset(torch.utils.data.Dataset):
+    """Shared behaviour: whole-matrix access + the reference's per-sample tuple."""
+
+    def __len__(self):
+        return self.length
+
+    def matrix(self):
+        """(response float32 [P,I], mask bool [P,I]) numpy views of the whole split."""
+        r = self.response if self.response.ndim == 2 else self.response[:, :, 0]
+        m = self.mask if self.mask.ndim == 2 else self.mask[:, :, 0]
+        return np.ascontiguousarray(r, dtype=np.float32), np.ascontiguousarray(m != 0)
+
+
+class IRTSimulation(_MatrixDataset):
+    """datasets.py:866-940: loads simulation.pth, first 80 % of persons = train."""
+
+    def __init__(self, train=True, irt_model='3pl', num_person=1000, num_item=100, ability_dim=1,
+                 nonlinear=False, generate_if_missing=True, **kwargs):
+        super().__init__()
+        path = os.path.join(simulation_dir(irt_model, num_person, num_item, ability_dim, nonlinear,
+                                           data_dir=config.DATA_DIR), 'simulation.pth')
+        if os.path.exists(path):
+            data = torch.load(path, weights_only=False)
+        elif generate_if_missing:
+            # the reference requires `python src/simulate.py` first; do the same thing on the fly
+            data = generate(irt_model, num_person, num_item, ability_dim, seed=42, nonlinear=nonlinear)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save(data, path)
+        else:
+            raise FileNotFoundError(path)
+        response = data['response'].numpy()
+        ability = data['ability'].numpy()
+        item_feat = data['item_feat'].numpy()
+        n_train = int(0.8 * response.shape[0])
+        sl = slice(0, n_train) if train else slice(n_train, None)
+        response = response[sl]
+        mask = np.ones_like(response)
+        mask[response == -1] = 0
+        self.response = response
+        self.true_ability = ability[sl]
+        self.true_item_feat = item_feat[sl]     # (sic) the reference slices items by the person split too
+        self.item_id = np.arange(response.shape[1])
+        self.mask = mask
+        self.length = self.num_person = response.shape[0]
+        self.num_item = response.shape[1]
+
+    def __getitem__(self, index):
+        response = self.response[index]
+        item_id = self.item_id.copy()
+        item_id[response.flatten() == -1] = -1
+        return (index, torch.from_numpy(response).float(), torch.from_numpy(item_id).long(),
+                torch.from_numpy(self.mask[index]).bool())
+
+
+class Children_LanguageAcquisition(_MatrixDataset):
+    """CritLangAcq (datasets.py:283-440): DATA_DIR/critlangacq/data.csv, 95 q* columns,
+    RandomState(42) row shuffle, 80/20 split, -1 = missing."""
+
+    def __init__(self, train=True, max_num_person=None, max_num_item=None, **kwargs):
+        super().__init__()
+        import pandas as pd
+        path = os.path.join(config.DATA_DIR, 'critlangacq', 'data.csv')
+        if not os.path.exists(path):
+            raise FileNotFoundError(f'{path}: CritLangAcq is not redistributed; place data.csv there')
+        df = pd.read_csv(path)
+        keys = critlangacq_item_keys()
+        response = np.asarray(df[keys])
+        order = np.arange(response.shape[0])
+        np.random.RandomState(42).shuffle(order)
+        response = response[order]
+        n_train = int(0.8 * response.shape[0])
+        response = response[:n_train] if train else response[n_train:]
+        item_id = np.arange(len(keys))
+        if max_num_person is not None:
+            response = response[:max_num_person]
+        if max_num_item is not None:
+            response = response[:, :max_num_item]
+            item_id = item_id[:max_num_item]
+        mask = np.ones_like(response)
+        mask[response == -1] = 0
+        self.metadata = {k: np.asarray(df[k]) for k in ('age', 'education') if k in df}
+        self.response, self.mask, self.item_id = response, mask, item_id
+        self.length = self.num_person = response.shape[0]
+        self.num_item = response.shape[1]
+
+    def __getitem__(self, index):
+        response = self.response[index]
+        item_id = self.item_id.copy()
+        item_id[response == -1] = -1
+        return (index, torch.from_numpy(response).float().unsqueeze(1),
+                torch.from_numpy(item_id).long().unsqueeze(1),
+                torch.from_numpy(self.mask[index]).bool().unsqueeze(1))

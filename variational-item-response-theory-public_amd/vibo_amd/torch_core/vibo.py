@@ -1,0 +1,363 @@
+"""VIBO training / evaluation CLI on the MI355X-native ELBO engine.
+
+Drop-in for ``python src/torch_core/vibo.py`` of the reference: same flags and
+flag interactions (vibo.py:24-125), same output directory name (:127-142), same
+artefacts -- ``checkpoint.pth.tar`` / ``model_best.pth.tar`` with keys
+``model_state_dict, epoch, args`` enriched post hoc with ``infer_dict``,
+``posterior_predict_samples``, ``missing_imputation_accuracy[_mean]``,
+``train_logp``, ``test_logp`` (:478-558), ``train_losses.npy``,
+``test_losses.npy``, ``train_times.npy`` (negative, as the reference stores them).
+
+What differs is HOW a step runs: the split's response matrix lives in HBM, a
+minibatch is a vector of row indices gathered inside the fused HIP kernel, and
+forward+backward of the whole [B,I] block is one launch.
+
+    python -m vibo_amd.torch_core.vibo --irt-model 2pl --dataset 2pl_simulation \
+        --num-person 10000 --num-item 100 --cuda
+    torchrun --nproc-per-node 8 -m vibo_amd.torch_core.vibo ... --cuda     # persons sharded over GPUs
+"""
+import argparse
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import config
+from ..datasets import artificially_mask_dataset, load_dataset
+from ..utils import AverageMeter, save_checkpoint
+from .models import VIBO_1PL, VIBO_2PL, VIBO_3PL
+
+MODELS = {'1pl': VIBO_1PL, '2pl': VIBO_2PL, '3pl': VIBO_3PL}
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--irt-model', type=str, default='1pl', choices=['1pl', '2pl', '3pl'])
+    p.add_argument('--dataset', type=str, default='1pl_simulation',
+                   choices=['1pl_simulation', '2pl_simulation', '3pl_simulation', 'critlangacq',
+                            'duolingo', 'wordbank', 'pisa2015_science'])
+    p.add_argument('--ability-dim', type=int, default=1)
+    p.add_argument('--ability-merge', type=str, default='product', choices=['mean', 'product', 'transformer'])
+    p.add_argument('--conditional-posterior', action='store_true', default=False)
+    p.add_argument('--generative-model', type=str, default='irt', choices=['irt', 'link', 'deep', 'residual'])
+    p.add_argument('--response-dist', type=str, default='bernoulli', choices=['gaussian', 'bernoulli'])
+    p.add_argument('--drop-missing', action='store_true', default=False)
+    p.add_argument('--artificial-missing-perc', type=float, default=0.)
+    p.add_argument('--n-norm-flows', type=int, default=0)
+    p.add_argument('--no-infer-dict', action='store_true', default=False)
+    p.add_argument('--no-marginal', action='store_true', default=False)
+    p.add_argument('--no-test', action='store_true', default=False)
+    p.add_argument('--no-predictive', action='store_true', default=False)
+    p.add_argument('--num-person', type=int, default=1000)
+    p.add_argument('--num-item', type=int, default=100)
+    p.add_argument('--num-posterior-samples', type=int, default=400)
+    p.add_argument('--hidden-dim', type=int, default=64)
+    p.add_argument('--max-num-person')
+    p.add_argument('--max-num-item')
+    p.add_argument('--out-dir', type=str, default=config.OUT_DIR)
+    p.add_argument('--lr', type=float, default=5e-3)
+    p.add_argument('--batch-size', type=int, default=16, metavar='N')
+    p.add_argument('--epochs', type=int, default=100, metavar='N')
+    p.add_argument('--max-iters', type=int, default=-1, metavar='N')
+    p.add_argument('--num-workers', type=int, default=0)
+    p.add_argument('--anneal-kl', action='store_true', default=False)
+    p.add_argument('--beta-kl', type=float, default=1.0)
+    p.add_argument('--seed', type=int, default=42, metavar='S')
+    p.add_argument('--gpu-device', type=int, default=0)
+    p.add_argument('--cuda', action='store_true', default=False)
+    # additive (not in the reference)
+    p.add_argument('--store-predictive-samples', action='store_true', default=False,
+                   help='keep all S posterior-predictive samples [S,P,I,1] in the checkpoint like the '
+                        'reference (default: only their mean, [1,P,I,1])')
+    return p
+
+
+def finalize_args(args):
+    """Flag interactions of vibo.py:102-125."""
+    if args.n_norm_flows > 0:
+        args.no_infer_dict = True
+        args.no_predictive = True
+    if args.artificial_missing_perc > 0:
+        args.no_predictive = False
+    if config.IS_REAL_WORLD[args.dataset]:
+        args.num_person = None
+        args.num_item = None
+        if args.max_num_person is not None:
+            args.max_num_person = int(args.max_num_person)
+        if args.max_num_item is not None:
+            args.max_num_item = int(args.max_num_item)
+    else:
+        args.max_num_person = None
+        args.max_num_item = None
+    return args
+
+
+def out_dir_name(args):
+    """vibo.py:127-141."""
+    return 'VIBO_{}_{}_{}_{}_{}person_{}item_{}maxperson_{}maxitem_{}maskperc_{}ability_{}_{}_seed{}'.format(
+        args.irt_model, args.dataset, args.response_dist, args.generative_model, args.num_person, args.num_item,
+        args.max_num_person, args.max_num_item, args.artificial_missing_perc, args.ability_dim,
+        args.ability_merge, 'conditional_q' if args.conditional_posterior else 'unconditional_q', args.seed)
+
+
+class ResidentSplit:
+    """One dataset split resident on the device: response f32 [P,I], mask bool [P,I]."""
+
+    def __init__(self, dataset, device, row_slice=None):
+        r, m = dataset.matrix()
+        if row_slice is not None:
+            r, m = r[row_slice], m[row_slice]
+        self.response = torch.from_numpy(r).to(device)
+        self.mask = torch.from_numpy(m).to(device)
+        self.num_person, self.num_item = self.response.shape
+        self.device = device
+
+    def num_batches(self, batch_size):
+        return (self.num_person + batch_size - 1) // batch_size
+
+    def batches(self, batch_size, shuffle, generator=None):
+        """Row-index vectors (int64, on device); the kernel gathers the rows itself."""
+        if shuffle:
+            order = torch.randperm(self.num_person, device=self.device, generator=generator)
+        else:
+            order = torch.arange(self.num_person, device=self.device)
+        for s in range(0, self.num_person, batch_size):
+            yield order[s:s + batch_size]
+
+
+def annealing_factor(args, epoch, batch_idx, n_batches):
+    """vibo.py:223-230."""
+    if args.anneal_kl:
+        return float(batch_idx + epoch * n_batches + 1) / float(args.epochs // 2 * n_batches)
+    return args.beta_kl
+
+
+def train_epoch(model, optimizer, data, args, epoch, batch_size):
+    model.train()
+    n_batches = data.num_batches(batch_size)
+    wsum = torch.zeros((), device=data.device)
+    count = 0
+    for batch_idx, rows in enumerate(data.batches(batch_size, shuffle=True)):
+        beta = annealing_factor(args, epoch, batch_idx, n_batches)
+        optimizer.zero_grad(set_to_none=True)
+        loss = model.elbo_step(data.response, data.mask, annealing_factor=beta, row_index=rows)
+        loss.backward()
+        optimizer.step()
+        wsum += loss.detach() * rows.numel()          # AverageMeter weighting (vibo.py:270), one sync per epoch
+        count += rows.numel()
+    avg = float(wsum) / max(1, count)
+    print('====> Train Epoch: {} Loss: {:.4f}'.format(epoch, avg))
+    return avg
+
+
+def test_epoch(model, data, epoch, batch_size):
+    model.eval()
+    wsum = torch.zeros((), device=data.device)
+    count = 0
+    with torch.no_grad():
+        for rows in data.batches(batch_size, shuffle=False):
+            wsum += model.elbo_step(data.response, data.mask, row_index=rows) * rows.numel()
+            count += rows.numel()
+    avg = float(wsum) / max(1, count)
+    print('====> Test Epoch: {} Loss: {:.4f}'.format(epoch, avg))
+    return avg
+
+
+def log_marginal_density(model, data, args, batch_size):
+    """vibo.py:322-347: batch-level importance-weighted bound, averaged with batch-size weights."""
+    model.eval()
+    meter = AverageMeter()
+    with torch.no_grad():
+        for rows in data.batches(batch_size, shuffle=False):
+            r, m = data.response[rows], data.mask[rows]
+            marginal = model.log_marginal(r, m, num_samples=args.num_posterior_samples)
+            meter.update(float(torch.mean(marginal)), rows.numel())
+    print('====> Marginal: {:.4f}'.format(meter.avg))
+    return meter.avg
+
+
+def infer_dict(model, data, batch_size):
+    """vibo.py:420-454."""
+    model.eval()
+    mus, lvs = [], []
+    with torch.no_grad():
+        for rows in data.batches(batch_size, shuffle=False):
+            _, amu, alv, _, item_mu, item_lv = model.encode(data.response, data.mask, row_index=rows)
+            mus.append(amu.cpu())
+            lvs.append(alv.cpu())
+    return {'ability_mu': torch.cat(mus, 0), 'ability_logvar': torch.cat(lvs, 0),
+            'item_feat_mu': item_mu.detach(), 'item_feat_logvar': item_lv.detach()}
+
+
+def posterior_predictive(model, data, args, batch_size, keep_samples):
+    """vibo.py:349-390: S draws of (ability, item) from the posteriors, decoded.  The mean over S
+    is accumulated on the device; the [S,P,I,1] stack is only materialised on request."""
+    model.eval()
+    S = args.num_posterior_samples
+    means, stacks = [], []
+    with torch.no_grad():
+        for rows in data.batches(batch_size, shuffle=False):
+            _, amu, alv, _, imu, ilv = model.encode(data.response, data.mask, row_index=rows)
+            a_s = amu + torch.exp(0.5 * alv) * torch.randn((S,) + amu.shape, device=amu.device)
+            i_s = imu + torch.exp(0.5 * ilv) * torch.randn((S,) + imu.shape, device=imu.device)
+            acc = torch.zeros(rows.numel(), data.num_item, device=data.device)
+            per = []
+            for s in range(S):
+                pr = model.decode(a_s[s], i_s[s]).squeeze(2)
+                acc += pr
+                if keep_samples:
+                    per.append(pr.cpu())
+            means.append((acc / S).cpu())
+            if keep_samples:
+                stacks.append(torch.stack(per))
+    if keep_samples:
+        return {'response': torch.cat(stacks, dim=1).unsqueeze(3)}
+    return {'response': torch.cat(means, dim=0).unsqueeze(0).unsqueeze(3)}
+
+
+def posterior_mean_prediction(model, data, batch_size):
+    """vibo.py:392-418."""
+    model.eval()
+    out = []
+    with torch.no_grad():
+        for rows in data.batches(batch_size, shuffle=False):
+            _, amu, _, _, imu, _ = model.encode(data.response, data.mask, row_index=rows)
+            out.append(model.decode(amu, imu).cpu())
+    return {'response': torch.cat(out, dim=0).unsqueeze(0)}
+
+
+def imputation_accuracy(inferred, missing_indices, missing_labels):
+    """vibo.py:508-548, vectorised: round the inferred probability, compare at the hidden cells."""
+    labels = np.asarray(missing_labels)
+    if labels.ndim > 1:
+        labels = labels.reshape(labels.shape[0], -1)[:, 0]
+    idx = torch.as_tensor(np.asarray(missing_indices))
+    pred = torch.round(inferred[idx[:, 0], idx[:, 1]]).reshape(-1)
+    return float((pred == torch.as_tensor(labels, dtype=pred.dtype)).float().mean())
+
+
+def main(argv=None):
+    args = finalize_args(build_parser().parse_args(argv))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(args.gpu_device)))
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    from .. import ops
+    if args.cuda:
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    elif ops._BACKEND['elbo'] is not ops._hip_launch_elbo:
+        device = torch.device('cpu')          # tests/ swapped in the CPU oracle to exercise this host logic
+    else:
+        raise SystemExit('the MI355X engine has no CPU path: pass --cuda '
+                         '(the reference without --cuda is the CPU baseline)')
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.cuda:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    args.out_dir = os.path.join(args.out_dir, out_dir_name(args))
+    if rank == 0:
+        os.makedirs(args.out_dir, exist_ok=True)
+
+    dataset_name = args.dataset if args.response_dist == 'bernoulli' else f'{args.dataset}_continuous'
+    kw = dict(num_person=args.num_person, num_item=args.num_item, ability_dim=args.ability_dim,
+              max_num_person=args.max_num_person, max_num_item=args.max_num_item)
+    train_dataset = load_dataset(dataset_name, train=True, **kw)
+    test_dataset = load_dataset(dataset_name, train=False, **kw)
+    if args.artificial_missing_perc > 0:
+        train_dataset = artificially_mask_dataset(train_dataset, args.artificial_missing_perc)
+    num_item = train_dataset.num_item
+
+    # persons are sharded in contiguous blocks over the ranks
+    def shard(n):
+        return slice(rank * n // world, (rank + 1) * n // world) if world > 1 else None
+    train = ResidentSplit(train_dataset, device, shard(train_dataset.num_person))
+    test = ResidentSplit(test_dataset, device, shard(test_dataset.num_person))
+    local_bs = max(1, args.batch_size // world)
+    n_batches = train.num_batches(local_bs)
+    if args.max_iters != -1:
+        args.epochs = int(math.ceil(args.max_iters / float(n_batches)))
+        print(f'Found MAX_ITERS={args.max_iters}, setting EPOCHS={args.epochs}')
+
+    model = MODELS[args.irt_model](
+        args.ability_dim, num_item, hidden_dim=args.hidden_dim, ability_merge=args.ability_merge,
+        conditional_posterior=args.conditional_posterior, generative_model=args.generative_model,
+        response_dist=args.response_dist, replace_missing_with_prior=not args.drop_missing,
+        n_norm_flows=args.n_norm_flows).to(device)
+    if world > 1:
+        model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+
+    best_loss = np.inf
+    train_losses, test_losses, train_times = np.zeros(args.epochs), np.zeros(args.epochs), np.zeros(args.epochs)
+    for epoch in range(args.epochs):
+        t0 = time.time()
+        train_loss = train_epoch(model, optimizer, train, args, epoch, local_bs)
+        if args.cuda:
+            torch.cuda.synchronize()
+        train_losses[epoch] = train_loss
+        train_times[epoch] = t0 - time.time()          # negative, like the reference (vibo.py:467)
+        if not args.no_test:
+            test_loss = test_epoch(model, test, epoch, local_bs)
+            test_losses[epoch] = test_loss
+            is_best, best_loss = test_loss < best_loss, min(test_loss, best_loss)
+        else:
+            is_best, best_loss = train_loss < best_loss, min(train_loss, best_loss)
+        if rank == 0:
+            save_checkpoint({'model_state_dict': model.state_dict(), 'epoch': epoch, 'args': args},
+                            is_best, folder=args.out_dir)
+            np.save(os.path.join(args.out_dir, 'train_losses.npy'), train_losses)
+            np.save(os.path.join(args.out_dir, 'train_times.npy'), train_times)
+            if not args.no_test:
+                np.save(os.path.join(args.out_dir, 'test_losses.npy'), test_losses)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:      # post-hoc enrichment (rank 0, on the whole split)
+        if world > 1:
+            train, test = ResidentSplit(train_dataset, device), ResidentSplit(test_dataset, device)
+            local_bs = args.batch_size
+        for name in ('checkpoint.pth.tar', 'model_best.pth.tar'):
+            path = os.path.join(args.out_dir, name)
+            if not os.path.exists(path):
+                continue
+            ckpt = torch.load(path, weights_only=False)
+            model.load_state_dict(ckpt['model_state_dict'])
+            saved_reducer, model._reducer = model._reducer, None      # evaluation is local
+            if not args.no_infer_dict:
+                ckpt['infer_dict'] = infer_dict(model, train, local_bs)
+            if not args.no_predictive:
+                pp = posterior_predictive(model, train, args, local_bs, args.store_predictive_samples)
+                ckpt['posterior_predict_samples'] = pp
+                if args.artificial_missing_perc > 0:
+                    acc = imputation_accuracy(pp['response'].mean(0).squeeze(-1), train_dataset.missing_indices,
+                                              train_dataset.missing_labels)
+                    ckpt['missing_imputation_accuracy'] = acc
+                    print(f'Missing Imputation Accuracy from samples: {acc}')
+                    pm = posterior_mean_prediction(model, train, local_bs)
+                    acc = imputation_accuracy(pm['response'].squeeze(0).squeeze(-1), train_dataset.missing_indices,
+                                              train_dataset.missing_labels)
+                    ckpt['missing_imputation_accuracy_mean'] = acc
+                    print(f'Missing Imputation Accuracy from mean: {acc}')
+            if not args.no_marginal:
+                ckpt['train_logp'] = log_marginal_density(model, train, args, local_bs)
+                if not args.no_test:
+                    ckpt['test_logp'] = log_marginal_density(model, test, args, local_bs)
+            model._reducer = saved_reducer
+            torch.save(ckpt, path)
+            print(f'Train time: {np.abs(train_times[:100]).sum()}')
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
