@@ -51,6 +51,8 @@ static int check_desc(const vibo_desc* d) {
 
 struct Plan {
     bool general;             // wave-per-person kernel (conditional posterior / flows / > 1024 items)
+    bool row_ok;              // wave-per-row register kernel is applicable (subject to alignment)
+    int row_nblk;
     int AT, D, DP, n_tiles, nblk, lds_main;
     LaunchGeom geom;
     PartialLayout lay;
@@ -106,6 +108,10 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     int nblk = g_num_cu * per_cu;
     if (nblk > pl->n_tiles) nblk = pl->n_tiles;
     pl->nblk = nblk;
+    // wave-per-row kernel (A <= 2, 1PL/2PL, 192 <= I <= 1024): 4 workgroups of 4 waves per CU
+    pl->row_ok = A <= 2 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0);
+    pl->row_nblk = g_num_cu * 2;          // 16 items x (params + grads) per lane: 2 workgroups (8 waves) per CU
+    if (pl->row_nblk > (d->num_person + 3) / 4) pl->row_nblk = (d->num_person + 3) / 4;
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
     pl->geom.grid = nblk;
@@ -114,7 +120,8 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->off_item_prep = 0;
     size_t prep_bytes = ((size_t)((I + 15) & ~15) * pl->DP * 4 + 255) & ~(size_t)255;
     pl->off_partial = prep_bytes;
-    pl->total_bytes = prep_bytes + (size_t)nblk * pl->lay.stride * 4 + 256;
+    const int max_blk = (pl->row_ok && pl->row_nblk > nblk) ? pl->row_nblk : nblk;
+    pl->total_bytes = prep_bytes + (size_t)max_blk * pl->lay.stride * 4 + 256;
     return stride;
 }
 
@@ -378,6 +385,11 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     p.vec_ok = vec ? 1 : 0;
 
     const bool grad = d->want_grad != 0;
+    int nblk_used = pl.nblk;
+    if (pl.row_ok && vec) {
+        nblk_used = pl.row_nblk;
+        e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);
+    } else
     switch (pl.AT) {
         case 1: e = launch_elbo_a1(p, d->irt_model, grad, pl.geom, s); break;
         case 2: e = launch_elbo_a2(p, d->irt_model, grad, pl.geom, s); break;
@@ -390,7 +402,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     memset(&f, 0, sizeof(f));
     f.partial = partial; f.out_scalars = out_scalars; f.grad_table = grad_table; f.grad_item = grad_item;
     f.grad_flow = grad_flow;
-    f.nblk = pl.nblk; f.I = I; f.A = A; f.D = pl.D; f.n_flows = d->n_flows; f.reg_mode = d->reg_mode;
+    f.nblk = nblk_used; f.I = I; f.A = A; f.D = pl.D; f.n_flows = d->n_flows; f.reg_mode = d->reg_mode;
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
     const int n_out = 8 + (grad ? 8 * A + 2 * d->n_flows * (2 * A + 1) + I * pl.D : 0);
     hipLaunchKernelGGL(finalize_kernel, dim3((n_out + 63) / 64), dim3(256), 0, s, f);

@@ -71,18 +71,6 @@ __device__ __forceinline__ uint32_t load_mask1(const ElboParams& p, long long sr
     }
 }
 
-// 4 responses (fp32 0.0/1.0) + 4 mask bytes (0/1) -> 4 fp8 codes; counts packed n1<<16 | nobs.
-__device__ __forceinline__ uint32_t pack_codes4(const float4 x, const uint32_t m, int& packed) {
-    const uint32_t x0 = __builtin_bit_cast(uint32_t, x.x), x1 = __builtin_bit_cast(uint32_t, x.y);
-    const uint32_t x2 = __builtin_bit_cast(uint32_t, x.z), x3 = __builtin_bit_cast(uint32_t, x.w);
-    // byte 3 of 1.0f is 0x3F, of 0.0f is 0x00: bit 24 tells "correct"
-    const uint32_t hi = __builtin_amdgcn_perm(x1, x0, 0x0c0c0703u) | __builtin_amdgcn_perm(x3, x2, 0x07030c0cu);
-    const uint32_t xb = hi & 0x01010101u;
-    const uint32_t code = (0xB8B8B8B8u ^ (xb << 7)) & (m * 0xFFu);
-    packed += __builtin_popcount(m) + (__builtin_popcount(xb & m) << 16);
-    return code;
-}
-
 // Software-pipelined tile loader.  A wave owns RPW rows of every 64-person tile; they are fetched
 // in NSTEP steps of 4 (row, 64-lane chunk) units = 20 VGPRs, one step per 16-item compute block, so
 // each wave always has ~5 KB of HBM loads in flight while it computes (16 waves/CU -> 80 KB/CU).

@@ -18,4 +18,7 @@ hipError_t launch_elbo_a2(const ElboParams& p, int irt, bool grad, const LaunchG
 hipError_t launch_elbo_a4(const ElboParams& p, int irt, bool grad, const LaunchGeom& g, hipStream_t s);
 hipError_t launch_elbo_a8(const ElboParams& p, int irt, bool grad, const LaunchGeom& g, hipStream_t s);
 
+// wave-per-row kernel (vibo_row_kernel.hip): A in {1,2}, 1PL/2PL, I <= 1024, 16-byte aligned rows
+hipError_t launch_elbo_rows(const ElboParams& p, int irt, bool grad, int grid, hipStream_t s);
+
 }  // namespace vibo
