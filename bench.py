@@ -53,6 +53,8 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=8)
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
+    ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
+    ap.add_argument('--force-dist', action='store_true', help='create the process group even for one rank (tests the RCCL path)')
     return ap.parse_args()
 
 
@@ -126,9 +128,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from vibo_amd import ops
@@ -138,8 +141,8 @@ def main():
     resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
     torch.manual_seed(args.seed)
     model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge='product').to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
-    if world > 1:
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=not args.no_graph, fused=True)
+    if dist is not None:
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
 
     # HIP events around the native call, on the stream it is launched on
@@ -159,15 +162,47 @@ def main():
 
     ops._BACKEND['elbo'] = timed_native
 
+    graph = None
+
     def step():
         if args.eval_only:
             with torch.no_grad():
                 return model.elbo_step(resp, mask)
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad(set_to_none=False)
         loss = model.elbo_step(resp, mask)
         loss.backward()
         opt.step()
-        return loss
+        return loss.detach()
+
+    # The whole step (PyTorch O(I) part, fused HIP kernel, all-reduce, autograd, Adam) is captured once into a
+    # hipGraph and replayed: ~80 tiny launches per step cost more than a quarter of the 1-2 ms kernel otherwise.
+    eager_step = step
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()                   # allocator / hipFuncSetAttribute / Adam state / RCCL warm-up outside capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            for gen in (model._item_gen, model._ability_gen):      # dedicated generators of the person-sharded mode
+                if gen is not None:
+                    g.register_generator_state(gen)
+            opt.zero_grad(set_to_none=False)
+            with torch.cuda.graph(g):
+                static_loss = step()
+            graph = g
+
+            def step():
+                graph.replay()
+                return static_loss
+        except Exception as exc:             # never lose the measurement to a capture problem
+            print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
+            graph = None
+            step = eager_step
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         loss = step()
@@ -175,7 +210,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    recording['on'] = True
+    recording['on'] = graph is None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -191,6 +226,14 @@ def main():
         dt = float(t)
     final_loss = float(loss.detach())
 
+    if graph is not None:
+        # events cannot be recorded inside a replayed graph: time the native call on the same stream / inputs
+        # in an eager pass of the same step right after the timed region
+        recording['on'] = True
+        for _ in range(min(args.steps, 10)):
+            eager_step()
+        torch.cuda.synchronize()
+        recording['on'] = False
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
     bytes_per_term = 5.0 + 12.0 * A / I
     achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -206,7 +249,7 @@ def main():
             'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU, '
                                    f'ability_dim={A}, {args.missing:.0%} missing, product-of-experts encoder, '
                                    f'unconditional posterior, full-shard minibatch',
-                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}',
+                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': 'hipGraph replay' if graph is not None else 'eager',
                        'final_loss_per_term': final_loss / (P * I * world)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': None,

@@ -65,6 +65,37 @@ __global__ __launch_bounds__(256) void k_mix(float* out, float seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef short short8 __attribute__((ext_vector_type(8)));
+// bf16 MFMA (16x16x32) vs VALU: MODE 0 mfma only, 1 valu only, 2 same wave, 3 even/odd waves
+template <int MODE>
+__global__ __launch_bounds__(256) void k_mix_bf16(float* out, float seed) {
+    float4v acc[4];
+    float a[8];
+    for (int i = 0; i < 4; ++i) acc[i] = float4v{0, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) a[i] = seed + i;
+    short8 x, y;
+    for (int i = 0; i < 8; ++i) { x[i] = (short)(0x3f80 + threadIdx.x + i); y[i] = (short)(0x3f00 + i); }
+    const int wave = threadIdx.x >> 6;
+    const bool do_mfma = MODE == 0 || MODE == 2 || (MODE == 3 && (wave & 1) == 0);
+    const bool do_valu = MODE == 1 || MODE == 2 || (MODE == 3 && (wave & 1) == 1);
+    for (int it = 0; it < ITERS; ++it) {
+        if (do_mfma) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc[i], 0, 0, 0);
+        }
+        if (do_valu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = fmaf(a[i], 1.0001f, 0.5f);
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F>
 float time_ms(F f) {
     hipEvent_t e0, e1;
@@ -92,5 +123,8 @@ int main() {
     const char* mn[] = {"MFMA only (16/iter/wave)", "VALU only (32 fma/iter/wave)", "MFMA+VALU same wave", "even waves MFMA, odd VALU"};
 #define RUNM(M) { float ms = time_ms([&]{ hipLaunchKernelGGL(k_mix<M>, dim3(blocks), dim3(256), 0, 0, out, 1.0f); }); printf("%-30s %8.3f ms\n", mn[M], ms); }
     RUNM(0) RUNM(1) RUNM(2) RUNM(3)
+    const char* bn[] = {"bf16 MFMA only (4/iter/wave)", "VALU only (32 fma/iter/wave)", "bf16 MFMA+VALU same wave", "even waves bf16 MFMA, odd VALU"};
+#define RUNB(M) { float ms = time_ms([&]{ hipLaunchKernelGGL(k_mix_bf16<M>, dim3(blocks), dim3(256), 0, 0, out, 1.0f); }); printf("%-34s %8.3f ms\n", bn[M], ms); }
+    RUNB(0) RUNB(1) RUNB(2) RUNB(3)
     return 0;
 }

@@ -77,11 +77,10 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
         pl->total_bytes = 256;            // 8 scalar accumulators
         return 16;
     }
-    int stride = (I + 15) & ~15;
-    if (((stride / 16) & 1) == 0) stride += 16;   // odd multiple of 16 B: conflict-free ds_read_b128 across rows
     // waves per workgroup (each wave owns <= SB 16-item blocks, see vibo_elbo_kernel.hpp geometry table);
     // the code tile is double-buffered in LDS, 16/waves workgroups share a CU
     const int waves = I <= 144 ? 2 : I <= 304 ? 4 : I <= 512 ? 8 : 16;
+    const int stride = code_tile_stride(waves);
     size_t main_b = (size_t)kTilePersons * stride;                    // one fp8 code tile
     const size_t red = (size_t)waves * pl->AT * 65 * 4;               // per-wave dLL/dtheta partials (aliased)
     if (main_b < red) main_b = red;

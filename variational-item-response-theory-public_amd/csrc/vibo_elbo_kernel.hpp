@@ -197,6 +197,7 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
     constexpr int SROW = 20;                              // staging row stride (floats): conflict-free b32 writes
     constexpr int PS = 65;                                // person-row stride (floats) of share / red: spreads MFMA-layout reads over banks
     constexpr float kLoS = kLogitLo * kLog2e, kHiS = kLogitHi * kLog2e;   // clamp bounds in log2 units
+    constexpr int STRIDE = code_tile_stride(NW);          // bytes per person row of the code tile (odd multiple of 16)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* share_base = reinterpret_cast<float*>(smem + 2 * p.lds_main);
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
     const int gq = lane >> 4, nq = lane & 15;             // MFMA lane coordinates
     const int I = p.I;
     const int Ar = p.A;
-    const int stride = p.lds_stride;
+    constexpr int stride = STRIDE;
     float* stage = stage_base + wave * 16 * SROW;
 
     // ---- encoder-table constants -> LDS ------------------------------------
@@ -411,12 +412,14 @@ __global__ __launch_bounds__(NW * 64, 4) void elbo_kernel(const ElboParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) stage[(4 * gq + r) * SROW + nq] = G[r];
                         const float4v GT = *reinterpret_cast<const float4v*>(stage + nq * SROW + 4 * gq);
-                        float4v ag = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ag = __builtin_amdgcn_mfma_f32_16x16x4f32(GT[r], ai[r], ag, 0, 0, 0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (q == pt) acc_g[q] += ag;
+#define VIBO_GTH_ACC(Q)                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                             \
+        acc_g[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(GT[r], ai[r], acc_g[Q], 0, 0, 0);
+                        if (pt == 0) { VIBO_GTH_ACC(0) }
+                        else if (pt == 1) { VIBO_GTH_ACC(1) }
+                        else if (pt == 2) { VIBO_GTH_ACC(2) }
+                        else { VIBO_GTH_ACC(3) }
+#undef VIBO_GTH_ACC
                     }
                 }
                 if constexpr (GRAD) {

@@ -7,6 +7,10 @@ namespace vibo {
 
 constexpr int kTilePersons = 64;   // persons per tile = lanes per wave
 
+// bytes per person row of the fp8 code tile for a workgroup of `waves` waves (I <= 1024 / 512 / 304 / 144):
+// an odd multiple of 16 B, so the per-person ds_read_b128 / ds_read_u8 accesses spread over all LDS banks
+constexpr int code_tile_stride(int waves) { return waves >= 16 ? 1040 : waves == 8 ? 528 : waves == 4 ? 304 : 144; }
+
 // template ability width for a runtime ability_dim (1,2,4,8)
 inline int padded_ability_dim(int a) { return a <= 1 ? 1 : a <= 2 ? 2 : a <= 4 ? 4 : 8; }
 

@@ -75,8 +75,10 @@ __global__ __launch_bounds__(256, 2) void row_kernel(const ElboParams p) {
     float s_log = 0.f, s_kl = 0.f, s_logq0 = 0.f, s_logp = 0.f, s_nobs = 0.f;
     __syncthreads();
 
-    auto load_row = [&](long long row, float4 (&x)[CH], uint32_t (&m)[CH]) {
+    auto load_row = [&](long long row, float4 (&x)[CH], uint32_t (&m)[CH], float (&ep)[A]) {
         const long long src = p.row_index ? p.row_index[row] : row;
+#pragma unroll
+        for (int a = 0; a < A; ++a) ep[a] = p.eps[row * A + a];
         const float4* rp = reinterpret_cast<const float4*>(p.response + src * p.resp_stride);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void row_kernel(const ElboParams p) {
     // two row buffers: while a row is being processed, the loads of the next TWO rows are in flight
     float4 xa[CH], xb[CH];
     uint32_t ma[CH], mb[CH];
-    auto process = [&](float4 (&x)[CH], uint32_t (&m)[CH], const long long row, const long long prow) {
+    float epa[A], epb[A];
+    auto process = [&](float4 (&x)[CH], uint32_t (&m)[CH], float (&ep)[A], const long long row, const long long prow) {
         // ---- sweep 1: pack the row to one fp8 byte per cell (+1 correct / -1 wrong / 0 missing) and count
         //      observed / correct cells -> product of experts (models.py:596-629).  The raw row registers die
         //      here, so the NEXT row's HBM loads are issued into them and fly under this row's math.
@@ -111,12 +114,15 @@ __global__ __launch_bounds__(256, 2) void row_kernel(const ElboParams p) {
         int packed = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) cw[c] = pack_codes4(x[c], m[c], packed);
-        if (prow < p.B) load_row(prow, x, m);
+        float epsv[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) epsv[a] = ep[a];
+        if (prow < p.B) load_row(prow, x, m, ep);
         __builtin_amdgcn_sched_barrier(0);
         const int cnt = lane63(wave_sum63(packed));
         const float n1 = (float)(cnt >> 16), nobs = (float)(cnt & 0xffff);
         const float n0 = nobs - n1, nmiss = (float)I - nobs;
-        float th[A], amu[A], inv_lam[A], sig[A], epsv[A], lamv[A];
+        float th[A], amu[A], inv_lam[A], sig[A], lamv[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             float lam = n0 * ctab[(0 * 2 + 0) * A + a] + n1 * ctab[(0 * 2 + 1) * A + a];
@@ -126,14 +132,27 @@ __global__ __launch_bounds__(256, 2) void row_kernel(const ElboParams p) {
             inv_lam[a] = 1.0f / lam;
             amu[a] = s * inv_lam[a];
             sig[a] = fast_rsq(lam);
-            epsv[a] = p.eps[row * A + a];
             th[a] = amu[a] + sig[a] * epsv[a];
         }
 
         // ---- sweep 2: decode, masked Bernoulli log-lik, backward (all in registers) ----
+        // The reference clamps the Bernoulli probability (utils.py:46-49 -> torch): log-lik value clamped at
+        // logit +-kLogitLo, gradient exactly zero outside [-kLogitLo, kLogitHi].  |logit| > 15.9 is rare, so
+        // the exact form is a wave-uniform slow path chosen per row.
         float gth[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) gth[a] = 0.f;
+        float lg[NI];
+        bool sat = false;
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            float l = nb[t];
+#pragma unroll
+            for (int a = 0; a < A; ++a) l = fmaf(na[t][a], th[a], l);
+            lg[t] = l;
+            sat |= fabsf(l) > kLoS;
+        }
+        const bool exact = __any(sat);
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
             float w;
@@ -141,19 +160,16 @@ __global__ __launch_bounds__(256, 2) void row_kernel(const ElboParams p) {
             else if ((t & 3) == 1) w = code_to_f32<1>(cw[t >> 2]);
             else if ((t & 3) == 2) w = code_to_f32<2>(cw[t >> 2]);
             else w = code_to_f32<3>(cw[t >> 2]);
-            if ((t & 3) == 0 && t > 0) __builtin_amdgcn_sched_barrier(0);   // bound live temporaries
-            float l = nb[t];
-#pragma unroll
-            for (int a = 0; a < A; ++a) l = fmaf(na[t][a], th[a], l);
-            // reference clamp (utils.py:46-49 -> torch Bernoulli): value clamped at +-kLogitLo,
-            // gradient exactly zero outside [-kLogitLo, kLogitHi]
-            const float l2 = med3(l, -kLoS, kHiS);
-            const float lc = fminf(l2, kLoS);
+            float lc = lg[t], wg = w;
+            if (exact) {
+                const float l2 = med3(lg[t], -kLoS, kHiS);
+                lc = fminf(l2, kLoS);
+                wg = (lg[t] == l2) ? w : 0.f;
+            }
             const float eu = fast_exp2(-w * lc);
             const float tt = 1.0f + eu;
             s_log = fmaf(fabsf(w), fast_log2(tt), s_log);
             if constexpr (GRAD) {
-                const float wg = (l == l2) ? w : 0.f;
                 const float gl = wg * (eu * fast_rcp(tt));                  // d ll / d logit
 #pragma unroll
                 for (int a = 0; a < A; ++a) {
@@ -210,11 +226,11 @@ __global__ __launch_bounds__(256, 2) void row_kernel(const ElboParams p) {
     };
     {
         const long long r0 = wave_id, r1 = wave_id + n_waves;
-        if (r0 < p.B) load_row(r0, xa, ma);
-        if (r1 < p.B) load_row(r1, xb, mb);
+        if (r0 < p.B) load_row(r0, xa, ma, epa);
+        if (r1 < p.B) load_row(r1, xb, mb, epb);
         for (long long row = r0; row < p.B; row += 2 * n_waves) {
-            process(xa, ma, row, row + 2 * n_waves);
-            if (row + n_waves < p.B) process(xb, mb, row + n_waves, row + 3 * n_waves);
+            process(xa, ma, epa, row, row + 2 * n_waves);
+            if (row + n_waves < p.B) process(xb, mb, epb, row + n_waves, row + 3 * n_waves);
         }
     }
 

@@ -56,11 +56,13 @@ class AbilityEncoder(nn.Module):
             # (models.py:675-693); do the same so parameter init consumes the RNG identically
             _encoder_mlp(1, hidden_dim, 2 * ability_dim)
         self.mlp = _encoder_mlp(1 + (item_dim if conditional else 0), hidden_dim, 2 * ability_dim)
+        # the two observed response values; a non-persistent buffer (not in state_dict) so that building the
+        # table needs no host->device copy (keeps the step hipGraph-capturable)
+        self.register_buffer('_response_values', torch.tensor([[0.0], [1.0]]), persistent=False)
 
     def expert_table(self, item_feat=None):
         """[2,2A] (row c = mlp([c])) or [2,I,2A] (entry = mlp([c, item_i]))."""
-        w = self.mlp[0].weight
-        vals = torch.tensor([[0.0], [1.0]], dtype=w.dtype, device=w.device)
+        vals = self._response_values.to(self.mlp[0].weight.dtype)
         if not self.conditional:
             return self.mlp(vals)
         I = item_feat.shape[0]
