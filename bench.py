@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--persons', type=int, default=1_000_000, help='persons per GPU (weak scaling)')
     ap.add_argument('--items', type=int, default=1000)
     ap.add_argument('--ability-dim', type=int, default=8)
+    ap.add_argument('--also-ability-dim', type=int, default=1, help='second workload reported under "also" (0 = none)')
     ap.add_argument('--irt-model', type=str, default='2pl', choices=['1pl', '2pl', '3pl'])
     ap.add_argument('--missing', type=float, default=0.1)
     ap.add_argument('--lr', type=float, default=5e-3)
@@ -137,107 +138,135 @@ def main():
     from vibo_amd import ops
     from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
 
-    P, I, A = args.persons, args.items, args.ability_dim
-    resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
-    torch.manual_seed(args.seed)
-    model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge='product').to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=not args.no_graph, fused=True)
-    if dist is not None:
-        model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
+    def measure(A):
+        """-> dict(dt, kern_ms, final_loss, graph) for ability_dim A on this rank's shard."""
+        P, I = args.persons, args.items
+        resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
+        torch.manual_seed(args.seed)
+        model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge='product').to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=not args.no_graph, fused=True)
+        if dist is not None:
+            model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
 
-    # HIP events around the native call, on the stream it is launched on
-    events = []
-    native = ops._BACKEND['elbo']
-    recording = {'on': False}
+        # HIP events around the native call, on the stream it is launched on
+        events = []
+        native = ops._BACKEND['elbo']
+        recording = {'on': False}
 
-    def timed_native(*a, **k):
-        if not recording['on']:
-            return native(*a, **k)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = native(*a, **k)
-        e1.record()
-        events.append((e0, e1))
-        return out
+        def timed_native(*a, **k):
+            if not recording['on']:
+                return native(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = native(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+            return out
 
-    ops._BACKEND['elbo'] = timed_native
+        ops._BACKEND['elbo'] = timed_native
 
-    graph = None
+        graph = None
 
-    def step():
-        if args.eval_only:
-            with torch.no_grad():
-                return model.elbo_step(resp, mask)
-        opt.zero_grad(set_to_none=False)
-        loss = model.elbo_step(resp, mask)
-        loss.backward()
-        opt.step()
-        return loss.detach()
-
-    # The whole step (PyTorch O(I) part, fused HIP kernel, all-reduce, autograd, Adam) is captured once into a
-    # hipGraph and replayed: ~80 tiny launches per step cost more than a quarter of the 1-2 ms kernel otherwise.
-    eager_step = step
-    if not args.no_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()                   # allocator / hipFuncSetAttribute / Adam state / RCCL warm-up outside capture
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            for gen in (model._item_gen, model._ability_gen):      # dedicated generators of the person-sharded mode
-                if gen is not None:
-                    g.register_generator_state(gen)
+        def step():
+            if args.eval_only:
+                with torch.no_grad():
+                    return model.elbo_step(resp, mask)
             opt.zero_grad(set_to_none=False)
-            with torch.cuda.graph(g):
-                static_loss = step()
-            graph = g
+            loss = model.elbo_step(resp, mask)
+            loss.backward()
+            opt.step()
+            return loss.detach()
 
-            def step():
-                graph.replay()
-                return static_loss
-        except Exception as exc:             # never lose the measurement to a capture problem
-            print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
-            graph = None
-            step = eager_step
-            torch.cuda.synchronize()
+        # The whole step (PyTorch O(I) part, fused HIP kernel, all-reduce, autograd, Adam) is captured once into a
+        # hipGraph and replayed: ~80 tiny launches per step cost more than a quarter of the 1-2 ms kernel otherwise.
+        eager_step = step
+        if not args.no_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        step()                   # allocator / hipFuncSetAttribute / Adam state / RCCL warm-up outside capture
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                for gen in (model._item_gen, model._ability_gen):      # dedicated generators of the person-sharded mode
+                    if gen is not None:
+                        g.register_generator_state(gen)
+                opt.zero_grad(set_to_none=False)
+                with torch.cuda.graph(g):
+                    static_loss = step()
+                graph = g
 
-    for _ in range(args.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    recording['on'] = graph is None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    recording['on'] = False
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    final_loss = float(loss.detach())
+                def step():
+                    graph.replay()
+                    return static_loss
+            except Exception as exc:             # never lose the measurement to a capture problem
+                print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
+                graph = None
+                step = eager_step
+                torch.cuda.synchronize()
 
-    if graph is not None:
-        # events cannot be recorded inside a replayed graph: time the native call on the same stream / inputs
-        # in an eager pass of the same step right after the timed region
-        recording['on'] = True
-        for _ in range(min(args.steps, 10)):
-            eager_step()
+        for _ in range(args.warmup):
+            loss = step()
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        recording['on'] = graph is None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         recording['on'] = False
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        final_loss = float(loss.detach())
+
+        if graph is not None:
+            # events cannot be recorded inside a replayed graph: time the native call on the same stream / inputs
+            # in an eager pass of the same step right after the timed region
+            recording['on'] = True
+            for _ in range(min(args.steps, 10)):
+                eager_step()
+            torch.cuda.synchronize()
+            recording['on'] = False
+        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+        bytes_per_term = 5.0 + 12.0 * A / I
+        achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        ops._BACKEND['elbo'] = native
+        del resp, mask, model, opt
+        torch.cuda.empty_cache()
+        return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None)
+
+    P, I, A = args.persons, args.items, args.ability_dim
+    m = measure(A)
+    dt, kern_ms, final_loss = m['dt'], m['kern_ms'], m['final_loss']
     bytes_per_term = 5.0 + 12.0 * A / I
     achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    also = None
+    if args.also_ability_dim and args.also_ability_dim != A:
+        A2 = args.also_ability_dim
+        m2 = measure(A2)
+        b2 = 5.0 + 12.0 * A2 / I
+        also = {'workload': f'same, ability_dim={A2} (BASELINE configs[1] shape at 1M persons; wave-per-row kernel)',
+                'value': float(P) * I * args.steps * world / m2['dt'], 'ms_per_step': m2['dt'] / args.steps * 1e3,
+                'kernel_ms': m2['kern_ms'], 'roofline_achieved_GBps': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9,
+                'roofline_frac': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 8000.0}
 
+    # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of
+    # MI355X_MICROARCH.md) cannot be collected from inside this process; for the default workload the value
+    # recorded in profiles/r01_bench_profile.txt is reported, otherwise null.
+    traffic, traffic_note = None, 'not measured for this workload'
+    if (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and A in (1, 8):
+        traffic = {8: 2 * 2891894e3 + 391581e3, 1: 2 * 2473670e3 + 34040e3}[A]
+        traffic_note = 'recorded measurement: profiles/r01_bench_profile.txt (2*FETCH_SIZE + WRITE_SIZE, KB)'
     if rank == 0:
         terms = float(P) * I * args.steps * world
         line = {
@@ -249,13 +278,15 @@ def main():
             'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU, '
                                    f'ability_dim={A}, {args.missing:.0%} missing, product-of-experts encoder, '
                                    f'unconditional posterior, full-shard minibatch',
-                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': 'hipGraph replay' if graph is not None else 'eager',
+                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': 'hipGraph replay' if m['graph'] else 'eager',
                        'final_loss_per_term': final_loss / (P * I * world)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': None,
-                         'kernel': 'vibo::elbo_kernel (+item_prep, finalize helpers inside the timed events)',
+                         'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_note': traffic_note,
+                         'kernel': ('vibo::row_kernel' if A <= 2 and irt <= 2 else 'vibo::elbo_kernel') + ' (+ item_prep, finalize helpers inside the timed events)',
                          'kernel_ms': kern_ms, 'bytes_per_term': bytes_per_term},
         }
+        if also is not None:
+            line['also'] = also
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, irt)
         print(json.dumps(line))

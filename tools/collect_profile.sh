@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run on the GPU box: rocprofv3 evidence for `python bench.py --steps 5 --warmup 2 --no-cpu-baseline`.
+# Writes a text summary to gpurun_out/profile_summary.txt (the rocpd databases are deleted: too large to copy back).
+# Counter passes follow MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, no tracing flags
+# other than the implicit kernel dispatch table.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+W=/tmp/vibo_prof; rm -rf $W; mkdir -p $W
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $BENCH_ARGS"
+S=$OUT/profile_summary.txt
+{
+echo "# command: rocprofv3 --kernel-trace --stats -- $B"
+rocprofv3 --kernel-trace --stats -d $W/kt -o kt -- $B > $W/kt.log 2>&1
+echo "# bench line under the profiler:"; grep "^{" $W/kt.log
+python $R/tools/rocpd_summary.py $W/kt/kt_results.db | head -12
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  n=$(echo $pass | cut -d' ' -f1)
+  echo; echo "# command: rocprofv3 --pmc $pass -- $B     (per-dispatch averages, vibo kernels only)"
+  rocprofv3 --pmc $pass -d $W/$n -o p -- $B > /dev/null 2>&1
+  python $R/tools/rocpd_summary.py $W/$n/p_results.db vibo | grep -E "10ElboParams|finalize|item_prep"
+done
+} > $S 2>&1
+rm -rf $W
+echo "wrote $S"

@@ -19,27 +19,32 @@ ap.add_argument('--ability-dim', type=int, default=8)
 ap.add_argument('--irt', type=int, default=2)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--no-grad', action='store_true')
+ap.add_argument('--cond', action='store_true')
+ap.add_argument('--flows', type=int, default=0)
+ap.add_argument('--missing', type=float, default=0.1)
 a = ap.parse_args()
 d = torch.device('cuda:0')
 g = torch.Generator(device=d).manual_seed(0)
 P, I, A = a.persons, a.items, a.ability_dim
 D = {1: 1, 2: A + 1, 3: A + 2}[a.irt]
 resp = (torch.rand(P, I, device=d, generator=g) < 0.5).float()
-mask = torch.rand(P, I, device=d, generator=g) > 0.1
-spec = ElboSpec(irt_model=a.irt, ability_dim=A)
-table = torch.randn(2, 2 * A, device=d, generator=g) * 0.5
+mask = torch.rand(P, I, device=d, generator=g) >= a.missing
+spec = ElboSpec(irt_model=a.irt, ability_dim=A, conditional=a.cond, n_flows=a.flows)
+table = torch.randn(*spec.table_shape(I), device=d, generator=g) * 0.5
+flow = torch.randn(a.flows, 2 * A + 1, device=d, generator=g) * 0.5 if a.flows else None
+reg = _lib.REG_SAMPLED if a.flows else _lib.REG_KL
 item = torch.randn(I, D, device=d, generator=g)
 eps = torch.randn(P, A, device=d, generator=g)
 m, code = ops.prepare_mask(mask)
 for _ in range(a.iters):
-    raw = ops._hip_launch_elbo(spec, resp, m, code, None, table, item, eps, None, _lib.REG_KL, not a.no_grad, P)
+    raw = ops._hip_launch_elbo(spec, resp, m, code, None, table, item, eps, flow, reg, not a.no_grad, P)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.iters):
-    raw = ops._hip_launch_elbo(spec, resp, m, code, None, table, item, eps, None, _lib.REG_KL, not a.no_grad, P)
+    raw = ops._hip_launch_elbo(spec, resp, m, code, None, table, item, eps, flow, reg, not a.no_grad, P)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
-print(f'P={P} I={I} A={A} irt={a.irt} grad={not a.no_grad}: {ms:.3f} ms/call, {P*I/ms/1e9:.3f} T terms/s, '
+print(f'P={P} I={I} A={A} irt={a.irt} cond={a.cond} flows={a.flows} grad={not a.no_grad}: {ms:.3f} ms/call, {P*I/ms/1e9:.3f} T terms/s, '
       f'{(5+12*A/I)*P*I/ms/1e6:.0f} GB/s algorithmic, ll={float(raw.scalars[0]):.1f}')
