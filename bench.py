@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=8)
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
+    ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
     ap.add_argument('--force-dist', action='store_true', help='create the process group even for one rank (tests the RCCL path)')
     return ap.parse_args()
@@ -144,9 +145,14 @@ def main():
         resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
         torch.manual_seed(args.seed)
         model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge='product').to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=not args.no_graph, fused=True)
         if dist is not None:
             model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
+        trainer, opt = None, None
+        if args.torch_optimizer or args.eval_only:
+            opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=not args.no_graph, fused=True)
+        else:
+            from vibo_amd.trainer import FusedTrainer
+            trainer = FusedTrainer(model, lr=args.lr)
 
         # HIP events around the native call, on the stream it is launched on
         events = []
@@ -171,6 +177,8 @@ def main():
             if args.eval_only:
                 with torch.no_grad():
                     return model.elbo_step(resp, mask)
+            if trainer is not None:
+                return trainer.step(resp, mask)
             opt.zero_grad(set_to_none=False)
             loss = model.elbo_step(resp, mask)
             loss.backward()
@@ -193,7 +201,8 @@ def main():
                 for gen in (model._item_gen, model._ability_gen):      # dedicated generators of the person-sharded mode
                     if gen is not None:
                         g.register_generator_state(gen)
-                opt.zero_grad(set_to_none=False)
+                if opt is not None:
+                    opt.zero_grad(set_to_none=False)
                 with torch.cuda.graph(g):
                     static_loss = step()
                 graph = g
@@ -241,7 +250,7 @@ def main():
         bytes_per_term = 5.0 + 12.0 * A / I
         achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         ops._BACKEND['elbo'] = native
-        del resp, mask, model, opt
+        del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()
         return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None)
 
@@ -279,6 +288,7 @@ def main():
                                    f'ability_dim={A}, {args.missing:.0%} missing, product-of-experts encoder, '
                                    f'unconditional posterior, full-shard minibatch',
                        'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': 'hipGraph replay' if m['graph'] else 'eager',
+                       'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',
                        'final_loss_per_term': final_loss / (P * I * world)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_note': traffic_note,

@@ -159,6 +159,40 @@ int vibo_encode(const vibo_desc* d,
 int vibo_decode(const vibo_desc* d, const float* ability, const float* item,
                 float* response_mu, void* stream);
 
+
+/*
+ * Fused O(I) part of one VIBO train step (unconditional posterior, no flows), for trainers that want the whole
+ * step as ~5 kernels instead of ~80 tiny PyTorch launches.  Semantics = the PyTorch statements they replace:
+ *
+ * vibo_train_prologue   (models.py:356-361, 575-582, 713-726, 506-510; utils.py:85-88)
+ *     step_count += 1
+ *     item_feat = item_mu + exp(0.5 * item_logvar) * eps_item                       [I][D]
+ *     kl_parts[b] = partial sums of  -0.5 (1 + logvar - mu^2 - exp(logvar))         (summed by the epilogue)
+ *     table[c] = W2 . elu(W1 . elu(W0 * c + b0) + b1) + b2   for c in {0,1}          [2][2A]
+ *     saved activations h1, h2 [2][H]
+ * vibo_train_epilogue   (models.py:427-443; vibo.py:267-268 = loss.backward(); optimizer.step())
+ *     loss = -LL + beta * (REG + KL_item)                with LL, REG, d/dtable, d/ditem read from `flat`
+ *            (the buffer vibo_elbo_fwd_bwd filled: [8 scalars | grad_table[2][2][2A] | grad_item[I][D]])
+ *     gradients of the encoder MLP (2-row backward by hand) and of item_mu / item_logvar, immediately
+ *     applied with Adam (betas 0.9/0.999, eps 1e-8, no weight decay, torch.optim.Adam's update formula).
+ *     Parameters and Adam moments are updated IN PLACE.
+ *
+ *  mlp_params / adam_m / adam_v: one flat fp32 buffer each laid out  W0[H] | b0[H] | W1[H][H] | b1[H] | W2[2A][H] | b2[2A]
+ *  item_mu, item_logvar, item_m/v (mu then logvar): [I][D] each
+ *  beta, lr: device scalars (fp32) so that an annealing schedule stays hipGraph-capturable
+ *  step_count: device int32, incremented by the prologue
+ *  kl_parts: workspace of at least ceil(I*D/256) floats;  hidden_dim H <= 256
+ */
+int vibo_train_prologue(const vibo_desc* d, int hidden_dim, const float* mlp_params, const float* item_mu,
+                        const float* item_logvar, const float* eps_item, float* item_feat, float* table,
+                        float* saved_h, float* kl_parts, int32_t* step_count, void* stream);
+
+int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, const float* saved_h,
+                        const float* kl_parts, const float* eps_item, const float* beta, const float* lr,
+                        const int32_t* step_count, float* mlp_params, float* mlp_m, float* mlp_v,
+                        float* item_mu, float* item_logvar, float* item_m, float* item_v, float* loss_out,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

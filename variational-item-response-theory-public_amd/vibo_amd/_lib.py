@@ -43,7 +43,7 @@ class ViboDesc(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
-                    'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode')
+                    'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue')
 
 _lib = None
 
@@ -80,6 +80,10 @@ def load():
     lib.vibo_encode.argtypes = [dp, fp, vp, i64p, fp, fp, fp, vp, ctypes.c_size_t, vp]
     lib.vibo_decode.restype = ctypes.c_int
     lib.vibo_decode.argtypes = [dp, fp, fp, fp, vp]
+    lib.vibo_train_prologue.restype = ctypes.c_int
+    lib.vibo_train_prologue.argtypes = [dp, ctypes.c_int] + [fp] * 8 + [vp, vp]
+    lib.vibo_train_epilogue.restype = ctypes.c_int
+    lib.vibo_train_epilogue.argtypes = [dp, ctypes.c_int] + [fp] * 6 + [vp] + [fp] * 8 + [vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

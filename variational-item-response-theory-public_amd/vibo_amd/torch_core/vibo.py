@@ -68,6 +68,8 @@ def build_parser():
     p.add_argument('--gpu-device', type=int, default=0)
     p.add_argument('--cuda', action='store_true', default=False)
     # additive (not in the reference)
+    p.add_argument('--torch-optimizer', action='store_true', default=False,
+                   help='use autograd + torch.optim.Adam for the O(I) part instead of the fused HIP trainer kernels')
     p.add_argument('--store-predictive-samples', action='store_true', default=False,
                    help='keep all S posterior-predictive samples [S,P,I,1] in the checkpoint like the '
                         'reference (default: only their mean, [1,P,I,1])')
@@ -134,17 +136,20 @@ def annealing_factor(args, epoch, batch_idx, n_batches):
     return args.beta_kl
 
 
-def train_epoch(model, optimizer, data, args, epoch, batch_size):
+def train_epoch(model, optimizer, data, args, epoch, batch_size, trainer=None):
     model.train()
     n_batches = data.num_batches(batch_size)
     wsum = torch.zeros((), device=data.device)
     count = 0
     for batch_idx, rows in enumerate(data.batches(batch_size, shuffle=True)):
         beta = annealing_factor(args, epoch, batch_idx, n_batches)
-        optimizer.zero_grad(set_to_none=True)
-        loss = model.elbo_step(data.response, data.mask, annealing_factor=beta, row_index=rows)
-        loss.backward()
-        optimizer.step()
+        if trainer is not None:          # fused prologue / ELBO / epilogue+Adam kernels
+            loss = trainer.step(data.response, data.mask, beta=beta, row_index=rows)
+        else:
+            optimizer.zero_grad(set_to_none=True)
+            loss = model.elbo_step(data.response, data.mask, annealing_factor=beta, row_index=rows)
+            loss.backward()
+            optimizer.step()
         wsum += loss.detach() * rows.numel()          # AverageMeter weighting (vibo.py:270), one sync per epoch
         count += rows.numel()
     avg = float(wsum) / max(1, count)
@@ -295,12 +300,16 @@ def main(argv=None):
     if world > 1:
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    trainer = None
+    if args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and not args.torch_optimizer:
+        from ..trainer import FusedTrainer
+        trainer = FusedTrainer(model, lr=args.lr)       # same Adam arithmetic, ~7 launches per step
 
     best_loss = np.inf
     train_losses, test_losses, train_times = np.zeros(args.epochs), np.zeros(args.epochs), np.zeros(args.epochs)
     for epoch in range(args.epochs):
         t0 = time.time()
-        train_loss = train_epoch(model, optimizer, train, args, epoch, local_bs)
+        train_loss = train_epoch(model, optimizer, train, args, epoch, local_bs, trainer)
         if args.cuda:
             torch.cuda.synchronize()
         train_losses[epoch] = train_loss
