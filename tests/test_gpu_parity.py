@@ -131,6 +131,14 @@ SHAPES = [
     (3, 8, 90, 640, 0.0),
     (3, 2, 50, 95, 0.3),
     (3, 6, 64, 1003, 0.1),
+    # row-split kernel (A >= 3, 1PL/2PL, 192 <= I <= 1024, I % 4 == 0): 1..4 waves per row
+    (2, 3, 257, 256, 0.2),
+    (2, 6, 41, 260, 0.1),
+    (2, 8, 1001, 768, 0.1),
+    (1, 8, 64, 1000, 0.1),
+    (1, 4, 77, 332, 0.2),
+    (2, 4, 9, 1024, 0.5),
+    (2, 7, 3, 196, 0.0),
 ]
 
 

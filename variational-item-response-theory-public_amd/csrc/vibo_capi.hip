@@ -53,6 +53,8 @@ struct Plan {
     bool general;             // wave-per-person kernel (conditional posterior / flows / > 1024 items)
     bool row_ok;              // wave-per-row register kernel is applicable (subject to alignment)
     int row_nblk;
+    bool split_ok;            // row-split register kernel (ability_dim 3..8) is applicable (subject to alignment)
+    int split_nq, split_nblk;
     int AT, D, DP, n_tiles, nblk, lds_main;
     LaunchGeom geom;
     PartialLayout lay;
@@ -111,6 +113,11 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->row_ok = A <= 2 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0);
     pl->row_nblk = g_num_cu * 2;          // 16 items x (params + grads) per lane: 2 workgroups (8 waves) per CU
     if (pl->row_nblk > (d->num_person + 3) / 4) pl->row_nblk = (d->num_person + 3) / 4;
+    // row-split kernel (3 <= A <= 8, 1PL/2PL, 192 <= I <= 1024): NQ waves share a row, 8 waves per CU
+    pl->split_ok = A >= 3 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
+    pl->split_nq = (I + 255) / 256;
+    pl->split_nblk = g_num_cu * (8 / pl->split_nq);
+    if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
     pl->geom.grid = nblk;
@@ -119,7 +126,9 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->off_item_prep = 0;
     size_t prep_bytes = ((size_t)((I + 15) & ~15) * pl->DP * 4 + 255) & ~(size_t)255;
     pl->off_partial = prep_bytes;
-    const int max_blk = (pl->row_ok && pl->row_nblk > nblk) ? pl->row_nblk : nblk;
+    int max_blk = nblk;
+    if (pl->row_ok && pl->row_nblk > max_blk) max_blk = pl->row_nblk;
+    if (pl->split_ok && pl->split_nblk > max_blk) max_blk = pl->split_nblk;
     pl->total_bytes = prep_bytes + (size_t)max_blk * pl->lay.stride * 4 + 256;
     return stride;
 }
@@ -388,6 +397,9 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     if (pl.row_ok && vec) {
         nblk_used = pl.row_nblk;
         e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);
+    } else if (pl.split_ok && vec) {
+        nblk_used = pl.split_nblk;
+        e = launch_elbo_split(p, pl.AT, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
     } else
     switch (pl.AT) {
         case 1: e = launch_elbo_a1(p, d->irt_model, grad, pl.geom, s); break;

@@ -21,4 +21,7 @@ hipError_t launch_elbo_a8(const ElboParams& p, int irt, bool grad, const LaunchG
 // wave-per-row kernel (vibo_row_kernel.hip): A in {1,2}, 1PL/2PL, I <= 1024, 16-byte aligned rows
 hipError_t launch_elbo_rows(const ElboParams& p, int irt, bool grad, int grid, hipStream_t s);
 
+// row-split kernel (vibo_split_kernel.hip): ability_dim 3..8 (at = 4 | 8), 1PL/2PL, I <= 1024, nq = ceil(I / 256)
+hipError_t launch_elbo_split(const ElboParams& p, int at, int irt, bool grad, int nq, int grid, hipStream_t s);
+
 }  // namespace vibo
