@@ -18,6 +18,7 @@
 //     whose lane (r, d) backpropagates through the sample and the PoE into the 8 table-gradient accumulators.
 // Outputs use the same per-workgroup partial record as the other kernels (fixed order, bitwise reproducible).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "vibo_device.hpp"
 #include "vibo_launch.hpp"
 #include "vibo_params.hpp"
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
     __shared__ float red[NQ][8];
     __shared__ float tred[8][64];
     __shared__ uint32_t codes[NQ][R][64];  // this batch's fp8 code words (read back one row at a time)
+    __shared__ __attribute__((aligned(16))) float thl[NQ][64];         // theta[r][d] of the batch, per wave
+    __shared__ __attribute__((aligned(16))) float gtl[NQ][2][8][68];   // d LL/d theta partials, transposed
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -120,15 +123,17 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
     }
 
     // ---- this lane's 4 items (log2 units: rows prepped by item_prep_kernel) ----
-    float na[4][AT], nb[4];
-    float acc_a[4][AT], acc_b[4];
+    float2v na2[4][AT / 2];
+    float nb[4];
+    float2v acc_a2[4][AT / 2];
+    float acc_b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = 4 * chunk + j;
 #pragma unroll
         for (int a = 0; a < AT; ++a) {
-            na[j][a] = chunk_ok ? p.item_prep[(size_t)i * p.DP + a] : 0.f;
-            acc_a[j][a] = 0.f;
+            na2[j][a >> 1][a & 1] = chunk_ok ? p.item_prep[(size_t)i * p.DP + a] : 0.f;
+            acc_a2[j][a >> 1][a & 1] = 0.f;
         }
         nb[j] = chunk_ok ? p.item_prep[(size_t)i * p.DP + AT] : 0.f;
         acc_b[j] = 0.f;
@@ -216,66 +221,98 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
             if (ed == 0) s_nobs += nobs;
         }
 
-        // ---- decode, masked Bernoulli log-lik, backward: 4 items per lane, theta in SGPRs ----
-        // The reference clamps the Bernoulli probability (utils.py:46-49 -> torch): log-lik value clamped at
-        // logit +-kLogitLo, gradient exactly zero outside [-kLogitLo, kLogitHi]; rare, so wave-uniform slow path.
-        const int th_bits = __builtin_bit_cast(int, thv);
+        // ---- decode, masked Bernoulli log-lik, backward: 4 items per lane ----
+        // theta goes through a wave-private LDS row and comes back as broadcast reads (v_readlane costs 3 VALU
+        // slots each, tools/ubench2).  The reference clamps the Bernoulli probability (utils.py:46-49 -> torch):
+        // log-lik value clamped at logit +-kLogitLo, gradient exactly zero outside [-kLogitLo, kLogitHi]; that
+        // is rare, so the clamped arithmetic lives in a second copy of the row body behind a wave-uniform branch.
+        thl[q][lane] = thv;
+        auto reduce_group = [&](const int g) {
+            // transposed read-back of group g's 8 x 64 partials: lane (k = l >> 3, s = l & 7) sums 8 lanes of
+            // value k, then 3 DPP steps finish the 64-lane sum
+            const float* src = &gtl[q][g & 1][lane >> 3][(lane & 7) * 8];
+            const float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
+            float t = ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
+            t += dpp_f<0xb1>(t);                     // quad_perm [1,0,3,2]
+            t += dpp_f<0x4e>(t);                     // quad_perm [2,3,0,1]
+            t += dpp_f<0x141>(t);                    // row_half_mirror
+            if ((lane & 7) == 0) gthp[q][g * 8 + (lane >> 3)] = t;
+        };
 #pragma unroll 1
         for (int g = 0; g < R / RPB; ++g) {
-            float gth[8];
+            float2v gth2[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) gth[k] = 0.f;
+            for (int k = 0; k < 4; ++k) gth2[k] = float2v{0.f, 0.f};
 #pragma unroll
             for (int rr = 0; rr < RPB; ++rr) {
                 const int r = g * RPB + rr;
                 const uint32_t cwr = codes[q][r][lane];
-                float th[AT];
+                float2v th2[AT / 2];
 #pragma unroll
-                for (int a = 0; a < AT; ++a)
-                    th[a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(th_bits, r * AT + a));
-                float lg[4];
-                bool sat = false;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float l = nb[t];
-#pragma unroll
-                    for (int a = 0; a < AT; ++a) l = fmaf(na[t][a], th[a], l);
-                    lg[t] = l;
-                    sat |= fabsf(l) > kLoS;
+                for (int a = 0; a < AT; a += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&thl[q][r * AT + a]);
+                    th2[a / 2] = float2v{t4.x, t4.y};
+                    th2[a / 2 + 1] = float2v{t4.z, t4.w};
                 }
-                const bool exact = __any(sat);
+                float lg[4];
+                float lmax = 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    float w;
-                    if (t == 0) w = code_to_f32<0>(cwr);
-                    else if (t == 1) w = code_to_f32<1>(cwr);
-                    else if (t == 2) w = code_to_f32<2>(cwr);
-                    else w = code_to_f32<3>(cwr);
-                    float lc = lg[t], wg = w;
-                    if (exact) {
-                        const float l2 = med3(lg[t], -kLoS, kHiS);
-                        lc = fminf(l2, kLoS);
-                        wg = (lg[t] == l2) ? w : 0.f;
-                    }
-                    const float eu = fast_exp2(-w * lc);
-                    const float tt = 1.0f + eu;
-                    s_log = fmaf(fabsf(w), fast_log2(tt), s_log);
-                    if constexpr (GRAD) {
-                        const float gl = wg * (eu * fast_rcp(tt));                   // d ll / d logit
+                    float2v l2 = float2v{nb[t], 0.f};
 #pragma unroll
-                        for (int a = 0; a < AT; ++a) {
-                            gth[rr * AT + a] = fmaf(gl, na[t][a], gth[rr * AT + a]);   // x log2e, removed below
-                            if (IRT != 1) acc_a[t][a] = fmaf(gl, th[a], acc_a[t][a]);  // = -d/d a_ia
+                    for (int h = 0; h < AT / 2; ++h) l2 = na2[t][h] * th2[h] + l2;
+                    lg[t] = l2[0] + l2[1];
+                    lmax = fmaxf(lmax, fabsf(lg[t]));
+                }
+                const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cwr, false);
+                const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cwr, true);
+                const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
+                float prod = 1.0f;
+                float gls[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    // value: the clamp at +-kLogitLo is exactly the reference's; gradient: see the fix-up below
+                    const float lc = med3(lg[t], -kLoS, kLoS);
+                    const float eu = fast_exp2(-w[t] * lc);
+                    const float tt = fmaf(fabsf(w[t]), eu, 1.0f);     // 1 for a missing cell: log2 = 0
+                    prod *= tt;                                       // <= (1 + 2^23)^4: one log2 per 4 terms
+                    if constexpr (GRAD) {
+                        const float gl = w[t] * (eu * fast_rcp(tt));  // d ll / d logit
+                        gls[t] = gl;
+#pragma unroll
+                        for (int h = 0; h < AT / 2; ++h) {
+                            gth2[rr * (AT / 2) + h] = na2[t][h] * gl + gth2[rr * (AT / 2) + h];   // x log2e, removed below
+                            if (IRT != 1) acc_a2[t][h] = th2[h] * gl + acc_a2[t][h];              // = -d/d a_ia
                         }
                         acc_b[t] += gl;
                     }
                 }
+                s_log += fast_log2(prod);
+                if constexpr (GRAD) {
+                    if (__any(lmax > kLoS)) {
+                        // rare: the reference's gradient is exactly zero outside [-kLogitLo, kLogitHi]; take the
+                        // contributions of those cells back out
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float gl = (lg[t] < -kLoS || lg[t] > kHiS) ? -gls[t] : 0.f;
+#pragma unroll
+                            for (int h = 0; h < AT / 2; ++h) {
+                                gth2[rr * (AT / 2) + h] = na2[t][h] * gl + gth2[rr * (AT / 2) + h];
+                                if (IRT != 1) acc_a2[t][h] = th2[h] * gl + acc_a2[t][h];
+                            }
+                            acc_b[t] += gl;
+                        }
+                    }
+                }
             }
             if constexpr (GRAD) {
-                const float tot = bfly8(gth, lane);
-                if ((lane & 7) == 0) gthp[q][g * 8 + (lane >> 3)] = tot;
+                // 64-lane sums of the 8 partials through an LDS transpose, one group behind the math
+                if (g > 0) reduce_group(g - 1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gtl[q][g & 1][k][lane] = gth2[k >> 1][k & 1];
             }
         }
+        if constexpr (GRAD) reduce_group(R / RPB - 1);
         if constexpr (GRAD) {
             __syncthreads();
             // ---- wave 0, lane (er, ed): backward through the sample and the PoE into the table gradients ----
@@ -352,7 +389,7 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
                 for (int a = 0; a < AT; ++a)
                     if (a < A)
                         *reinterpret_cast<float4*>(oi + (size_t)a * p.lay.i_pad) =
-                            float4{-acc_a[0][a], -acc_a[1][a], -acc_a[2][a], -acc_a[3][a]};
+                            float4{-acc_a2[0][a >> 1][a & 1], -acc_a2[1][a >> 1][a & 1], -acc_a2[2][a >> 1][a & 1], -acc_a2[3][a >> 1][a & 1]};
                 *reinterpret_cast<float4*>(oi + (size_t)A * p.lay.i_pad) = float4{acc_b[0], acc_b[1], acc_b[2], acc_b[3]};
             }
         }
