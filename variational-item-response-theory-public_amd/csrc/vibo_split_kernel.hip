@@ -190,7 +190,12 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
         __builtin_amdgcn_sched_barrier(0);
         {
             const int tot = bfly8(pk, lane);
-            if ((lane & 7) == 0) cntp[q][lane >> 3] = tot;
+            if ((lane & 7) == 0) {
+                cntp[q][lane >> 3] = tot;
+                // every lane-cell without an observation (missing, padding, rows past the end) contributes
+                // log2(1 + 2^0) = 1 to the running log-lik sum below: take those out here, once per row
+                s_log -= (float)(256 - (tot & 0xffff));
+            }
         }
         __syncthreads();
 
@@ -227,33 +232,44 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
         // log-lik value clamped at logit +-kLogitLo, gradient exactly zero outside [-kLogitLo, kLogitHi]; that
         // is rare, so the clamped arithmetic lives in a second copy of the row body behind a wave-uniform branch.
         thl[q][lane] = thv;
-        auto reduce_group = [&](const int g) {
-            // transposed read-back of group g's 8 x 64 partials: lane (k = l >> 3, s = l & 7) sums 8 lanes of
-            // value k, then 3 DPP steps finish the 64-lane sum
-            const float* src = &gtl[q][g & 1][lane >> 3][(lane & 7) * 8];
-            const float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
-            float t = ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
-            t += dpp_f<0xb1>(t);                     // quad_perm [1,0,3,2]
-            t += dpp_f<0x4e>(t);                     // quad_perm [2,3,0,1]
-            t += dpp_f<0x141>(t);                    // row_half_mirror
-            if ((lane & 7) == 0) gthp[q][g * 8 + (lane >> 3)] = t;
+        // row group = RPB rows (one d LL/d theta reduction).  Software pipeline over groups: the LDS reads of
+        // group g+1 (codes, theta) and the transposed partials of group g-1 are issued before group g's math.
+        struct GroupIn {
+            uint32_t cw[RPB];
+            float2v th2[RPB][AT / 2];
         };
-#pragma unroll 1
-        for (int g = 0; g < R / RPB; ++g) {
+        auto fetch_group = [&](const int g, GroupIn& gi) {
+#pragma unroll
+            for (int rr = 0; rr < RPB; ++rr) {
+                const int r = g * RPB + rr;
+                gi.cw[rr] = codes[q][r][lane];
+#pragma unroll
+                for (int a = 0; a < AT; a += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&thl[q][r * AT + a]);
+                    gi.th2[rr][a / 2] = float2v{t4.x, t4.y};
+                    gi.th2[rr][a / 2 + 1] = float2v{t4.z, t4.w};
+                }
+            }
+        };
+        auto do_group = [&](const int g, const GroupIn& gi, GroupIn& nxt) {
+            constexpr int G = R / RPB;
+            if (g + 1 < G) fetch_group(g + 1, nxt);
+            float4 ru = float4{0.f, 0.f, 0.f, 0.f}, rv = ru;
+            if constexpr (GRAD) {
+                if (g > 0) {
+                    // transposed read-back of group g-1's 8 x 64 partials: lane (k = l >> 3, s = l & 7) sums 8
+                    // lanes of value k, then 3 DPP steps finish the 64-lane sum
+                    const float* src = &gtl[q][(g - 1) & 1][lane >> 3][(lane & 7) * 8];
+                    ru = *reinterpret_cast<const float4*>(src);
+                    rv = *reinterpret_cast<const float4*>(src + 4);
+                }
+            }
             float2v gth2[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) gth2[k] = float2v{0.f, 0.f};
 #pragma unroll
             for (int rr = 0; rr < RPB; ++rr) {
-                const int r = g * RPB + rr;
-                const uint32_t cwr = codes[q][r][lane];
-                float2v th2[AT / 2];
-#pragma unroll
-                for (int a = 0; a < AT; a += 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(&thl[q][r * AT + a]);
-                    th2[a / 2] = float2v{t4.x, t4.y};
-                    th2[a / 2 + 1] = float2v{t4.z, t4.w};
-                }
+                const float2v(&th2)[AT / 2] = gi.th2[rr];
                 float lg[4];
                 float lmax = 0.f;
 #pragma unroll
@@ -264,8 +280,8 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
                     lg[t] = l2[0] + l2[1];
                     lmax = fmaxf(lmax, fabsf(lg[t]));
                 }
-                const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cwr, false);
-                const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cwr, true);
+                const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)gi.cw[rr], false);
+                const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)gi.cw[rr], true);
                 const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
                 float prod = 1.0f;
                 float gls[4];
@@ -273,9 +289,10 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
                 for (int t = 0; t < 4; ++t) {
                     // value: the clamp at +-kLogitLo is exactly the reference's; gradient: see the fix-up below
                     const float lc = med3(lg[t], -kLoS, kLoS);
-                    const float eu = fast_exp2(-w[t] * lc);
-                    const float tt = fmaf(fabsf(w[t]), eu, 1.0f);     // 1 for a missing cell: log2 = 0
-                    prod *= tt;                                       // <= (1 + 2^23)^4: one log2 per 4 terms
+                    const float eu = fast_exp2(-w[t] * lc);           // exactly 1 for a missing cell (w = 0)
+                    const float tt = 1.0f + eu;
+                    prod *= tt;                 // <= (1 + 2^23)^4: one log2 per 4 terms; the 2s of missing cells
+                                                // are taken out per batch (s_log correction above)
                     if constexpr (GRAD) {
                         const float gl = w[t] * (eu * fast_rcp(tt));  // d ll / d logit
                         gls[t] = gl;
@@ -306,13 +323,37 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
                 }
             }
             if constexpr (GRAD) {
-                // 64-lane sums of the 8 partials through an LDS transpose, one group behind the math
-                if (g > 0) reduce_group(g - 1);
+                if (g > 0) {
+                    float t = ((ru.x + ru.y) + (ru.z + ru.w)) + ((rv.x + rv.y) + (rv.z + rv.w));
+                    t += dpp_f<0xb1>(t);                     // quad_perm [1,0,3,2]
+                    t += dpp_f<0x4e>(t);                     // quad_perm [2,3,0,1]
+                    t += dpp_f<0x141>(t);                    // row_half_mirror
+                    if ((lane & 7) == 0) gthp[q][(g - 1) * 8 + (lane >> 3)] = t;
+                }
+                // 64-lane sums of the 8 partials go through an LDS transpose, one group behind the math
 #pragma unroll
                 for (int k = 0; k < 8; ++k) gtl[q][g & 1][k][lane] = gth2[k >> 1][k & 1];
             }
+        };
+        {
+            GroupIn ga, gb;
+            fetch_group(0, ga);
+#pragma unroll 1
+            for (int g = 0; g < R / RPB; g += 2) {
+                do_group(g, ga, gb);
+                do_group(g + 1, gb, ga);
+            }
         }
-        if constexpr (GRAD) reduce_group(R / RPB - 1);
+        if constexpr (GRAD) {
+            constexpr int g = R / RPB - 1;
+            const float* src = &gtl[q][g & 1][lane >> 3][(lane & 7) * 8];
+            const float4 ru = *reinterpret_cast<const float4*>(src), rv = *reinterpret_cast<const float4*>(src + 4);
+            float t = ((ru.x + ru.y) + (ru.z + ru.w)) + ((rv.x + rv.y) + (rv.z + rv.w));
+            t += dpp_f<0xb1>(t);
+            t += dpp_f<0x4e>(t);
+            t += dpp_f<0x141>(t);
+            if ((lane & 7) == 0) gthp[q][g * 8 + (lane >> 3)] = t;
+        }
         if constexpr (GRAD) {
             __syncthreads();
             // ---- wave 0, lane (er, ed): backward through the sample and the PoE into the table gradients ----
