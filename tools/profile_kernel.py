@@ -22,6 +22,7 @@ ap.add_argument('--no-grad', action='store_true')
 ap.add_argument('--cond', action='store_true')
 ap.add_argument('--flows', type=int, default=0)
 ap.add_argument('--missing', type=float, default=0.1)
+ap.add_argument('--cached-rows', type=int, default=0, help='gather rows from the first N rows only (L2-resident): compute-only timing')
 a = ap.parse_args()
 d = torch.device('cuda:0')
 g = torch.Generator(device=d).manual_seed(0)
@@ -36,13 +37,14 @@ reg = _lib.REG_SAMPLED if a.flows else _lib.REG_KL
 item = torch.randn(I, D, device=d, generator=g)
 eps = torch.randn(P, A, device=d, generator=g)
 m, code = ops.prepare_mask(mask)
+ridx = (torch.arange(P, device=d) % a.cached_rows) if a.cached_rows else None
 for _ in range(a.iters):
-    raw = ops._hip_launch_elbo(spec, resp, m, code, None, table, item, eps, flow, reg, not a.no_grad, P)
+    raw = ops._hip_launch_elbo(spec, resp, m, code, ridx, table, item, eps, flow, reg, not a.no_grad, P)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.iters):
-    raw = ops._hip_launch_elbo(spec, resp, m, code, None, table, item, eps, flow, reg, not a.no_grad, P)
+    raw = ops._hip_launch_elbo(spec, resp, m, code, ridx, table, item, eps, flow, reg, not a.no_grad, P)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters

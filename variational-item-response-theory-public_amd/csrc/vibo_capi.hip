@@ -113,9 +113,15 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->row_ok = A <= 2 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0);
     pl->row_nblk = g_num_cu * 2;          // 16 items x (params + grads) per lane: 2 workgroups (8 waves) per CU
     if (pl->row_nblk > (d->num_person + 3) / 4) pl->row_nblk = (d->num_person + 3) / 4;
-    // row-split kernel (3 <= A <= 8, 1PL/2PL, 192 <= I <= 1024): NQ waves share a row, 8 waves per CU
-    pl->split_ok = A >= 3 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
+    // row-split kernel (1PL/2PL, 192 <= I <= 1024, u8 / no mask): NQ waves share a row, 8 waves per CU.
+    // Preferred over the wave-per-row kernel (1.03 vs 1.10 ms at A = 1, 1.03 vs 1.49 ms at A = 2 on 1M x 1k),
+    // which stays for int64 masks.
+    pl->split_ok = d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
     pl->split_nq = (I + 255) / 256;
+    if (pl->split_ok && pl->AT == 1) {       // the row-split kernel's narrowest template is 2 wide
+        pl->AT = 2;
+        pl->DP = prepped_item_width(d->irt_model, 2);
+    }
     pl->split_nblk = g_num_cu * (8 / pl->split_nq);
     if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
     pl->lds_main = (int)main_b;
@@ -394,12 +400,12 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
 
     const bool grad = d->want_grad != 0;
     int nblk_used = pl.nblk;
-    if (pl.row_ok && vec) {
-        nblk_used = pl.row_nblk;
-        e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);
-    } else if (pl.split_ok && vec) {
+    if (pl.split_ok && vec) {
         nblk_used = pl.split_nblk;
         e = launch_elbo_split(p, pl.AT, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
+    } else if (pl.row_ok && vec && pl.AT == A) {
+        nblk_used = pl.row_nblk;
+        e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);
     } else
     switch (pl.AT) {
         case 1: e = launch_elbo_a1(p, d->irt_model, grad, pl.geom, s); break;

@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t pack_codes4(const float4 x, const uint32_t m
     // byte 3 of 1.0f is 0x3F, of 0.0f is 0x00: bit 24 tells "correct"
     const uint32_t hi = __builtin_amdgcn_perm(x1, x0, 0x0c0c0703u) | __builtin_amdgcn_perm(x3, x2, 0x07030c0cu);
     const uint32_t xb = hi & 0x01010101u;
-    const uint32_t code = (0xB8B8B8B8u ^ (xb << 7)) & (m * 0xFFu);
+    const uint32_t code = (0xB8B8B8B8u ^ (xb << 7)) & ((m << 8) - m);   // m * 0xFF without the slow v_mul_lo_u32
     packed += __builtin_popcount(m) + (__builtin_popcount(xb & m) << 16);
     return code;
 }

@@ -243,11 +243,15 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
             for (int rr = 0; rr < RPB; ++rr) {
                 const int r = g * RPB + rr;
                 gi.cw[rr] = codes[q][r][lane];
+                if constexpr (AT >= 4) {
 #pragma unroll
-                for (int a = 0; a < AT; a += 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(&thl[q][r * AT + a]);
-                    gi.th2[rr][a / 2] = float2v{t4.x, t4.y};
-                    gi.th2[rr][a / 2 + 1] = float2v{t4.z, t4.w};
+                    for (int a = 0; a < AT; a += 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(&thl[q][r * AT + a]);
+                        gi.th2[rr][a / 2] = float2v{t4.x, t4.y};
+                        gi.th2[rr][a / 2 + 1] = float2v{t4.z, t4.w};
+                    }
+                } else {
+                    gi.th2[rr][0] = *reinterpret_cast<const float2v*>(&thl[q][r * AT]);
                 }
             }
         };
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(64 * NQ, 2) void split_kernel(const ElboParams p) {
 #pragma unroll 1
             for (int g = 0; g < R / RPB; g += 2) {
                 do_group(g, ga, gb);
-                do_group(g + 1, gb, ga);
+                if (g + 1 < R / RPB) do_group(g + 1, gb, ga);
             }
         }
         if constexpr (GRAD) {
@@ -451,6 +455,10 @@ static hipError_t launch_split_nq(const ElboParams& p, int nq, int grid, hipStre
 // ability_dim 3..8 (template widths 4 / 8), irt in {1,2}, I <= 1024, I % 4 == 0, 16-byte aligned rows,
 // mask u8 or none.  nq = ceil(I / 256) waves per workgroup.
 hipError_t launch_elbo_split(const ElboParams& p, int at, int irt, bool grad, int nq, int grid, hipStream_t s) {
+    if (at <= 2) {
+        if (irt == 1) return grad ? launch_split_nq<2, 1, true>(p, nq, grid, s) : launch_split_nq<2, 1, false>(p, nq, grid, s);
+        return grad ? launch_split_nq<2, 2, true>(p, nq, grid, s) : launch_split_nq<2, 2, false>(p, nq, grid, s);
+    }
     if (at == 4) {
         if (irt == 1) return grad ? launch_split_nq<4, 1, true>(p, nq, grid, s) : launch_split_nq<4, 1, false>(p, nq, grid, s);
         return grad ? launch_split_nq<4, 2, true>(p, nq, grid, s) : launch_split_nq<4, 2, false>(p, nq, grid, s);
