@@ -182,6 +182,13 @@ GENERAL_SHAPES = [
     (2, 3, 65, 257, 0.1, False, 2),
     (3, 1, 80, 1000, 0.1, True, 4),
     (1, 2, 30, 64, 0.0, False, 1),
+    # planar flows inside the row-split kernel (192 <= I <= 1024, I % 4 == 0)
+    (2, 1, 100, 1000, 0.2, False, 4),
+    (2, 8, 77, 1000, 0.1, False, 2),
+    (3, 2, 50, 256, 0.1, False, 3),
+    (1, 4, 33, 600, 0.0, False, 8),
+    (3, 5, 21, 1024, 0.3, False, 1),
+    (2, 3, 130, 196, 0.1, False, 4),
 ]
 
 

@@ -69,7 +69,13 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->D = item_feat_dim(d->irt_model, A);
     pl->DP = prepped_item_width(d->irt_model, pl->AT);
     pl->n_tiles = (d->num_person + kTilePersons - 1) / kTilePersons;
-    pl->general = d->posterior == VIBO_POSTERIOR_CONDITIONAL || d->n_flows > 0 || I > 1024;
+    // wave-per-person kernel: conditional posterior, > 1024 items; planar flows only when the row-split kernel
+    // cannot take the launch (ragged / unaligned rows, int64 mask, < 192 items)
+    pl->general = d->posterior == VIBO_POSTERIOR_CONDITIONAL || I > 1024;
+    const bool split_shape = I >= 192 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
+    if (d->n_flows > 0 && !split_shape) pl->general = true;
+    pl->row_ok = false;
+    pl->split_ok = false;
     if (pl->general) {
         pl->nblk = 0;
         pl->lds_main = 0;
@@ -110,19 +116,22 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     if (nblk > pl->n_tiles) nblk = pl->n_tiles;
     pl->nblk = nblk;
     // wave-per-row kernel (A <= 2, 1PL/2PL, 192 <= I <= 1024): 4 workgroups of 4 waves per CU
-    pl->row_ok = A <= 2 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0);
+    pl->row_ok = A <= 2 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0) && d->n_flows == 0;
     pl->row_nblk = g_num_cu * 2;          // 16 items x (params + grads) per lane: 2 workgroups (8 waves) per CU
     if (pl->row_nblk > (d->num_person + 3) / 4) pl->row_nblk = (d->num_person + 3) / 4;
-    // row-split kernel (1PL/2PL, 192 <= I <= 1024, u8 / no mask): NQ waves share a row, 8 waves per CU.
+    // row-split kernel (192 <= I <= 1024, u8 / no mask): nq waves share a row, 8 waves per CU.
     // Preferred over the wave-per-row kernel (1.03 vs 1.10 ms at A = 1, 1.03 vs 1.49 ms at A = 2 on 1M x 1k),
     // which stays for int64 masks.
-    pl->split_ok = d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
+    pl->split_ok = split_shape;
     pl->split_nq = (I + 255) / 256;
-    if (pl->split_ok && pl->AT == 1) {       // the row-split kernel's narrowest template is 2 wide
-        pl->AT = 2;
-        pl->DP = prepped_item_width(d->irt_model, 2);
+    if (pl->split_ok) {       // the row-split kernel's narrowest template is 2 wide (4 for 3PL)
+        const int at_min = d->irt_model == 3 ? 4 : 2;
+        if (pl->AT < at_min) {
+            pl->AT = at_min;
+            pl->DP = prepped_item_width(d->irt_model, at_min);
+        }
     }
-    pl->split_nblk = g_num_cu * (8 / pl->split_nq);
+    pl->split_nblk = g_num_cu * ((d->want_grad ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
     if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
@@ -347,8 +356,12 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     if ((uintptr_t)workspace & 255) return fail(-7, "workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int I = d->num_item, A = d->ability_dim;
+    // 16-byte row loads need aligned rows
+    bool vec = (I % 4 == 0) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
+    if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
+    if (d->mask_dtype == VIBO_MASK_I64) vec = vec && (d->mask_row_stride % 2 == 0) && (((uintptr_t)mask & 15) == 0);
 
-    if (pl.general) {
+    if (pl.general || (d->n_flows > 0 && !(pl.split_ok && vec))) {
         const size_t n_table = (size_t)(d->posterior == VIBO_POSTERIOR_CONDITIONAL ? 2 * I * 2 * A : 2 * 2 * A);
         const size_t n_flow = (size_t)d->n_flows * (2 * A + 1);
         hipError_t ge = hipMemsetAsync(workspace, 0, 256, s);
@@ -392,17 +405,17 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     p.B = d->num_person; p.I = I; p.A = A; p.D = pl.D; p.DP = pl.DP;
     p.n_tiles = pl.n_tiles; p.lds_stride = stride; p.lds_main = pl.lds_main;
     p.mask_dtype = d->mask_dtype; p.missing_mode = d->missing_mode; p.reg_mode = d->reg_mode;
+    p.flow = flow; p.ability_k = ability_k; p.ability_ladj = ability_ladj; p.n_flows = d->n_flows;
     p.lay = pl.lay;
-    bool vec = (I % 4 == 0) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
-    if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
-    if (d->mask_dtype == VIBO_MASK_I64) vec = vec && (d->mask_row_stride % 2 == 0) && (((uintptr_t)mask & 15) == 0);
     p.vec_ok = vec ? 1 : 0;
 
     const bool grad = d->want_grad != 0;
     int nblk_used = pl.nblk;
     if (pl.split_ok && vec) {
         nblk_used = pl.split_nblk;
-        e = launch_elbo_split(p, pl.AT, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
+        e = pl.AT <= 2   ? launch_elbo_split_a2(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
+            : pl.AT == 4 ? launch_elbo_split_a4(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
+                         : launch_elbo_split_a8(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
     } else if (pl.row_ok && vec && pl.AT == A) {
         nblk_used = pl.row_nblk;
         e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);

@@ -21,7 +21,10 @@ hipError_t launch_elbo_a8(const ElboParams& p, int irt, bool grad, const LaunchG
 // wave-per-row kernel (vibo_row_kernel.hip): A in {1,2}, 1PL/2PL, I <= 1024, 16-byte aligned rows
 hipError_t launch_elbo_rows(const ElboParams& p, int irt, bool grad, int grid, hipStream_t s);
 
-// row-split kernel (vibo_split_kernel.hip): ability_dim 3..8 (at = 4 | 8), 1PL/2PL, I <= 1024, nq = ceil(I / 256)
-hipError_t launch_elbo_split(const ElboParams& p, int at, int irt, bool grad, int nq, int grid, hipStream_t s);
+// row-split kernel (vibo_split_kernel.hpp): template ability width 2 / 4 / 8, 1PL/2PL/3PL, optional planar flows,
+// I <= 1024, I % 4 == 0, 16-byte aligned rows, mask u8 or none; nq = ceil(I / 256) waves per workgroup
+hipError_t launch_elbo_split_a2(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+hipError_t launch_elbo_split_a4(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+hipError_t launch_elbo_split_a8(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
 
 }  // namespace vibo

@@ -55,10 +55,13 @@ struct ElboParams {
     float* ability_logvar;
     float* ability;
     float* partial;           // [nblk][stride]
+    const float* flow;        // [n_flows][2A+1] = uhat | w | b   (row-split kernel only)
+    float* ability_k;         // [B][A] sample after the flows     (row-split kernel, n_flows > 0)
+    float* ability_ladj;      // [B] sum of log|det| of the flows  (row-split kernel, n_flows > 0)
     long long resp_stride, mask_stride;
     int B, I, A, D, DP;
     int n_tiles, lds_stride, lds_main;
-    int mask_dtype, missing_mode, reg_mode, vec_ok;
+    int mask_dtype, missing_mode, reg_mode, vec_ok, n_flows;
     PartialLayout lay;
 };
 
