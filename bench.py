@@ -55,6 +55,7 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=8)
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
     ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
+    ap.add_argument('--rng', choices=['native', 'torch'], default='native', help='reparameterisation noise: vibo_fill_normal (Philox, in the C ABI) or torch.randn')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
     ap.add_argument('--force-dist', action='store_true', help='create the process group even for one rank (tests the RCCL path)')
     return ap.parse_args()
@@ -152,7 +153,7 @@ def main():
             opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=not args.no_graph, fused=True)
         else:
             from vibo_amd.trainer import FusedTrainer
-            trainer = FusedTrainer(model, lr=args.lr)
+            trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)
 
         # HIP events around the native call, on the stream it is launched on
         events = []
@@ -264,7 +265,7 @@ def main():
         A2 = args.also_ability_dim
         m2 = measure(A2)
         b2 = 5.0 + 12.0 * A2 / I
-        also = {'workload': f'same, ability_dim={A2} (BASELINE configs[1] shape at 1M persons; wave-per-row kernel)',
+        also = {'workload': f'same, ability_dim={A2} (BASELINE configs[1] shape at 1M persons)',
                 'value': float(P) * I * args.steps * world / m2['dt'], 'ms_per_step': m2['dt'] / args.steps * 1e3,
                 'kernel_ms': m2['kern_ms'], 'roofline_achieved_GBps': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9,
                 'roofline_frac': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 8000.0}
@@ -289,10 +290,11 @@ def main():
                                    f'unconditional posterior, full-shard minibatch',
                        'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': 'hipGraph replay' if m['graph'] else 'eager',
                        'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',
+                       'noise': 'torch.randn' if (args.torch_optimizer or args.eval_only or args.rng == 'torch') else 'vibo_fill_normal (Philox4x32-10)',
                        'final_loss_per_term': final_loss / (P * I * world)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_note': traffic_note,
-                         'kernel': ('vibo::row_kernel' if A <= 2 and irt <= 2 else 'vibo::elbo_kernel') + ' (+ item_prep, finalize helpers inside the timed events)',
+                         'kernel': 'vibo::split_kernel (+ item_prep, finalize helpers inside the timed events)',
                          'kernel_ms': kern_ms, 'bytes_per_term': bytes_per_term},
         }
         if also is not None:

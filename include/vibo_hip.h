@@ -193,6 +193,15 @@ int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, c
                         float* item_mu, float* item_logvar, float* item_m, float* item_v, float* loss_out,
                         void* stream);
 
+/*
+ * Standard-normal fill for the reparameterisation noise (replaces the torch.randn_like calls of utils.py:85-88 as
+ * used at models.py:361,368 when the caller does not need PyTorch's generator stream):
+ *     out[i] ~ N(0,1),  Philox4x32-10 keyed by `seed`, counter (i / 4, *step_count, stream_id), Box-Muller.
+ * The step number is read on the device, so a captured hipGraph draws fresh noise on every replay (the prologue
+ * increments step_count).  Deterministic: same (seed, step, stream_id, i) -> same value.
+ */
+int vibo_fill_normal(float* out, int64_t n, uint64_t seed, const int32_t* step_count, uint32_t stream_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,3 +38,48 @@ def test_fused_trainer_matches_torch_adam(cls, A, I, B, beta):
     for (k, a), (_, b) in zip(ref.state_dict().items(), fus.state_dict().items()):
         assert (a - b).abs().max() < 2e-5, k
     assert int(trainer.step_count) == 4
+
+
+@pytest.mark.gpu
+def test_fill_normal_moments_determinism_and_step_dependence():
+    """vibo_fill_normal: N(0,1) moments, same (seed, step, stream) -> same draw, new step -> new draw."""
+    import ctypes
+    from vibo_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    n = 4_000_003                                    # not a multiple of 4: tail path
+    step = torch.zeros((), dtype=torch.int32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def draw(seed, stream_id, out=None):
+        out = torch.empty(n, device=dev) if out is None else out
+        _lib.check(lib.vibo_fill_normal(ops._ptr(out), n, seed, ops._ptr(step), stream_id, stream), 'vibo_fill_normal')
+        return out
+
+    a = draw(7, 0)
+    assert torch.isfinite(a).all()
+    assert abs(float(a.mean())) < 3e-3 and abs(float(a.std()) - 1.0) < 3e-3
+    assert abs(float((a ** 3).mean())) < 1e-2 and abs(float((a ** 4).mean()) - 3.0) < 3e-2
+    assert abs(float((a[:-1] * a[1:]).mean())) < 3e-3            # neighbouring draws uncorrelated
+    assert torch.equal(a, draw(7, 0))
+    assert not torch.equal(a, draw(8, 0)) and not torch.equal(a, draw(7, 1))
+    step.add_(1)
+    assert not torch.equal(a, draw(7, 0))
+
+
+@pytest.mark.gpu
+def test_fused_trainer_native_rng_trains():
+    from vibo_amd.trainer import FusedTrainer
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    B, I, A = 4096, 256, 2
+    model = VIBO_2PL(A, I, hidden_dim=16, ability_merge='product').to(dev)
+    theta = torch.randn(B, A, device=dev)
+    a_ = torch.randn(I, A, device=dev)
+    logits = -(theta @ a_.t()) + torch.randn(I, device=dev)
+    resp = (torch.rand(B, I, device=dev) < torch.sigmoid(logits)).float()
+    mask = torch.ones(B, I, dtype=torch.bool, device=dev)
+    tr = FusedTrainer(model, lr=1e-2, rng='native', seed=3)
+    losses = [float(tr.step(resp, mask, beta=1.0)) for _ in range(60)]
+    assert all(l == l for l in losses)
+    assert sum(losses[-5:]) < 0.9 * sum(losses[:5])

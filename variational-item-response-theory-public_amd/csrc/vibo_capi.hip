@@ -181,19 +181,19 @@ __global__ void item_prep_kernel(const float* __restrict__ item, float* __restri
 // ---------------------------------------------------------------------------
 // finalize: fixed-order sum of the per-block partial records (fp64 accumulate)
 // ---------------------------------------------------------------------------
-__global__ void finalize_kernel(const FinalizeParams f) {
+constexpr int kFinSlices = 16;       // slices of the block list per output (1024 threads = 64 outputs x 16 slices)
+__global__ __launch_bounds__(64 * kFinSlices) void finalize_kernel(const FinalizeParams f) {
     // element e of the logical output vector: [0,8) scalars | table grads | flow grads | item grads
     const int n_tab = 8 * f.A;
     const int n_flow = 2 * f.n_flows * (2 * f.A + 1);
     const int n_item = f.I * f.D;
     const int n_out = 8 + (f.want_grad ? n_tab + n_flow + n_item : 0);
-    // 64 outputs x 4 slices of blocks per workgroup
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
-    __shared__ double part[4][64];
+    __shared__ double part[kFinSlices][64];
     double acc = 0.0;
-    int src = -1;
     if (e < n_out) {
+        int src;
         if (e < 8 + n_tab + n_flow) {
             src = e;   // same offsets in the partial record (off_table = 8, off_flow = 8 + 8A)
         } else {
@@ -201,12 +201,15 @@ __global__ void finalize_kernel(const FinalizeParams f) {
             const int i = k / f.D, dd = k % f.D;
             src = f.lay.off_item + dd * f.lay.i_pad + i;
         }
-        for (int b = slice; b < f.nblk; b += 4) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
+        // fixed order: slice s sums blocks s, s+16, ... in fp64, then the slices are summed in order
+        for (int b = slice; b < f.nblk; b += kFinSlices) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
     }
     part[slice][lane] = acc;
     __syncthreads();
     if (slice == 0 && e < n_out) {
-        const double t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        double t = 0.0;
+#pragma unroll
+        for (int s = 0; s < kFinSlices; ++s) t += part[s][lane];
         if (e < 8) {
             // partial scalars: 0 ll, 1 kl, 2 logq0, 3 logp, 4 ladj, 5 nobs
             part[0][lane] = t;
@@ -435,7 +438,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     f.nblk = nblk_used; f.I = I; f.A = A; f.D = pl.D; f.n_flows = d->n_flows; f.reg_mode = d->reg_mode;
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
     const int n_out = 8 + (grad ? 8 * A + 2 * d->n_flows * (2 * A + 1) + I * pl.D : 0);
-    hipLaunchKernelGGL(finalize_kernel, dim3((n_out + 63) / 64), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(finalize_kernel, dim3((n_out + 63) / 64), dim3(64 * kFinSlices), 0, s, f);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "finalize launch");
     return 0;

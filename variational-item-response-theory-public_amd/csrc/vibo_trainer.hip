@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
         for (int t = tid; t < 2 * H; t += 256) {
             const int r = t / H, j = t % H;
             float a = P[o.b1 + j];
+#pragma unroll 16
             for (int k = 0; k < H; ++k) a = fmaf(P[o.w1 + j * H + k], h1[r][k], a);
             h2[r][j] = elu(a);
         }
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
         for (int t = tid; t < 2 * O; t += 256) {
             const int r = t / O, q = t % O;
             float a = P[o.b2 + q];
+#pragma unroll 16
             for (int k = 0; k < H; ++k) a = fmaf(P[o.w2 + q * H + k], h2[r][k], a);
             table[r * O + q] = a;
         }
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
         for (int k = tid; k < 2 * H; k += 256) {
             const int r = k / H, j = k % H;
             float a = 0.f;
-            for (int q = 0; q < O; ++q) a = fmaf(P[o.w2 + q * H + j], gout[r][q], a);
+#pragma unroll 16
+            for (int q = 0; q < O; ++q) a = fmaf(P[o.w2 + q * H + j], gout[r][q], a);      // 16 loads in flight
             const float h = h2[r][j];
             gh2[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
         }
@@ -116,32 +119,53 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
         for (int k = tid; k < 2 * H; k += 256) {
             const int r = k / H, j = k % H;
             float a = 0.f;
+#pragma unroll 16
             for (int q = 0; q < H; ++q) a = fmaf(P[o.w1 + q * H + j], gh2[r][q], a);
             const float h = h1[r][j];
             gh1[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
         }
         __syncthreads();      // all reads of the OLD weights are done: parameters may now be updated in place
-        for (int k = tid; k < o.total; k += 256) {
-            float g;
-            if (k < o.b0) {                         // W0[j]: input of row r is r
-                g = gh1[1][k - o.w0];
-            } else if (k < o.w1) {
-                const int j = k - o.b0;
-                g = gh1[0][j] + gh1[1][j];
-            } else if (k < o.b1) {
-                const int j = (k - o.w1) / H, q = (k - o.w1) % H;
-                g = gh2[0][j] * h1[0][q] + gh2[1][j] * h1[1][q];
-            } else if (k < o.w2) {
-                const int j = k - o.b1;
-                g = gh2[0][j] + gh2[1][j];
-            } else if (k < o.b2) {
-                const int q = (k - o.w2) / H, j = (k - o.w2) % H;
-                g = gout[0][q] * h2[0][j] + gout[1][q] * h2[1][j];
-            } else {
-                const int q = k - o.b2;
-                g = gout[0][q] + gout[1][q];
+        // Adam over the MLP parameters: 8 independent elements per thread and pass, all loads issued before the
+        // first store (P, M, V are not restrict-qualified, so a store would otherwise fence the next loads)
+        constexpr int U = 8;
+        for (int k0 = tid; k0 < o.total; k0 += 256 * U) {
+            float pv[U], mv[U], vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                const bool ok = k < o.total;
+                pv[u] = ok ? P[k] : 0.f;
+                mv[u] = ok ? M[k] : 0.f;
+                vv[u] = ok ? V[k] : 0.f;
             }
-            adam_update(P[k], M[k], V[k], g, lr, bc1, bc2_sqrt);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                if (k >= o.total) continue;
+                float g;
+                if (k < o.b0) {                         // W0[j]: input of row r is r
+                    g = gh1[1][k - o.w0];
+                } else if (k < o.w1) {
+                    const int j = k - o.b0;
+                    g = gh1[0][j] + gh1[1][j];
+                } else if (k < o.b1) {
+                    const int j = (k - o.w1) / H, q = (k - o.w1) % H;
+                    g = gh2[0][j] * h1[0][q] + gh2[1][j] * h1[1][q];
+                } else if (k < o.w2) {
+                    const int j = k - o.b1;
+                    g = gh2[0][j] + gh2[1][j];
+                } else if (k < o.b2) {
+                    const int q = (k - o.w2) / H, j = (k - o.w2) % H;
+                    g = gout[0][q] * h2[0][j] + gout[1][q] * h2[1][j];
+                } else {
+                    const int q = k - o.b2;
+                    g = gout[0][q] + gout[1][q];
+                }
+                adam_update(pv[u], mv[u], vv[u], g, lr, bc1, bc2_sqrt);
+                P[k] = pv[u];
+                M[k] = mv[u];
+                V[k] = vv[u];
+            }
         }
         return;
     }
@@ -159,9 +183,54 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
     }
 }
 
+// ---------------------------------------------------------------------------
+// N(0,1) fill: Philox4x32-10 (Salmon et al. 2011) + Box-Muller, 4 normals per counter
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t k0, const uint32_t k1) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+}
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ out, long long n, uint32_t seed_lo, uint32_t seed_hi,
+                                                          const int32_t* __restrict__ step_count, uint32_t stream_id) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;        // group of 4 outputs
+    if (4 * g >= n) return;
+    uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(*step_count), stream_id};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    // uniforms in (0, 1]; v_sin / v_cos take their argument in revolutions
+    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * kLn2 * fast_log2(u0)), r1 = sqrtf(-2.0f * kLn2 * fast_log2(u2));
+    const float4 z = float4{r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
+                            r1 * __builtin_amdgcn_sinf(u3)};
+    if (4 * g + 3 < n && (((uintptr_t)out & 15) == 0)) {
+        reinterpret_cast<float4*>(out)[g] = z;
+    } else {
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+        for (int k = 0; k < 4; ++k)
+            if (4 * g + k < n) out[4 * g + k] = zz[k];
+    }
+}
+
 }  // namespace vibo
 
 using namespace vibo;
+
+extern "C" int vibo_fill_normal(float* out, int64_t n, uint64_t seed, const int32_t* step_count, uint32_t stream_id, void* stream) {
+    if (!out || !step_count || n < 0) return -5;
+    if (n == 0) return 0;
+    const long long groups = (n + 3) / 4;
+    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       (long long)n, (uint32_t)seed, (uint32_t)(seed >> 32), step_count, stream_id);
+    return (int)hipGetLastError();
+}
 
 static int item_dim_of(const vibo_desc* d) { return d->irt_model == 1 ? 1 : (d->irt_model == 2 ? d->ability_dim + 1 : d->ability_dim + 2); }
 

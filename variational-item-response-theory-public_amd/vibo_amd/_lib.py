@@ -43,7 +43,7 @@ class ViboDesc(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
-                    'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue')
+                    'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal')
 
 _lib = None
 
@@ -84,6 +84,8 @@ def load():
     lib.vibo_train_prologue.argtypes = [dp, ctypes.c_int] + [fp] * 8 + [vp, vp]
     lib.vibo_train_epilogue.restype = ctypes.c_int
     lib.vibo_train_epilogue.argtypes = [dp, ctypes.c_int] + [fp] * 6 + [vp] + [fp] * 8 + [vp]
+    lib.vibo_fill_normal.restype = ctypes.c_int
+    lib.vibo_fill_normal.argtypes = [fp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_uint32, vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

@@ -224,6 +224,7 @@ class VIBO_1PL(nn.Module):
         kernel's flat [scalars | grads] buffer in place.  Item noise must be
         identical on every rank, ability noise must differ: dedicated generators."""
         self._reducer = reducer
+        self._shard_rank = int(rank)
         dev = self.item_encoder.mu_lookup.weight.device
         self._item_gen = torch.Generator(device=dev).manual_seed(int(seed))
         self._ability_gen = torch.Generator(device=dev).manual_seed(int(seed) + 1 + int(rank))

@@ -4,7 +4,7 @@ reference loop (vibo.py:243-268) as ~7 kernel launches instead of ~80.
     trainer = FusedTrainer(model, lr=5e-3)
     loss = trainer.step(response, mask, beta=1.0, row_index=rows)      # device scalar, parameters updated in place
 
-What runs: torch.randn (item eps) -> vibo_train_prologue (item sample, item KL, encoder table) -> torch.randn
+What runs: torch.randn or vibo_fill_normal (item eps) -> vibo_train_prologue (item sample, item KL, encoder table) -> torch.randn
 (ability eps) -> vibo_elbo_fwd_bwd (fused ELBO forward+backward) -> [one all-reduce when person-sharded] ->
 vibo_train_epilogue (loss, encoder-MLP backward, item backward, Adam).  Same arithmetic as the PyTorch path
 (tests/test_gpu_trainer.py compares parameters after several steps); `.grad` fields are not populated.
@@ -18,7 +18,7 @@ from . import _lib, ops
 
 
 class FusedTrainer:
-    def __init__(self, model, lr=5e-3):
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0):
         if model.conditional_posterior or model.n_norm_flows > 0:
             raise NotImplementedError('FusedTrainer covers the unconditional posterior without flows; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
@@ -55,6 +55,14 @@ class FusedTrainer:
         self.kl_parts = torch.empty((n_item + 255) // 256, device=dev)
         self.loss = torch.zeros((), device=dev)
         self.last = None                      # RawElbo of the last step (posterior outputs, scalars)
+        # (person-sharded: item noise is the same on every rank, ability noise uses stream 1 + rank)
+        # reparameterisation noise: 'torch' = torch.randn on the model's generators (the reference's stream for a
+        # given seed), 'native' = vibo_fill_normal (Philox4x32-10 keyed by `seed`, ~5x faster on [1M, 8])
+        if rng not in ('torch', 'native'):
+            raise ValueError("rng must be 'torch' or 'native'")
+        self.rng, self.seed = rng, int(seed)
+        self._eps_item = torch.empty_like(self.item_mu) if rng == 'native' else None
+        self._eps_ab = None
 
     def set_beta(self, beta):
         """KL weight (vibo.py:223-230).  A device scalar: update it between graph replays when annealing."""
@@ -76,12 +84,22 @@ class FusedTrainer:
         d = ops._make_desc(spec, B, I, code, _lib.REG_KL, True, response.stride(0), mask.stride(0) if mask is not None else 0)
         p = ops._ptr
         # reference draw order: item eps, then ability eps (models.py:361,368)
-        eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
+        if self.rng == 'native':
+            eps_item = self._eps_item
+            _lib.check(lib.vibo_fill_normal(p(eps_item), eps_item.numel(), self.seed, p(self.step_count), 0, stream), 'vibo_fill_normal')
+        else:
+            eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
         rc = lib.vibo_train_prologue(ctypes.byref(d), self.hidden, p(self.mlp_flat), p(self.item_mu), p(self.item_lv),
                                      p(eps_item), p(self.item_feat), p(self.table), p(self.saved_h), p(self.kl_parts),
                                      p(self.step_count), stream)
         _lib.check(rc, 'vibo_train_prologue')
-        eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
+        if self.rng == 'native':
+            if self._eps_ab is None or self._eps_ab.shape[0] != B:
+                self._eps_ab = torch.empty(B, model.ability_dim, device=dev)
+            eps_ab = self._eps_ab
+            _lib.check(lib.vibo_fill_normal(p(eps_ab), eps_ab.numel(), self.seed, p(self.step_count), 1 + getattr(model, '_shard_rank', 0), stream), 'vibo_fill_normal')
+        else:
+            eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
         raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None,
                                    _lib.REG_KL, True, B)
         if model._reducer is not None:
