@@ -189,6 +189,12 @@ GENERAL_SHAPES = [
     (1, 4, 33, 600, 0.0, False, 8),
     (3, 5, 21, 1024, 0.3, False, 1),
     (2, 3, 130, 196, 0.1, False, 4),
+    # more than 1024 items, unconditional: row-count pass + one row-split launch per 1024-item panel
+    (2, 1, 100, 2500, 0.2, False, 4),
+    (1, 3, 50, 1028, 0.1, False, 0),
+    (3, 8, 30, 3000, 0.1, False, 0),
+    (2, 2, 9, 10000, 0.3, False, 2),
+    (2, 5, 200, 4096, 0.0, False, 0),
 ]
 
 

@@ -55,6 +55,8 @@ struct Plan {
     int row_nblk;
     bool split_ok;            // row-split register kernel (ability_dim 3..8) is applicable (subject to alignment)
     int split_nq, split_nblk;
+    int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
+    size_t off_cnt;           // panel mode: per-person packed counts of the whole row
     int AT, D, DP, n_tiles, nblk, lds_main;
     LaunchGeom geom;
     PartialLayout lay;
@@ -76,6 +78,35 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     if (d->n_flows > 0 && !split_shape) pl->general = true;
     pl->row_ok = false;
     pl->split_ok = false;
+    pl->panels = 0;
+    if (d->posterior == VIBO_POSTERIOR_UNCONDITIONAL && I > 1024 && I <= 65535 && (I % 4 == 0) &&
+        d->mask_dtype != VIBO_MASK_I64) {
+        // panel mode: a row-count pass, then one row-split launch per 1024 items (the backward is linear in
+        // d LL/d theta, so the panels backpropagate their partial sums independently); the wave-per-person kernel
+        // remains the fallback for unaligned rows (decided at launch)
+        if (g_num_cu == 0) {
+            int dev = 0, n = 0;
+            g_num_cu = (hipGetDevice(&dev) == hipSuccess &&
+                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        pl->panels = (I + 1023) / 1024;
+        const int at_min = d->irt_model == 3 ? 4 : 2;
+        if (pl->AT < at_min) pl->AT = at_min;
+        pl->DP = prepped_item_width(d->irt_model, pl->AT);
+        pl->split_nq = 4;
+        pl->split_nblk = g_num_cu * (d->want_grad ? 2 : 3);
+        if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
+        pl->nblk = 0;
+        pl->lds_main = 0;
+        pl->lay = partial_layout(A, pl->D, 1024, d->n_flows);
+        pl->off_item_prep = 0;
+        const size_t prep_bytes = ((size_t)((I + 15) & ~15) * pl->DP * 4 + 255) & ~(size_t)255;
+        pl->off_cnt = prep_bytes;
+        pl->off_partial = prep_bytes + (((size_t)d->num_person * 4 + 255) & ~(size_t)255);
+        pl->total_bytes = pl->off_partial + (size_t)pl->panels * pl->split_nblk * pl->lay.stride * 4 + 256;
+        pl->general = false;
+        return 16;
+    }
     if (pl->general) {
         pl->nblk = 0;
         pl->lds_main = 0;
@@ -179,6 +210,43 @@ __global__ void item_prep_kernel(const float* __restrict__ item, float* __restri
 }
 
 // ---------------------------------------------------------------------------
+// panel mode: packed counts (n_correct << 16 | n_observed) of every person row, one wave per row
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict__ response, const void* __restrict__ mask,
+                                                        const int64_t* __restrict__ row_index, int* __restrict__ cnt,
+                                                        long long resp_stride, long long mask_stride, int B, int I,
+                                                        int mask_dtype) {
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * 4;
+    const int n4 = I >> 2;
+    for (long long row = wave_id; row < B; row += n_waves) {
+        const long long src = row_index ? row_index[row] : row;
+        const float4* rp = reinterpret_cast<const float4*>(response + src * resp_stride);
+        const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(mask) + src * mask_stride);
+        int packed = 0;
+        for (int c0 = lane; c0 < n4; c0 += 256) {          // 4 chunks per lane in flight
+            float4 x[4];
+            uint32_t m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 64 * u;
+                x[u] = float4{0.f, 0.f, 0.f, 0.f};
+                m[u] = 0u;
+                if (c < n4) {
+                    x[u] = rp[c];
+                    m[u] = mask_dtype == 0 ? mp[c] : 0x01010101u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) (void)pack_codes4(x[u], m[u], packed);
+        }
+        const int tot = lane63(wave_sum63(packed));
+        if (lane == 0) cnt[row] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // finalize: fixed-order sum of the per-block partial records (fp64 accumulate)
 // ---------------------------------------------------------------------------
 constexpr int kFinSlices = 16;       // slices of the block list per output (1024 threads = 64 outputs x 16 slices)
@@ -193,16 +261,19 @@ __global__ __launch_bounds__(64 * kFinSlices) void finalize_kernel(const Finaliz
     __shared__ double part[kFinSlices][64];
     double acc = 0.0;
     if (e < n_out) {
-        int src;
+        int src, b0 = 0, b1 = f.nblk;
         if (e < 8 + n_tab + n_flow) {
             src = e;   // same offsets in the partial record (off_table = 8, off_flow = 8 + 8A)
         } else {
             const int k = e - (8 + n_tab + n_flow);
             const int i = k / f.D, dd = k % f.D;
-            src = f.lay.off_item + dd * f.lay.i_pad + i;
+            const int panel = i / f.panel_items;          // panel mode: only this panel's blocks hold item i
+            src = f.lay.off_item + dd * f.lay.i_pad + (i - panel * f.panel_items);
+            b0 = panel * f.bpp;
+            b1 = b0 + f.bpp;
         }
         // fixed order: slice s sums blocks s, s+16, ... in fp64, then the slices are summed in order
-        for (int b = slice; b < f.nblk; b += kFinSlices) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
+        for (int b = b0 + slice; b < b1; b += kFinSlices) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
     }
     part[slice][lane] = acc;
     __syncthreads();
@@ -364,7 +435,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
     if (d->mask_dtype == VIBO_MASK_I64) vec = vec && (d->mask_row_stride % 2 == 0) && (((uintptr_t)mask & 15) == 0);
 
-    if (pl.general || (d->n_flows > 0 && !(pl.split_ok && vec))) {
+    if (pl.general || (d->n_flows > 0 && !(pl.split_ok && vec) && pl.panels == 0) || (pl.panels > 0 && !vec)) {
         const size_t n_table = (size_t)(d->posterior == VIBO_POSTERIOR_CONDITIONAL ? 2 * I * 2 * A : 2 * 2 * A);
         const size_t n_flow = (size_t)d->n_flows * (2 * A + 1);
         hipError_t ge = hipMemsetAsync(workspace, 0, 256, s);
@@ -411,10 +482,33 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     p.flow = flow; p.ability_k = ability_k; p.ability_ladj = ability_ladj; p.n_flows = d->n_flows;
     p.lay = pl.lay;
     p.vec_ok = vec ? 1 : 0;
+    p.row_cnt = nullptr; p.item0 = 0; p.I_total = I; p.primary = 1;
 
     const bool grad = d->want_grad != 0;
     int nblk_used = pl.nblk;
-    if (pl.split_ok && vec) {
+    int panel_items = 1 << 30, bpp = 0;
+    if (pl.panels > 0) {
+        int* cnt = reinterpret_cast<int*>(static_cast<char*>(workspace) + pl.off_cnt);
+        int cgrid = g_num_cu * 8;
+        if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
+        hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
+                           (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
+        e = hipGetLastError();
+        p.row_cnt = cnt;
+        for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
+            p.item0 = pn * 1024;
+            p.I = I - p.item0 < 1024 ? I - p.item0 : 1024;
+            p.primary = pn == 0 ? 1 : 0;
+            p.partial = partial + (size_t)pn * pl.split_nblk * pl.lay.stride;
+            const int nq = (p.I + 255) / 256;
+            e = pl.AT <= 2   ? launch_elbo_split_a2(p, d->irt_model, grad, nq, pl.split_nblk, s)
+                : pl.AT == 4 ? launch_elbo_split_a4(p, d->irt_model, grad, nq, pl.split_nblk, s)
+                             : launch_elbo_split_a8(p, d->irt_model, grad, nq, pl.split_nblk, s);
+        }
+        nblk_used = pl.panels * pl.split_nblk;
+        panel_items = 1024;
+        bpp = pl.split_nblk;
+    } else if (pl.split_ok && vec) {
         nblk_used = pl.split_nblk;
         e = pl.AT <= 2   ? launch_elbo_split_a2(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
             : pl.AT == 4 ? launch_elbo_split_a4(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
@@ -437,6 +531,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     f.grad_flow = grad_flow;
     f.nblk = nblk_used; f.I = I; f.A = A; f.D = pl.D; f.n_flows = d->n_flows; f.reg_mode = d->reg_mode;
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
+    f.panel_items = panel_items; f.bpp = bpp ? bpp : nblk_used;
     const int n_out = 8 + (grad ? 8 * A + 2 * d->n_flows * (2 * A + 1) + I * pl.D : 0);
     hipLaunchKernelGGL(finalize_kernel, dim3((n_out + 63) / 64), dim3(64 * kFinSlices), 0, s, f);
     e = hipGetLastError();

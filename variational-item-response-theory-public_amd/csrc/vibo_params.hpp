@@ -58,6 +58,11 @@ struct ElboParams {
     const float* flow;        // [n_flows][2A+1] = uhat | w | b   (row-split kernel only)
     float* ability_k;         // [B][A] sample after the flows     (row-split kernel, n_flows > 0)
     float* ability_ladj;      // [B] sum of log|det| of the flows  (row-split kernel, n_flows > 0)
+    // panel mode of the row-split kernel (more than 1024 items): one launch per panel of <= 1024 items
+    const int* row_cnt;       // [B] packed counts (n1 << 16 | nobs) over the WHOLE row, or null (single panel)
+    int item0;                // first item of this panel
+    int I_total;              // items of the whole row (PoE prior experts, nmiss)
+    int primary;              // 1: this launch writes the per-person outputs and owns the KL / REG terms
     long long resp_stride, mask_stride;
     int B, I, A, D, DP;
     int n_tiles, lds_stride, lds_main;
@@ -72,6 +77,7 @@ struct FinalizeParams {
     float* grad_item;
     float* grad_flow;
     int nblk, I, A, D, n_flows, reg_mode, irt, want_grad;
+    int panel_items, bpp;     // item grads of item i live in blocks [i / panel_items * bpp, +bpp) (panel mode)
     PartialLayout lay;
 };
 

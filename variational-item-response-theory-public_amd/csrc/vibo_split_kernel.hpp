@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
     float gs[4], om[4], acc_g[4];       // 3PL: guess, 1 - guess, d / d guess-logit
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float* ir = p.item_prep + (size_t)(4 * chunk + j) * p.DP;
+        const float* ir = p.item_prep + (size_t)(p.item0 + 4 * chunk + j) * p.DP;
 #pragma unroll
         for (int a = 0; a < AT; ++a) {
             na2[j][a >> 1][a & 1] = chunk_ok ? ir[a] : 0.f;
@@ -222,9 +222,9 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
             m[r] = 0u;
             if (row < p.B && chunk_ok) {
                 const long long src = p.row_index ? p.row_index[row] : row;
-                x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride)[chunk];
+                x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
                 if (p.mask_dtype == 0)
-                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride)[chunk];
+                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
                 else
                     m[r] = 0x01010101u;
             }
@@ -260,13 +260,17 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
         __syncthreads();
 
         // ---- product of experts + reparameterised sample for (person er, dim ed)  (models.py:596-629) ----
-        int cnt = 0;
-#pragma unroll
-        for (int w = 0; w < (NQT > 0 ? NQT : 4); ++w)
-            if (w < nq) cnt += wls[w].cntp[er];
-        const float n1 = (float)(cnt >> 16), nobs = (float)(cnt & 0xffff);
-        const float n0 = nobs - n1, nmiss = (float)I - nobs;
         const bool live = e_ok && (row0 + er) < p.B;
+        int cnt = 0;
+        if (p.row_cnt) {                    // panel mode: counts of the whole row from row_count_kernel
+            cnt = live ? p.row_cnt[row0 + er] : 0;
+        } else {
+#pragma unroll
+            for (int w = 0; w < (NQT > 0 ? NQT : 4); ++w)
+                if (w < nq) cnt += wls[w].cntp[er];
+        }
+        const float n1 = (float)(cnt >> 16), nobs = (float)(cnt & 0xffff);
+        const float n0 = nobs - n1, nmiss = (float)p.I_total - nobs;
         float lam = n0 * tau0 + n1 * tau1;
         if (p.missing_mode == 0) lam += nmiss * (1.0f / (1.0f + kPoeEps));
         if (!live) lam = 1.0f;              // rows past the end / padded dims: keep the arithmetic finite
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                 }
             }
         }
-        if (q == 0 && live) {
+        if (q == 0 && live && p.primary) {
             const long long o = (row0 + er) * A + ed;
             const float alv = -kLn2 * fast_log2(lam);
             p.ability_mu[o] = amu;
@@ -469,7 +473,10 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                 for (int w = 0; w < (NQT > 0 ? NQT : 4); ++w)
                     if (w < nq) g0 += wls[w].gthp[lane & (NE - 1)];
                 float gz0 = live ? g0 * kLn2 : 0.f;                                    // d LL  / d theta_K
-                float gz1 = (live && p.reg_mode != 0) ? thv : 0.f;                     // d REG / d theta_K (-log p)
+                // the backward is linear in d LL/d theta, so every panel backpropagates its own partial sum; the
+                // regulariser's own terms (set 1) belong to the primary launch only
+                const bool reg_on = live && p.primary;
+                float gz1 = (reg_on && p.reg_mode != 0) ? thv : 0.f;                   // d REG / d theta_K (-log p)
                 if constexpr (FLOWS) {
 #pragma unroll
                     for (int f = kMF - 1; f >= 0; --f) {
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                             const float t = fa.st[f][0][lane], psi = fa.st[f][1][lane], zin = fa.st[f][2][lane];
                             const float omt = 1.0f - t * t;
                             const float unit = ((psi >= 0.f) ? 1.0f : -1.0f) / (fabsf(psi) + 1e-8f);
-                            const float lv = live ? 1.0f : 0.f;
+                            const float lv = live ? 1.0f : 0.f, lv1 = reg_on ? 1.0f : 0.f;
                             // set 0 (LL): no log-det term
                             {
                                 const float g_t = group_sum<AT>(gz0 * ud);
@@ -495,10 +502,10 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                                 const float g_t = dl_dpsi * (-2.0f * t * cwu) + group_sum<AT>(gz1 * ud);
                                 const float g_c = dl_dpsi * omt;
                                 const float g_a = g_t * omt;
-                                fa.a[1][f][0][lane] += lv * (gz1 * t + g_c * wd);
-                                fa.a[1][f][1][lane] += lv * (g_a * zin + g_c * ud);
-                                fa.a[1][f][2][lane] += lv * g_a;
-                                gz1 = fmaf(g_a, wd, gz1) * lv;
+                                fa.a[1][f][0][lane] += lv1 * (gz1 * t + g_c * wd);
+                                fa.a[1][f][1][lane] += lv1 * (g_a * zin + g_c * ud);
+                                fa.a[1][f][2][lane] += lv1 * g_a;
+                                gz1 = fmaf(g_a, wd, gz1) * lv1;
                             }
                         }
                     }
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                     gmu[1] = gz1;
                     glv[1] = gz1 * h - 0.5f;
                 }
-                if (!live) { gmu[1] = 0.f; glv[1] = 0.f; }
+                if (!reg_on) { gmu[1] = 0.f; glv[1] = 0.f; }
                 const float nn[2] = {n0, n1};
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
