@@ -195,6 +195,13 @@ GENERAL_SHAPES = [
     (3, 8, 30, 3000, 0.1, False, 0),
     (2, 2, 9, 10000, 0.3, False, 2),
     (2, 5, 200, 4096, 0.0, False, 0),
+    # conditional posterior through cond_pre / row-split / cond_post (ability_dim <= 4, 192 <= I, I % 4 == 0)
+    (2, 2, 130, 1000, 0.2, True, 0),
+    (2, 4, 33, 600, 0.1, True, 2),
+    (3, 1, 20, 2500, 0.1, True, 4),
+    (1, 1, 50, 192, 0.0, True, 0),
+    (2, 3, 41, 1024, 0.3, True, 0),
+    (3, 1, 9, 10000, 0.2, True, 4),
 ]
 
 

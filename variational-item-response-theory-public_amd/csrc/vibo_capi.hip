@@ -8,6 +8,7 @@
 
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
+#include "vibo_cond.hpp"
 #include "vibo_general.hpp"
 #include "vibo_launch.hpp"
 #include "vibo_params.hpp"
@@ -57,6 +58,9 @@ struct Plan {
     int split_nq, split_nblk;
     int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
     size_t off_cnt;           // panel mode: per-person packed counts of the whole row
+    bool cond;                // panel mode with the conditional posterior: cond_pre / split / cond_post per panel
+    size_t off_pre, off_coef, off_cpart;
+    int cond_rec;             // floats per cond_post workgroup record
     int AT, D, DP, n_tiles, nblk, lds_main;
     LaunchGeom geom;
     PartialLayout lay;
@@ -79,17 +83,21 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->row_ok = false;
     pl->split_ok = false;
     pl->panels = 0;
-    if (d->posterior == VIBO_POSTERIOR_UNCONDITIONAL && I > 1024 && I <= 65535 && (I % 4 == 0) &&
-        d->mask_dtype != VIBO_MASK_I64) {
-        // panel mode: a row-count pass, then one row-split launch per 1024 items (the backward is linear in
-        // d LL/d theta, so the panels backpropagate their partial sums independently); the wave-per-person kernel
-        // remains the fallback for unaligned rows (decided at launch)
+    pl->cond = false;
+    const bool is_cond = d->posterior == VIBO_POSTERIOR_CONDITIONAL;
+    if (I >= 192 && I <= 65535 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
+        // panel mode: one row-split launch per 1024 items (the backward is linear in d LL/d theta, so the panels
+        // backpropagate their partial sums independently).  Unconditional posterior: a row-count pass supplies the
+        // whole-row counts.  Conditional posterior (any item count): cond_pre_kernel supplies the product-of-experts
+        // sums, cond_post_kernel scatters the table gradient (vibo_cond.hip).  The wave-per-person kernel remains
+        // the fallback for unaligned rows (decided at launch).
         if (g_num_cu == 0) {
             int dev = 0, n = 0;
             g_num_cu = (hipGetDevice(&dev) == hipSuccess &&
                         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
         }
         pl->panels = (I + 1023) / 1024;
+        pl->cond = is_cond;
         const int at_min = d->irt_model == 3 ? 4 : 2;
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
@@ -100,10 +108,23 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
         pl->lds_main = 0;
         pl->lay = partial_layout(A, pl->D, 1024, d->n_flows);
         pl->off_item_prep = 0;
-        const size_t prep_bytes = ((size_t)((I + 15) & ~15) * pl->DP * 4 + 255) & ~(size_t)255;
-        pl->off_cnt = prep_bytes;
-        pl->off_partial = prep_bytes + (((size_t)d->num_person * 4 + 255) & ~(size_t)255);
-        pl->total_bytes = pl->off_partial + (size_t)pl->panels * pl->split_nblk * pl->lay.stride * 4 + 256;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        size_t off = up((size_t)((I + 15) & ~15) * pl->DP * 4);
+        pl->off_cnt = off;
+        off += up((size_t)d->num_person * 4);
+        pl->off_partial = off;
+        off += up((size_t)pl->panels * pl->split_nblk * pl->lay.stride * 4);
+        pl->cond_rec = 8 * A * 1024;
+        pl->off_pre = pl->off_coef = pl->off_cpart = off;
+        if (is_cond) {
+            pl->off_pre = off;
+            off += up((size_t)pl->panels * d->num_person * (2 * A + 1) * 4);
+            pl->off_coef = off;
+            off += up((size_t)pl->panels * d->num_person * 4 * A * 4);
+            pl->off_cpart = off;
+            off += up((size_t)pl->panels * pl->split_nblk * pl->cond_rec * 4);
+        }
+        pl->total_bytes = off + 256;
         pl->general = false;
         return 16;
     }
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(64 * kFinSlices) void finalize_kernel(const Finaliz
             // partial scalars: 0 ll, 1 kl, 2 logq0, 3 logp, 4 ladj, 5 nobs
             part[0][lane] = t;
         } else if (e < 8 + n_tab) {
-            f.grad_table[e - 8] = (float)t;
+            if (f.grad_table) f.grad_table[e - 8] = (float)t;      // null: conditional posterior (cond_finalize_kernel)
         } else if (e < 8 + n_tab + n_flow) {
             f.grad_flow[e - 8 - n_tab] = (float)t;
         } else {
@@ -488,22 +509,54 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     int nblk_used = pl.nblk;
     int panel_items = 1 << 30, bpp = 0;
     if (pl.panels > 0) {
-        int* cnt = reinterpret_cast<int*>(static_cast<char*>(workspace) + pl.off_cnt);
-        int cgrid = g_num_cu * 8;
-        if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
-        hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
-                           (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
-        e = hipGetLastError();
-        p.row_cnt = cnt;
+        char* wsb = static_cast<char*>(workspace);
+        float* pre = reinterpret_cast<float*>(wsb + pl.off_pre);
+        float* coef = reinterpret_cast<float*>(wsb + pl.off_coef);
+        float* cpart = reinterpret_cast<float*>(wsb + pl.off_cpart);
+        CondParams cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.response = response; cp.mask = mask; cp.row_index = row_index; cp.table = table;
+        cp.resp_stride = d->response_row_stride; cp.mask_stride = d->mask_row_stride;
+        cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;
+        cp.coef_panels = pl.panels; cp.rec_stride = pl.cond_rec; cp.coef_in = coef;
+        e = hipSuccess;
+        if (pl.cond) {
+            for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
+                cp.item0 = pn * 1024;
+                cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
+                cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
+                e = launch_cond_pre(cp, pl.AT, (cp.I + 255) / 256, pl.split_nblk, s);
+            }
+            p.pre_stats = pre;
+            p.pre_panels = pl.panels;
+        } else {
+            int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
+            int cgrid = g_num_cu * 8;
+            if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
+            hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
+                               (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
+            e = hipGetLastError();
+            p.row_cnt = cnt;
+        }
         for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
             p.item0 = pn * 1024;
             p.I = I - p.item0 < 1024 ? I - p.item0 : 1024;
             p.primary = pn == 0 ? 1 : 0;
             p.partial = partial + (size_t)pn * pl.split_nblk * pl.lay.stride;
+            p.post_coef = (pl.cond && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
             const int nq = (p.I + 255) / 256;
             e = pl.AT <= 2   ? launch_elbo_split_a2(p, d->irt_model, grad, nq, pl.split_nblk, s)
                 : pl.AT == 4 ? launch_elbo_split_a4(p, d->irt_model, grad, nq, pl.split_nblk, s)
                              : launch_elbo_split_a8(p, d->irt_model, grad, nq, pl.split_nblk, s);
+        }
+        if (pl.cond && grad) {
+            for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
+                cp.item0 = pn * 1024;
+                cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
+                cp.partial = cpart + (size_t)pn * pl.split_nblk * pl.cond_rec;
+                e = launch_cond_post(cp, pl.AT, (cp.I + 255) / 256, pl.split_nblk, s);
+            }
+            if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.split_nblk, pl.cond_rec, s);
         }
         nblk_used = pl.panels * pl.split_nblk;
         panel_items = 1024;
@@ -527,7 +580,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
 
     FinalizeParams f;
     memset(&f, 0, sizeof(f));
-    f.partial = partial; f.out_scalars = out_scalars; f.grad_table = grad_table; f.grad_item = grad_item;
+    f.partial = partial; f.out_scalars = out_scalars; f.grad_table = (pl.panels > 0 && pl.cond) ? nullptr : grad_table; f.grad_item = grad_item;
     f.grad_flow = grad_flow;
     f.nblk = nblk_used; f.I = I; f.A = A; f.D = pl.D; f.n_flows = d->n_flows; f.reg_mode = d->reg_mode;
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;

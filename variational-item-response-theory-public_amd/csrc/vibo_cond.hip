@@ -1,0 +1,286 @@
+// vibo_cond.hip -- conditional posterior q(theta | responses, items) (models.py:664-710) around the row-split kernel.
+//
+// With --conditional-posterior the encoder table has one (mu, logvar) row per (response code, item):
+// table[2][I][2A].  The product of experts of a person is then a gather over the row, and the table gradient a
+// scatter over (code, item).  Both keep the row-split kernel's mapping (an item never leaves its lane):
+//   cond_pre_kernel   lane holds tau = 1/(exp(logvar)+eps) and mu*tau of its 4 items for both codes; per row it sums
+//                     the experts the codes select, 8-row butterflies + LDS finish the row sums
+//                     -> pre_stats[panel][B][2A+1] = lam | s | nobs
+//   split_kernel      (vibo_split_kernel.hpp) takes lam, s from pre_stats instead of the 2-row table; its per-person
+//                     backward writes P1 = gmu/lam, P2 = -(gmu amu + glv)/lam per head -> post_coef[panel][B][2][2][A]
+//   cond_post_kernel  lane accumulates S1 = sum_p [code] P1, S2 = sum_p [code] P2 per (head, code, dim) of its items
+//                     in registers; at the end  d/d mu = S1 tau,  d/d logvar = -(S1 mu + S2) tau^2 exp(logvar)
+//   cond_finalize_kernel  fixed-order fp64 sum of the per-workgroup records -> grad_table[2 heads][2][I][2A]
+// Three passes over the response matrix (5 B/term each) instead of one; every kernel streams rows exactly like the
+// row-split kernel (16-byte loads one batch ahead).  ability_dim <= 4 (8 A accumulators per item in cond_post).
+#include <hip/hip_runtime.h>
+#include "../../include/vibo_hip.h"
+#include "vibo_cond.hpp"
+#include "vibo_device.hpp"
+#include "vibo_split_kernel.hpp"
+
+namespace vibo {
+
+// 8 values per lane -> lane l returns the 64-lane sum of value (l >> 3)   (float twin of bfly8(int))
+__device__ __forceinline__ float bfly8f(const float (&v)[8], const int lane) {
+    float w[4], u[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned a = __builtin_bit_cast(unsigned, v[k]), b = __builtin_bit_cast(unsigned, v[k + 4]);
+        swap32(a, b);
+        w[k] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        unsigned a = __builtin_bit_cast(unsigned, w[k]), b = __builtin_bit_cast(unsigned, w[k + 2]);
+        swap16(a, b);
+        u[k] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+    const bool hi = (lane & 8) != 0;
+    const float keep = hi ? u[1] : u[0], give = hi ? u[0] : u[1];
+    float t = keep + dpp_f<0x128>(give);     // row_ror 8
+    t += dpp_f<0x141>(t);                    // row_half_mirror
+    t += dpp_f<0xb1>(t);                     // quad_perm [1,0,3,2]
+    t += dpp_f<0x4e>(t);                     // quad_perm [2,3,0,1]
+    return t;
+}
+
+constexpr int kCR = 8;   // rows per batch
+
+struct RowBatch {
+    float4 x[kCR];
+    uint32_t m[kCR];
+};
+__device__ __forceinline__ void load_rows(const CondParams& p, const long long bt, const int chunk, const bool chunk_ok,
+                                          RowBatch& rb) {
+    const long long row0 = bt * kCR;
+#pragma unroll
+    for (int r = 0; r < kCR; ++r) {
+        const long long row = row0 + r;
+        rb.x[r] = float4{0.f, 0.f, 0.f, 0.f};
+        rb.m[r] = 0u;
+        if (row < p.B && chunk_ok) {
+            const long long src = p.row_index ? p.row_index[row] : row;
+            rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
+            if (p.mask_dtype == 0)
+                rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
+            else
+                rb.m[r] = 0x01010101u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <int AT>
+__global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
+    constexpr int NV = 2 * AT + 1;
+    __shared__ float part[4][kCR][NV];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = blockDim.x >> 6;
+    const int A = p.A;
+    const int chunk = q * 64 + lane;
+    const bool chunk_ok = chunk < (p.I >> 2);
+    float tau[4][2][AT], mt[4][2][AT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float* te = p.table + ((size_t)c * p.I_total + (p.item0 + 4 * chunk + j)) * 2 * A;
+#pragma unroll
+            for (int a = 0; a < AT; ++a) {
+                float t = 0.f, mm = 0.f;
+                if (chunk_ok && a < A) {
+                    t = 1.0f / (expf(te[A + a]) + kPoeEps);       // utils.py:105-113
+                    mm = te[a] * t;
+                }
+                tau[j][c][a] = t;
+                mt[j][c][a] = mm;
+            }
+        }
+    const long long n_batches = ((long long)p.B + kCR - 1) / kCR;
+    RowBatch rb;
+    long long bt = blockIdx.x;
+    if (bt < n_batches) load_rows(p, bt, chunk, chunk_ok, rb);
+    for (; bt < n_batches; bt += gridDim.x) {
+        const long long row0 = bt * kCR;
+        float v[NV][kCR];
+#pragma unroll
+        for (int r = 0; r < kCR; ++r) {
+            int pk = 0;
+            const uint32_t cw = pack_codes4(rb.x[r], rb.m[r], pk);
+            const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, false);
+            const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, true);
+            const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
+#pragma unroll
+            for (int a = 0; a < AT; ++a) { v[a][r] = 0.f; v[AT + a][r] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float wp = fmaxf(w[j], 0.f), wn = fmaxf(-w[j], 0.f);      // [correct], [wrong]
+#pragma unroll
+                for (int a = 0; a < AT; ++a) {
+                    v[a][r] = fmaf(wp, tau[j][1][a], fmaf(wn, tau[j][0][a], v[a][r]));
+                    v[AT + a][r] = fmaf(wp, mt[j][1][a], fmaf(wn, mt[j][0][a], v[AT + a][r]));
+                }
+            }
+            v[2 * AT][r] = (float)(pk & 0xffff);
+        }
+        if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const float t = bfly8f(v[k], lane);            // lane l: row l >> 3
+            if ((lane & 7) == 0) part[q][lane >> 3][k] = t;
+        }
+        __syncthreads();
+        if (tid < kCR * NV) {
+            const int r = tid / NV, k = tid % NV;
+            float t = 0.f;
+            for (int w = 0; w < nq; ++w) t += part[w][r][k];
+            const long long row = row0 + r;
+            // [lam 0..A) | s 0..A) | nobs]: drop the padded dims
+            const int a = k < AT ? k : k - AT;
+            if (row < p.B) {
+                if (k == 2 * AT) p.pre_out[row * (2 * A + 1) + 2 * A] = t;
+                else if (a < A) p.pre_out[row * (2 * A + 1) + (k < AT ? a : A + a)] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <int AT>
+__global__ __launch_bounds__(256, 2) void cond_post_kernel(const CondParams p) {
+    constexpr int NC = 4 * AT;                       // coefficients per person: [head][P1|P2][dim]
+    __shared__ __attribute__((aligned(16))) float cbuf[4][kCR][NC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A;
+    const int chunk = q * 64 + lane;
+    const bool chunk_ok = chunk < (p.I >> 2);
+    float S[4][2][NC];                               // [item][code][head, P1|P2, dim]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) S[j][c][k] = 0.f;
+    const long long n_batches = ((long long)p.B + kCR - 1) / kCR;
+    RowBatch rb;
+    long long bt = blockIdx.x;
+    if (bt < n_batches) load_rows(p, bt, chunk, chunk_ok, rb);
+    for (; bt < n_batches; bt += gridDim.x) {
+        const long long row0 = bt * kCR;
+        uint32_t cw[kCR];
+#pragma unroll
+        for (int r = 0; r < kCR; ++r) {
+            int pk = 0;
+            cw[r] = pack_codes4(rb.x[r], rb.m[r], pk);
+        }
+        if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
+        // this batch's coefficients (sum over the panels' shares), wave-private copy
+        for (int e = lane; e < kCR * NC; e += 64) {
+            const int r = e / NC, k = e % NC, a = k % AT, hk = k / AT;
+            float t = 0.f;
+            if (row0 + r < p.B && a < A)
+                for (int pn = 0; pn < p.coef_panels; ++pn)
+                    t += p.coef_in[((size_t)pn * p.B + (row0 + r)) * 4 * A + hk * A + a];
+            cbuf[q][r][k] = t;
+        }
+#pragma unroll
+        for (int r = 0; r < kCR; ++r) {
+            const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw[r], false);
+            const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw[r], true);
+            const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
+            float C[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&cbuf[q][r][k]);
+                C[k] = t4.x; C[k + 1] = t4.y; C[k + 2] = t4.z; C[k + 3] = t4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float wp = fmaxf(w[j], 0.f), wn = fmaxf(-w[j], 0.f);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    S[j][1][k] = fmaf(wp, C[k], S[j][1][k]);
+                    S[j][0][k] = fmaf(wn, C[k], S[j][0][k]);
+                }
+            }
+        }
+    }
+    // d / d table of this workgroup's share:  record [head][code][mu dims | logvar dims][1024 items]
+    if (chunk_ok) {
+        float* out = p.partial + (size_t)blockIdx.x * p.rec_stride + 4 * chunk;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int a = 0; a < AT; ++a) {
+                if (a >= A) continue;
+                float tauv[4], muv[4], esv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* te = p.table + ((size_t)c * p.I_total + (p.item0 + 4 * chunk + j)) * 2 * A;
+                    esv[j] = expf(te[A + a]);
+                    tauv[j] = 1.0f / (esv[j] + kPoeEps);
+                    muv[j] = te[a];
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float gm[4], gl[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float s1 = S[j][c][(h * 2 + 0) * AT + a], s2 = S[j][c][(h * 2 + 1) * AT + a];
+                        gm[j] = s1 * tauv[j];
+                        gl[j] = -(s1 * muv[j] + s2) * tauv[j] * tauv[j] * esv[j];
+                    }
+                    *reinterpret_cast<float4*>(out + (size_t)((h * 2 + c) * 2 * A + a) * 1024) = float4{gm[0], gm[1], gm[2], gm[3]};
+                    *reinterpret_cast<float4*>(out + (size_t)((h * 2 + c) * 2 * A + A + a) * 1024) = float4{gl[0], gl[1], gl[2], gl[3]};
+                }
+            }
+    }
+}
+
+// grad_table[head][code][i][j2] = sum over the panel's workgroup records (fp64, fixed order)
+__global__ __launch_bounds__(1024) void cond_finalize_kernel(const float* __restrict__ partial, float* __restrict__ grad_table,
+                                                             int I, int A, int panels, int bpp, int rec_stride) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int hcj = blockIdx.y;                       // (head * 2 + code) * 2A + j2
+    const int i = blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (i < I) {
+        const int pn = i >> 10, local = i & 1023;
+        const float* src = partial + (size_t)pn * bpp * rec_stride + (size_t)hcj * 1024 + local;
+        for (int b = slice; b < bpp; b += 16) acc += (double)src[(size_t)b * rec_stride];
+    }
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && i < I) {
+        double t = 0.0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) t += part[s][lane];
+        const int hc = hcj / (2 * A), j2 = hcj % (2 * A);
+        grad_table[((size_t)hc * I + i) * 2 * A + j2] = (float)t;
+    }
+    (void)panels;
+}
+
+hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
+    if (at <= 2) hipLaunchKernelGGL(cond_pre_kernel<2>, dim3(grid), dim3(64 * nq), 0, s, p);
+    else hipLaunchKernelGGL(cond_pre_kernel<4>, dim3(grid), dim3(64 * nq), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_cond_post(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
+    if (at <= 2) hipLaunchKernelGGL(cond_post_kernel<2>, dim3(grid), dim3(64 * nq), 0, s, p);
+    else hipLaunchKernelGGL(cond_post_kernel<4>, dim3(grid), dim3(64 * nq), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_cond_finalize(const float* partial, float* grad_table, int I, int A, int panels, int bpp, int rec_stride,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(cond_finalize_kernel, dim3((I + 63) / 64, 2 * 2 * 2 * A), dim3(1024), 0, s, partial, grad_table, I, A,
+                       panels, bpp, rec_stride);
+    return hipGetLastError();
+}
+
+}  // namespace vibo

@@ -1,0 +1,25 @@
+// vibo_cond.hpp -- launch interface of the conditional-posterior kernels (vibo_cond.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vibo {
+
+struct CondParams {
+    const float* response;
+    const void* mask;
+    const int64_t* row_index;
+    const float* table;        // [2][I_total][2A]
+    float* pre_out;            // cond_pre:  [B][2A+1] of this panel
+    const float* coef_in;      // cond_post: [coef_panels][B][4A]
+    float* partial;            // cond_post: [grid][rec_stride] records of this panel
+    long long resp_stride, mask_stride;
+    int B, I, I_total, item0, A, mask_dtype, coef_panels, rec_stride;
+};
+
+hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s);
+hipError_t launch_cond_post(const CondParams& p, int at, int nq, int grid, hipStream_t s);
+hipError_t launch_cond_finalize(const float* partial, float* grad_table, int I, int A, int panels, int bpp, int rec_stride,
+                                hipStream_t s);
+
+}  // namespace vibo

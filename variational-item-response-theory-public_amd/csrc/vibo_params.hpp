@@ -63,6 +63,11 @@ struct ElboParams {
     int item0;                // first item of this panel
     int I_total;              // items of the whole row (PoE prior experts, nmiss)
     int primary;              // 1: this launch writes the per-person outputs and owns the KL / REG terms
+    // conditional posterior (vibo_cond.hip): product-of-experts sums come from cond_pre_kernel, the backward
+    // hands per-person coefficients to cond_post_kernel instead of accumulating the 2-row table gradient
+    const float* pre_stats;   // [pre_panels][B][2A+1] = lam[A] | s[A] | nobs, or null
+    float* post_coef;         // [B][2 sets][2][A]: P1 = gmu / lam, P2 = -(gmu amu + glv) / lam   (this launch's share)
+    int pre_panels;
     long long resp_stride, mask_stride;
     int B, I, A, D, DP;
     int n_tiles, lds_stride, lds_main;

@@ -269,13 +269,24 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
             for (int w = 0; w < (NQT > 0 ? NQT : 4); ++w)
                 if (w < nq) cnt += wls[w].cntp[er];
         }
-        const float n1 = (float)(cnt >> 16), nobs = (float)(cnt & 0xffff);
-        const float n0 = nobs - n1, nmiss = (float)p.I_total - nobs;
-        float lam = n0 * tau0 + n1 * tau1;
+        const float n1 = (float)(cnt >> 16);
+        float nobs = (float)(cnt & 0xffff);
+        const float n0 = nobs - n1;
+        float lam = n0 * tau0 + n1 * tau1, smu = n0 * mt0 + n1 * mt1;
+        if (p.pre_stats) {                  // conditional posterior: per-(code, item) experts summed by cond_pre_kernel
+            lam = 0.f; smu = 0.f; nobs = 0.f;
+            if (live) {
+                for (int pn = 0; pn < p.pre_panels; ++pn) {
+                    const float* st = p.pre_stats + ((size_t)pn * p.B + (row0 + er)) * (2 * A + 1);
+                    lam += st[ed]; smu += st[A + ed]; nobs += st[2 * A];
+                }
+            }
+        }
+        const float nmiss = (float)p.I_total - nobs;
         if (p.missing_mode == 0) lam += nmiss * (1.0f / (1.0f + kPoeEps));
         if (!live) lam = 1.0f;              // rows past the end / padded dims: keep the arithmetic finite
         const float inv_lam = 1.0f / lam;
-        const float amu = (n0 * mt0 + n1 * mt1) * inv_lam;
+        const float amu = smu * inv_lam;
         const float sig = fast_rsq(lam);
         const float th0 = live ? amu + sig * eps_c : 0.f;
         float thv = th0;
@@ -522,6 +533,16 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                     glv[1] = gz1 * h - 0.5f;
                 }
                 if (!reg_on) { gmu[1] = 0.f; glv[1] = 0.f; }
+                if (p.post_coef) {
+                    if (live) {
+                        float* pc = p.post_coef + (size_t)(row0 + er) * 4 * A;
+#pragma unroll
+                        for (int st = 0; st < 2; ++st) {
+                            pc[(st * 2 + 0) * A + ed] = gmu[st] * inv_lam;
+                            pc[(st * 2 + 1) * A + ed] = -(gmu[st] * amu + glv[st]) * inv_lam;
+                        }
+                    }
+                }
                 const float nn[2] = {n0, n1};
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
