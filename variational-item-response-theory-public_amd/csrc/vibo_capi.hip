@@ -525,7 +525,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                 cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
-                e = launch_cond_pre(cp, pl.AT, (cp.I + 255) / 256, pl.split_nblk, s);
+                e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.split_nblk, s);   // own template width (3PL widens the split kernel's)
             }
             p.pre_stats = pre;
             p.pre_panels = pl.panels;
@@ -554,7 +554,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                 cp.partial = cpart + (size_t)pn * pl.split_nblk * pl.cond_rec;
-                e = launch_cond_post(cp, pl.AT, (cp.I + 255) / 256, pl.split_nblk, s);
+                e = launch_cond_post(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.split_nblk, s);
             }
             if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.split_nblk, pl.cond_rec, s);
         }

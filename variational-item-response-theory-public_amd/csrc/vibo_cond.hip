@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
 
 // ---------------------------------------------------------------------------
 template <int AT>
-__global__ __launch_bounds__(256, 2) void cond_post_kernel(const CondParams p) {
+__global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const CondParams p) {
     constexpr int NC = 4 * AT;                       // coefficients per person: [head][P1|P2][dim]
     __shared__ __attribute__((aligned(16))) float cbuf[4][kCR][NC];
     const int tid = threadIdx.x, lane = tid & 63;
