@@ -78,14 +78,14 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     // wave-per-person kernel: conditional posterior, > 1024 items; planar flows only when the row-split kernel
     // cannot take the launch (ragged / unaligned rows, int64 mask, < 192 items)
     pl->general = d->posterior == VIBO_POSTERIOR_CONDITIONAL || I > 1024;
-    const bool split_shape = I >= 192 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
+    const bool split_shape = I >= 4 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
     if (d->n_flows > 0 && !split_shape) pl->general = true;
     pl->row_ok = false;
     pl->split_ok = false;
     pl->panels = 0;
     pl->cond = false;
     const bool is_cond = d->posterior == VIBO_POSTERIOR_CONDITIONAL;
-    if (I >= 192 && I <= 65535 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
+    if (I >= 4 && I <= 65535 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
         // panel mode: one row-split launch per 1024 items (the backward is linear in d LL/d theta, so the panels
         // backpropagate their partial sums independently).  Unconditional posterior: a row-count pass supplies the
         // whole-row counts.  Conditional posterior (any item count): cond_pre_kernel supplies the product-of-experts
