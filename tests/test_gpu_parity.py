@@ -403,3 +403,39 @@ def test_full_size_shard_additivity_permutation_determinism(A, P):
     ref = T.fused_elbo_ref(table.cpu().double(), item.cpu().double(), resp[sl].cpu().double(), mask[sl].cpu(),
                            eps[sl].cpu().double(), irt_model=irt, ability_dim=A, mode='kl')
     compare_raw(run(sl), ref, (I, A + 1))
+
+
+@pytest.mark.parametrize('irt,A,I,cond,n_flows', [(2, 1, 95, False, 0), (2, 8, 1003, False, 0), (3, 2, 333, False, 2),
+                                                   (2, 1, 2501, False, 0), (2, 2, 201, True, 0)])
+def test_ragged_item_count_with_padded_row_strides(irt, A, I, cond, n_flows):
+    """I % 4 != 0 (CritLangAcq: 95 items): rows padded to 16 bytes by ops.pad_rows take the row-split kernels; the
+    padding cells (and, for a column-sliced view, the neighbouring columns) are read but never interpreted."""
+    B = 77
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, n_flows=n_flows)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.2, seed=I + A, cond=cond)
+    g = torch.Generator().manual_seed(I)
+    flow = torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5 if n_flows else None
+    flows = [(f[:A].double(), f[A:2 * A].double(), f[2 * A:].double()) for f in flow] if n_flows else None
+    mode = 'sampled' if n_flows else 'kl'
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt,
+                           ability_dim=A, conditional_posterior=cond, replace_missing_with_prior=True, mode=mode,
+                           flow_uhat_w_b=flows)
+    d = dev()
+    # (a) padded copies; (b) a column slice of a wider matrix whose extra columns hold garbage that must be ignored
+    wide_r = torch.full((B, I + 9), 1.0)
+    wide_m = torch.ones(B, I + 9, dtype=torch.bool)
+    wide_r[:, :I] = resp
+    wide_m[:, :I] = mask.bool()
+    cases = [ops.pad_rows(resp.to(d), mask.bool().to(d))]
+    if (I + 9) % 4 == 0:
+        cases.append((wide_r.to(d)[:, :I], wide_m.to(d)[:, :I]))
+    for r_, m_ in cases:
+        assert r_.stride(0) % 4 == 0 and r_.stride(0) >= I
+        r = ops.prepare_response(r_)
+        m, code = ops.prepare_mask(m_)
+        assert r.stride(0) == r_.stride(0) and m.stride(0) == m_.stride(0)          # read in place, not copied
+        raw = ops._hip_launch_elbo(spec, r, m, code, None, table.to(d).contiguous(), item.to(d).contiguous(),
+                                   eps.to(d).contiguous(), flow.to(d).contiguous() if flow is not None else None,
+                                   _lib.REG_SAMPLED if n_flows else _lib.REG_KL, True, B)
+        torch.cuda.synchronize()
+        compare_raw(raw, ref, (I, spec.item_dim), tol=5e-4)

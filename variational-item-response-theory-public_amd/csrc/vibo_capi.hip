@@ -69,6 +69,17 @@ struct Plan {
 
 static int g_num_cu = 0;
 
+// 16-byte row chunks need I % 4 == 0, or row strides that pad every row to a multiple of 4 cells (the cells past
+// the row's end are read but masked out in the kernels)
+static bool rows_chunkable(const vibo_desc* d) {
+    const int I = d->num_item;
+    if (I % 4 == 0) return true;
+    const long long i4 = (I + 3) & ~3;
+    if (d->response_row_stride < i4) return false;
+    if (d->mask_dtype == VIBO_MASK_U8 && d->mask_row_stride < i4) return false;
+    return true;
+}
+
 static int make_plan(const vibo_desc* d, Plan* pl) {
     const int I = d->num_item, A = d->ability_dim;
     pl->AT = padded_ability_dim(A);
@@ -78,14 +89,14 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     // wave-per-person kernel: conditional posterior, > 1024 items; planar flows only when the row-split kernel
     // cannot take the launch (ragged / unaligned rows, int64 mask, < 192 items)
     pl->general = d->posterior == VIBO_POSTERIOR_CONDITIONAL || I > 1024;
-    const bool split_shape = I >= 4 && I <= 1024 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64;
+    const bool split_shape = I >= 4 && I <= 1024 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64;
     if (d->n_flows > 0 && !split_shape) pl->general = true;
     pl->row_ok = false;
     pl->split_ok = false;
     pl->panels = 0;
     pl->cond = false;
     const bool is_cond = d->posterior == VIBO_POSTERIOR_CONDITIONAL;
-    if (I >= 4 && I <= 65535 && (I % 4 == 0) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
+    if (I >= 4 && I <= 65535 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
         // panel mode: one row-split launch per 1024 items (the backward is linear in d LL/d theta, so the panels
         // backpropagate their partial sums independently).  Unconditional posterior: a row-count pass supplies the
         // whole-row counts.  Conditional posterior (any item count): cond_pre_kernel supplies the product-of-experts
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * 4;
-    const int n4 = I >> 2;
+    const int n4 = (I + 3) >> 2;
     for (long long row = wave_id; row < B; row += n_waves) {
         const long long src = row_index ? row_index[row] : row;
         const float4* rp = reinterpret_cast<const float4*>(response + src * resp_stride);
@@ -257,6 +268,7 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
                 if (c < n4) {
                     x[u] = rp[c];
                     m[u] = mask_dtype == 0 ? mp[c] : 0x01010101u;
+                    if ((I & 3) && c == (I >> 2)) m[u] &= (1u << (8 * (I & 3))) - 1u;      // padded tail of the row
                 }
             }
 #pragma unroll
@@ -452,7 +464,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     hipStream_t s = (hipStream_t)stream;
     const int I = d->num_item, A = d->ability_dim;
     // 16-byte row loads need aligned rows
-    bool vec = (I % 4 == 0) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
+    bool vec = rows_chunkable(d) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
     if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
     if (d->mask_dtype == VIBO_MASK_I64) vec = vec && (d->mask_row_stride % 2 == 0) && (((uintptr_t)mask & 15) == 0);
 
@@ -502,7 +514,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     p.mask_dtype = d->mask_dtype; p.missing_mode = d->missing_mode; p.reg_mode = d->reg_mode;
     p.flow = flow; p.ability_k = ability_k; p.ability_ladj = ability_ladj; p.n_flows = d->n_flows;
     p.lay = pl.lay;
-    p.vec_ok = vec ? 1 : 0;
+    p.vec_ok = (vec && I % 4 == 0) ? 1 : 0;      // the tiled / wave-per-row kernels' vector loads assume whole chunks
     p.row_cnt = nullptr; p.item0 = 0; p.I_total = I; p.primary = 1;
 
     const bool grad = d->want_grad != 0;
@@ -566,7 +578,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         e = pl.AT <= 2   ? launch_elbo_split_a2(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
             : pl.AT == 4 ? launch_elbo_split_a4(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
                          : launch_elbo_split_a8(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
-    } else if (pl.row_ok && vec && pl.AT == A) {
+    } else if (pl.row_ok && vec && I % 4 == 0 && pl.AT == A) {
         nblk_used = pl.row_nblk;
         e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);
     } else

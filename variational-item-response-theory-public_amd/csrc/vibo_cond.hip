@@ -54,6 +54,8 @@ struct RowBatch {
 __device__ __forceinline__ void load_rows(const CondParams& p, const long long bt, const int chunk, const bool chunk_ok,
                                           RowBatch& rb) {
     const long long row0 = bt * kCR;
+    // cells of the last chunk past the row's end (I % 4 != 0 with 16-byte padded row strides)
+    const uint32_t tail_mask = ((p.I & 3) && chunk == (p.I >> 2)) ? ((1u << (8 * (p.I & 3))) - 1u) : 0xFFFFFFFFu;
 #pragma unroll
     for (int r = 0; r < kCR; ++r) {
         const long long row = row0 + r;
@@ -63,9 +65,9 @@ __device__ __forceinline__ void load_rows(const CondParams& p, const long long b
             const long long src = p.row_index ? p.row_index[row] : row;
             rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
             if (p.mask_dtype == 0)
-                rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
+                rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk] & tail_mask;
             else
-                rb.m[r] = 0x01010101u;
+                rb.m[r] = 0x01010101u & tail_mask;
         }
     }
 }
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
     const int nq = blockDim.x >> 6;
     const int A = p.A;
     const int chunk = q * 64 + lane;
-    const bool chunk_ok = chunk < (p.I >> 2);
+    const bool chunk_ok = chunk < ((p.I + 3) >> 2);
     float tau[4][2][AT], mt[4][2][AT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const C
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int A = p.A;
     const int chunk = q * 64 + lane;
-    const bool chunk_ok = chunk < (p.I >> 2);
+    const bool chunk_ok = chunk < ((p.I + 3) >> 2);
     float S[4][2][NC];                               // [item][code][head, P1|P2, dim]
 #pragma unroll
     for (int j = 0; j < 4; ++j)

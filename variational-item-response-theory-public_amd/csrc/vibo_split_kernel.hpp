@@ -141,9 +141,11 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
     const int nq = NQT > 0 ? NQT : (int)(blockDim.x >> 6);
     SplitWaveLds& wl = wls[q];
     const int I = p.I, A = p.A;
-    const int n4 = I >> 2;
+    const int n4 = (I + 3) >> 2;                          // I % 4 != 0: rows are padded to 16 B by the caller's strides
     const int chunk = q * 64 + lane;                      // float4 chunk of the row this lane owns
     const bool chunk_ok = chunk < n4;
+    // cells of the last chunk that lie past the row's end (they belong to the padding / the next columns)
+    const uint32_t tail_mask = ((I & 3) && chunk == (I >> 2)) ? ((1u << (8 * (I & 3))) - 1u) : 0xFFFFFFFFu;
 
     if (tid < 2 * AT) {
         const int c = tid / AT, a = tid % AT;
@@ -224,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                 const long long src = p.row_index ? p.row_index[row] : row;
                 x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
                 if (p.mask_dtype == 0)
-                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
+                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk] & tail_mask;
                 else
-                    m[r] = 0x01010101u;
+                    m[r] = 0x01010101u & tail_mask;
             }
         }
         const long long erow = row0 + er;

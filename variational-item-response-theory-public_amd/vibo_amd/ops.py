@@ -90,11 +90,32 @@ def prepare_mask(mask):
         return None, _lib.MASK_NONE
     if mask.dim() == 3:
         mask = mask.squeeze(2)
-    if mask.dtype == torch.bool:
-        return mask.contiguous().view(torch.uint8), _lib.MASK_U8
+    if mask.dtype == torch.bool or mask.dtype == torch.uint8:
+        # rows may be strided (e.g. padded to 16 bytes, see pad_rows); only the cells must be unit-stride
+        if mask.stride(-1) != 1:
+            mask = mask.contiguous()
+        return (mask if mask.dtype == torch.uint8 else mask.view(torch.uint8)), _lib.MASK_U8
     if mask.dtype == torch.int64:
         return mask.contiguous(), _lib.MASK_I64
     return (mask != 0).contiguous().view(torch.uint8), _lib.MASK_U8
+
+
+def pad_rows(response, mask):
+    """Device-resident copies of a [P, I] response / mask pair whose row strides are padded to a multiple of 4
+    cells, returned as [P, I] views.  With I % 4 != 0 (CritLangAcq: 95 items) this keeps every row 16-byte aligned
+    so the row-split kernel's vector loads apply; the padding cells are never interpreted (masked in the kernel)."""
+    P, I = response.shape
+    I4 = (I + 3) // 4 * 4
+    if I4 == I:
+        return response.contiguous(), (mask.contiguous() if mask is not None else None)
+    r = torch.zeros(P, I4, dtype=response.dtype, device=response.device)
+    r[:, :I] = response
+    m = None
+    if mask is not None:
+        m = torch.zeros(P, I4, dtype=mask.dtype, device=mask.device)
+        m[:, :I] = mask
+        m = m[:, :I]
+    return r[:, :I], m
 
 
 def prepare_response(response):

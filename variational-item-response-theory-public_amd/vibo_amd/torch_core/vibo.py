@@ -24,7 +24,7 @@ import time
 import numpy as np
 import torch
 
-from .. import config
+from .. import config, ops
 from ..datasets import artificially_mask_dataset, load_dataset
 from ..utils import AverageMeter, save_checkpoint
 from .models import VIBO_1PL, VIBO_2PL, VIBO_3PL
@@ -111,8 +111,8 @@ class ResidentSplit:
         r, m = dataset.matrix()
         if row_slice is not None:
             r, m = r[row_slice], m[row_slice]
-        self.response = torch.from_numpy(r).to(device)
-        self.mask = torch.from_numpy(m).to(device)
+        # rows padded to 16 bytes when the item count is not a multiple of 4 (vector loads of the row-split kernel)
+        self.response, self.mask = ops.pad_rows(torch.from_numpy(r).to(device), torch.from_numpy(m).to(device))
         self.num_person, self.num_item = self.response.shape
         self.device = device
 
