@@ -47,6 +47,12 @@ __device__ __forceinline__ float bfly8f(const float (&v)[8], const int lane) {
 
 constexpr int kCR = 8;   // rows per batch
 
+// cells of a lane's chunk that lie inside the row (I % 4 != 0 with 16-byte padded row strides); applied where the
+// mask word is consumed, so that the loads stay in flight
+__device__ __forceinline__ uint32_t chunk_tail_mask(const CondParams& p, const int chunk) {
+    return ((p.I & 3) && chunk == (p.I >> 2)) ? ((1u << (8 * (p.I & 3))) - 1u) : 0xFFFFFFFFu;
+}
+
 struct RowBatch {
     float4 x[kCR];
     uint32_t m[kCR];
@@ -54,8 +60,6 @@ struct RowBatch {
 __device__ __forceinline__ void load_rows(const CondParams& p, const long long bt, const int chunk, const bool chunk_ok,
                                           RowBatch& rb) {
     const long long row0 = bt * kCR;
-    // cells of the last chunk past the row's end (I % 4 != 0 with 16-byte padded row strides)
-    const uint32_t tail_mask = ((p.I & 3) && chunk == (p.I >> 2)) ? ((1u << (8 * (p.I & 3))) - 1u) : 0xFFFFFFFFu;
 #pragma unroll
     for (int r = 0; r < kCR; ++r) {
         const long long row = row0 + r;
@@ -65,9 +69,9 @@ __device__ __forceinline__ void load_rows(const CondParams& p, const long long b
             const long long src = p.row_index ? p.row_index[row] : row;
             rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
             if (p.mask_dtype == 0)
-                rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk] & tail_mask;
+                rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
             else
-                rb.m[r] = 0x01010101u & tail_mask;
+                rb.m[r] = 0x01010101u;
         }
     }
 }
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
     const int A = p.A;
     const int chunk = q * 64 + lane;
     const bool chunk_ok = chunk < ((p.I + 3) >> 2);
+    const uint32_t tail_mask = chunk_tail_mask(p, chunk);
     float tau[4][2][AT], mt[4][2][AT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
             int pk = 0;
-            const uint32_t cw = pack_codes4(rb.x[r], rb.m[r], pk);
+            const uint32_t cw = pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
             const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, false);
             const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, true);
             const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const C
     const int A = p.A;
     const int chunk = q * 64 + lane;
     const bool chunk_ok = chunk < ((p.I + 3) >> 2);
+    const uint32_t tail_mask = chunk_tail_mask(p, chunk);
     float S[4][2][NC];                               // [item][code][head, P1|P2, dim]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const C
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
             int pk = 0;
-            cw[r] = pack_codes4(rb.x[r], rb.m[r], pk);
+            cw[r] = pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
         }
         if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
         // this batch's coefficients (sum over the panels' shares), wave-private copy

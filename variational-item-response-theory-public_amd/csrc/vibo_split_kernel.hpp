@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
                 const long long src = p.row_index ? p.row_index[row] : row;
                 x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
                 if (p.mask_dtype == 0)
-                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk] & tail_mask;
+                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
                 else
-                    m[r] = 0x01010101u & tail_mask;
+                    m[r] = 0x01010101u;
             }
         }
         const long long erow = row0 + er;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             pk[r] = 0;
-            wl.codes[r][lane] = pack_codes4(x[r], m[r], pk[r]);
+            wl.codes[r][lane] = pack_codes4(x[r], m[r] & tail_mask, pk[r]);   // mask at use: the loads stay in flight
         }
         const float eps_c = epn;
         if (bt + gridDim.x < n_batches) load_batch(bt + gridDim.x);
