@@ -274,9 +274,12 @@ def main():
     # MI355X_MICROARCH.md) cannot be collected from inside this process; for the default workload the value
     # recorded in profiles/r01_bench_profile.txt is reported, otherwise null.
     traffic, traffic_note = None, 'not measured for this workload'
-    if (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and A in (1, 8):
-        traffic = {8: 2 * 2891894e3 + 391581e3, 1: 2 * 2473670e3 + 34040e3}[A]
-        traffic_note = 'recorded measurement: profiles/r01_bench_profile.txt (2*FETCH_SIZE + WRITE_SIZE, KB)'
+    recorded = {8: (2 * 2461238 + 111894) * 1024.0, 1: (2 * 2453309 + 15751) * 1024.0}     # KiB counters -> bytes
+    if (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and A in recorded:
+        traffic = recorded[A]
+        traffic_note = 'recorded measurement: profiles/r01_bench_profile.txt (2*FETCH_SIZE + WRITE_SIZE of vibo::split_kernel, KiB)'
+    if also is not None and (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and args.also_ability_dim in recorded:
+        also['traffic'] = recorded[args.also_ability_dim]
     if rank == 0:
         terms = float(P) * I * args.steps * world
         line = {
