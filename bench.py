@@ -57,6 +57,7 @@ def parse():
     ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
     ap.add_argument('--rng', choices=['native', 'torch'], default='native', help='reparameterisation noise: vibo_fill_normal (Philox, in the C ABI) or torch.randn')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
+    ap.add_argument('--graph-collective', action='store_true', help='multi-GPU: capture the all-reduce inside the step graph instead of two graphs around an eager all-reduce')
     ap.add_argument('--force-dist', action='store_true', help='create the process group even for one rank (tests the RCCL path)')
     return ap.parse_args()
 
@@ -204,13 +205,29 @@ def main():
                         g.register_generator_state(gen)
                 if opt is not None:
                     opt.zero_grad(set_to_none=False)
-                with torch.cuda.graph(g):
-                    static_loss = step()
-                graph = g
+                if dist is not None and trainer is not None and not args.graph_collective:
+                    # person-sharded: two graphs around an EAGER all-reduce (a collective inside a captured graph
+                    # is one more thing that can go wrong on a node this script has never run on)
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        static_raw = trainer.forward_backward(resp, mask)
+                    with torch.cuda.graph(g2, pool=g.pool()):
+                        static_loss = trainer.update()
+                    graph = g
 
-                def step():
-                    graph.replay()
-                    return static_loss
+                    def step():
+                        graph.replay()
+                        dist.all_reduce(static_raw.flat)
+                        g2.replay()
+                        return static_loss
+                else:
+                    with torch.cuda.graph(g):
+                        static_loss = step()
+                    graph = g
+
+                    def step():
+                        graph.replay()
+                        return static_loss
             except Exception as exc:             # never lose the measurement to a capture problem
                 print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
                 graph = None
@@ -291,7 +308,7 @@ def main():
             'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU, '
                                    f'ability_dim={A}, {args.missing:.0%} missing, product-of-experts encoder, '
                                    f'unconditional posterior, full-shard minibatch',
-                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': 'hipGraph replay' if m['graph'] else 'eager',
+                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': ('hipGraph replay' if (dist is None or args.graph_collective) else 'two hipGraphs around an eager RCCL all-reduce') if m['graph'] else 'eager',
                        'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',
                        'noise': 'torch.randn' if (args.torch_optimizer or args.eval_only or args.rng == 'torch') else 'vibo_fill_normal (Philox4x32-10)',
                        'final_loss_per_term': final_loss / (P * I * world)},

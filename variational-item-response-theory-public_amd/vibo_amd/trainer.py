@@ -55,6 +55,7 @@ class FusedTrainer:
         self.kl_parts = torch.empty((n_item + 255) // 256, device=dev)
         self.loss = torch.zeros((), device=dev)
         self.last = None                      # RawElbo of the last step (posterior outputs, scalars)
+        self._pending = None
         # (person-sharded: item noise is the same on every rank, ability noise uses stream 1 + rank)
         # reparameterisation noise: 'torch' = torch.randn on the model's generators (the reference's stream for a
         # given seed), 'native' = vibo_fill_normal (Philox4x32-10 keyed by `seed`, ~5x faster on [1M, 8])
@@ -72,6 +73,17 @@ class FusedTrainer:
 
     @torch.no_grad()
     def step(self, response, mask, beta=None, row_index=None):
+        """One train step; returns the loss (device scalar).  = forward_backward(); [all-reduce]; update()."""
+        raw = self.forward_backward(response, mask, beta=beta, row_index=row_index)
+        if self.model._reducer is not None:
+            self.model._reducer(raw.flat)     # person-sharded: ONE all-reduce per step
+        return self.update()
+
+    @torch.no_grad()
+    def forward_backward(self, response, mask, beta=None, row_index=None):
+        """Noise, prologue and the fused ELBO forward+backward of this rank's persons.  Returns the RawElbo whose
+        `.flat` buffer [scalars | grads] a person-sharded caller all-reduces before `update()`.  (Split from
+        `update()` so that a multi-GPU loop can replay the two halves as hipGraphs around an eager collective.)"""
         if beta is not None:
             self.set_beta(beta)
         model, spec, lib = self.model, self.model.spec, _lib.load()
@@ -102,12 +114,19 @@ class FusedTrainer:
             eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
         raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None,
                                    _lib.REG_KL, True, B)
-        if model._reducer is not None:
-            model._reducer(raw.flat)          # person-sharded: ONE all-reduce per step
+        self._pending = (d, eps_item, raw)
+        self.last = raw
+        return raw
+
+    @torch.no_grad()
+    def update(self):
+        """Loss, encoder-MLP / item backward and Adam from the (all-reduced) flat buffer of forward_backward()."""
+        d, eps_item, raw = self._pending
+        lib, p = _lib.load(), ops._ptr
+        stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
         rc = lib.vibo_train_epilogue(ctypes.byref(d), self.hidden, p(raw.flat), p(self.saved_h), p(self.kl_parts),
                                      p(eps_item), p(self.beta), p(self.lr), p(self.step_count), p(self.mlp_flat),
                                      p(self.mlp_m), p(self.mlp_v), p(self.item_mu), p(self.item_lv), p(self.item_m),
                                      p(self.item_v), p(self.loss), stream)
         _lib.check(rc, 'vibo_train_epilogue')
-        self.last = raw
         return self.loss
