@@ -262,14 +262,30 @@ def test_row_index_gather_and_strided_rows():
     compare_raw(raw, ref, (I, spec.item_dim))
 
 
-def test_forward_only_matches_forward_of_train():
-    irt, A, B, I = 3, 4, 129, 777
-    spec = ElboSpec(irt_model=irt, ability_dim=A)
-    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.1, seed=3)
-    a = run_kernel(spec, resp, mask, table, item, eps, want_grad=True)
-    b = run_kernel(spec, resp, mask, table, item, eps, want_grad=False)
+@pytest.mark.parametrize('irt,A,B,I,cond,n_flows', [(3, 4, 129, 777, False, 0), (2, 8, 200, 1000, False, 0),
+                                                   (2, 1, 77, 1000, False, 4), (2, 2, 65, 2052, False, 0),
+                                                   (2, 1, 90, 600, True, 0), (3, 1, 33, 2500, True, 4)])
+def test_forward_only_matches_forward_of_train(irt, A, B, I, cond, n_flows):
+    """want_grad = 0 (eval / log_marginal): same heads and posteriors as the training launch, on every path
+    (tiled, row-split, panels, conditional)."""
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, n_flows=n_flows)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.1, seed=3, cond=cond)
+    g = torch.Generator().manual_seed(I)
+    flow = torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5 if n_flows else None
+    d = dev()
+    r = ops.prepare_response(resp.to(d))
+    m, code = ops.prepare_mask(mask.bool().to(d))
+    outs = []
+    for want_grad in (True, False):
+        outs.append(ops._hip_launch_elbo(spec, r, m, code, None, table.to(d).contiguous(), item.to(d).contiguous(),
+                                         eps.to(d).contiguous(), flow.to(d).contiguous() if flow is not None else None,
+                                         _lib.REG_SAMPLED if n_flows else _lib.REG_KL, want_grad, B))
+    torch.cuda.synchronize()
+    a, b = outs
     assert rel_err(b.scalars[:7].cpu(), a.scalars[:7].cpu()) < 1e-6
-    assert torch.equal(a.ability_mu, b.ability_mu)
+    assert torch.equal(a.ability_mu, b.ability_mu) and torch.equal(a.ability, b.ability)
+    if n_flows:
+        assert torch.equal(a.ability_k, b.ability_k)
 
 
 def test_all_missing_rows_and_saturated_logits():
