@@ -202,6 +202,22 @@ int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, c
  */
 int vibo_fill_normal(float* out, int64_t n, uint64_t seed, const int32_t* step_count, uint32_t stream_id, void* stream);
 
+/*
+ * num_samples forward evaluations of the ELBO heads in one pass over the response rows: the loop body of
+ * log_marginal (models.py:445-504, callers vibo.py:322-347, 550-556) under no_grad.  Per sample s the caller
+ * supplies a fresh item sample item[s] ([I][D], after the item flows if any) and ability noise eps[s] ([B][A]); the
+ * row loads, codes, counts and the product of experts are shared by the samples (2 or 4 per pass).
+ *     out_scalars[s][VIBO_NUM_SCALARS]   same heads as vibo_elbo_fwd_bwd's out_scalars, per sample
+ * Posterior outputs and gradients are not produced.  Returns -8 when nothing can be shared between the samples or
+ * the descriptor is not on the row-split path (conditional posterior: its table depends on the item sample; int64
+ * masks; unaligned rows): loop over vibo_elbo_fwd_bwd instead.
+ * Workspace: vibo_multi_workspace_bytes(d, num_samples) bytes, 256-byte aligned.
+ */
+size_t vibo_multi_workspace_bytes(const vibo_desc* d, int num_samples);
+int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* response, const void* mask,
+                            const int64_t* row_index, const float* table, const float* item, const float* eps,
+                            const float* flow, float* out_scalars, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,7 +71,10 @@ def install(ops):
         from oracle.vibo_oracle import irt_link
         return irt_link(spec.irt_model, ability, item)
 
-    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode)
+    def multi(spec, response, mask, mask_code, row_index, table, items, eps, flow, reg_mode, num_person):
+        return None          # "not covered": the module then loops over single forward launches
+
+    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi)
 
     def restore():
         ops._BACKEND.update(saved)

@@ -455,3 +455,44 @@ def test_ragged_item_count_with_padded_row_strides(irt, A, I, cond, n_flows):
                                    _lib.REG_SAMPLED if n_flows else _lib.REG_KL, True, B)
         torch.cuda.synchronize()
         compare_raw(raw, ref, (I, spec.item_dim), tol=5e-4)
+
+
+# ---------------------------------------------------------------------------
+# (4) multi-sample forward (log_marginal's loop body, models.py:445-504)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('irt,A,B,I,S,n_flows', [(2, 1, 100, 1000, 7, 0), (2, 8, 130, 1000, 5, 0), (3, 2, 77, 600, 4, 2),
+                                                 (1, 4, 33, 332, 3, 0), (2, 2, 50, 2500, 6, 4), (2, 3, 41, 95, 2, 0)])
+def test_multi_sample_forward_equals_single_launches(irt, A, B, I, S, n_flows):
+    """vibo_elbo_multi_forward (2 / 4 samples per pass over the rows) returns the heads of S separate forward launches."""
+    spec = ElboSpec(irt_model=irt, ability_dim=A, n_flows=n_flows)
+    resp, mask, table, _, _ = random_problem(irt, A, B, I, 0.15, seed=S * 100 + I)
+    g = torch.Generator().manual_seed(I + S)
+    items = torch.randn(S, I, spec.item_dim, generator=g)
+    eps = torch.randn(S, B, A, generator=g)
+    flow = torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5 if n_flows else None
+    d = dev()
+    r_, m_ = ops.pad_rows(resp.to(d), mask.bool().to(d))
+    r = ops.prepare_response(r_)
+    m, code = ops.prepare_mask(m_)
+    fl = flow.to(d).contiguous() if flow is not None else None
+    sc = ops._hip_multi_forward(spec, r, m, code, None, table.to(d).contiguous(), items.to(d).contiguous(),
+                                eps.to(d).contiguous(), fl, _lib.REG_SAMPLED, B)
+    assert sc is not None and sc.shape == (S, _lib.NUM_SCALARS)
+    for s in range(S):
+        one = ops._hip_launch_elbo(spec, r, m, code, None, table.to(d).contiguous(), items[s].to(d).contiguous(),
+                                   eps[s].to(d).contiguous(), fl, _lib.REG_SAMPLED, False, B)
+        a, b = sc[s, :7].cpu().double(), one.scalars[:7].cpu().double()
+        assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max())), (s, a, b)
+
+
+@pytest.mark.parametrize('name', ['logmarg_2pl_a2', 'logmarg_3pl_a1_cond_flows2'])
+def test_log_marginal_golden_through_module(name):
+    import os
+    from conftest import GOLDEN_DIR, Golden
+    g = Golden(os.path.join(GOLDEN_DIR, name + '.npz'))
+    d = dev()
+    model = build_model(g).to(d)
+    logp = model.log_marginal(g.response.to(d).unsqueeze(2), g.mask.to(d).bool().unsqueeze(2),
+                              num_samples=g.meta['num_samples'], eps_item=g.eps_item.to(d), eps_ability=g.eps_ability.to(d))
+    ref = float(g.out['logp'])
+    assert abs(float(logp) - ref) < 1e-4 * max(1.0, abs(ref))

@@ -6,7 +6,9 @@ assertions run against the real HIP kernel in tests/test_gpu_parity.py."""
 import pytest
 import torch
 
-from conftest import rel_err
+import os
+
+from conftest import GOLDEN_DIR, Golden, rel_err
 from oracle import cpu_backend
 from oracle import vibo_oracle as O
 from oracle import vibo_table_ref as T
@@ -167,3 +169,15 @@ def test_table_ref_matches_autograd_oracle(golden):
     assert rel_err(out['g_table'][0], g_t0) < 1e-8
     assert rel_err(out['g_table'][1], g_t1) < 1e-8
     assert rel_err(out['g_item'], g_i0) < 1e-8
+
+
+@pytest.mark.parametrize('name', ['logmarg_2pl_a2', 'logmarg_3pl_a1_cond_flows2'])
+def test_log_marginal_matches_reference_golden(name, cpu_ops):
+    """model.log_marginal (models.py:445-504) under the reference's recorded noise sequence; host logic on the CPU
+    stand-in backend (one forward per sample)."""
+    g = Golden(os.path.join(GOLDEN_DIR, name + '.npz'))
+    model = build_model(g)
+    logp = model.log_marginal(g.response.unsqueeze(2), g.mask.long().unsqueeze(2), num_samples=g.meta['num_samples'],
+                              eps_item=g.eps_item, eps_ability=g.eps_ability)
+    ref = float(g.out['logp'])
+    assert abs(float(logp) - ref) < 1e-4 * max(1.0, abs(ref))

@@ -11,6 +11,7 @@
 #include "vibo_cond.hpp"
 #include "vibo_general.hpp"
 #include "vibo_launch.hpp"
+#include "vibo_multi.hpp"
 #include "vibo_params.hpp"
 
 namespace vibo {
@@ -341,6 +342,38 @@ __global__ __launch_bounds__(64 * kFinSlices) void finalize_kernel(const Finaliz
     }
 }
 
+// multi-sample forward: out_scalars[s][8] from the per-block records (8 scalars per sample at record[8 s ..])
+__global__ __launch_bounds__(1024) void multi_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out_scalars,
+                                                              int nblk, int stride, int n_samples, int reg_mode) {
+    __shared__ double part[32][32];
+    const int e = threadIdx.x & 31, slice = threadIdx.x >> 5;      // e = 8 s + k
+    double acc = 0.0;
+    if (e < 8 * n_samples)
+        for (int b = slice; b < nblk; b += 32) acc += (double)partial[(size_t)b * stride + e];
+    part[slice][e] = acc;
+    __syncthreads();
+    if (slice == 0) {
+        double t = 0.0;
+        for (int s = 0; s < 32; ++s) t += part[s][e];
+        part[0][e] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < n_samples) {
+        const int s = threadIdx.x;
+        const double ll = part[0][8 * s + 0], kl = part[0][8 * s + 1], logq0 = part[0][8 * s + 2];
+        const double logp = part[0][8 * s + 3], ladj = part[0][8 * s + 4];
+        float* o = out_scalars + 8 * s;
+        o[VIBO_S_LL] = (float)ll;
+        o[VIBO_S_REG] = (float)(reg_mode == VIBO_REG_KL ? kl : (logq0 - ladj - logp));
+        o[VIBO_S_KL] = (float)kl;
+        o[VIBO_S_LOGQ0] = (float)logq0;
+        o[VIBO_S_LOGP] = (float)logp;
+        o[VIBO_S_LADJ] = (float)ladj;
+        o[VIBO_S_NOBS] = (float)part[0][8 * s + 5];
+        o[VIBO_S_RESERVED] = 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // forward-only encode: one wave per person (models.py:356-371 under no_grad)
 // ---------------------------------------------------------------------------
@@ -601,6 +634,101 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     hipLaunchKernelGGL(finalize_kernel, dim3((n_out + 63) / 64), dim3(64 * kFinSlices), 0, s, f);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "finalize launch");
+    return 0;
+}
+
+// plan of a multi-sample forward: the single-launch plan with want_grad = 0, restricted to the row-split paths
+static int multi_plan(const vibo_desc* d, vibo_desc* d0, Plan* pl, size_t* prep_bytes) {
+    *d0 = *d;
+    d0->want_grad = 0;
+    const int stride = make_plan(d0, pl);
+    if (stride < 0) return stride;
+    // conditional posterior: the expert table itself depends on the item sample, nothing is shared between samples
+    if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) return fail(-8, "multi-sample forward: conditional posterior (one table per sample)");
+    if (pl->general || !(pl->split_ok || pl->panels > 0)) return fail(-8, "multi-sample forward: shape is not on the row-split path");
+    *prep_bytes = ((size_t)((d->num_item + 15) & ~15) * pl->DP * 4 + 255) & ~(size_t)255;
+    return 0;
+}
+
+size_t vibo_multi_workspace_bytes(const vibo_desc* d, int num_samples) {
+    if (check_desc(d) != 0 || num_samples < 1) return 0;
+    vibo_desc d0;
+    Plan pl;
+    size_t prep = 0;
+    if (multi_plan(d, &d0, &pl, &prep) != 0) return 0;
+    return pl.total_bytes + 4 * prep;
+}
+
+int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* response, const void* mask,
+                            const int64_t* row_index, const float* table, const float* item, const float* eps,
+                            const float* flow, float* out_scalars, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (num_samples < 1) return fail(-3, "num_samples must be >= 1");
+    if (!response || !table || !item || !eps || !out_scalars) return fail(-5, "null required pointer");
+    if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
+    if (d->n_flows > 0 && !flow) return fail(-5, "flows need flow");
+    vibo_desc d0;
+    Plan pl;
+    size_t prep = 0;
+    rc = multi_plan(d, &d0, &pl, &prep);
+    if (rc) return rc;
+    if (!workspace || workspace_bytes < pl.total_bytes + 4 * prep) return fail(-7, "workspace too small");
+    if ((uintptr_t)workspace & 255) return fail(-7, "workspace must be 256-byte aligned");
+    const int I = d->num_item, A = d->ability_dim;
+    bool vec = rows_chunkable(d) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
+    if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
+    if (!vec) return fail(-8, "multi-sample forward: rows are not 16-byte chunkable");
+    hipStream_t s = (hipStream_t)stream;
+    char* wsb = static_cast<char*>(workspace);
+    float* partial = reinterpret_cast<float*>(wsb + pl.off_partial);
+    float* item_prep = reinterpret_cast<float*>(wsb + pl.total_bytes);       // up to 4 prepped tables
+    const int panels = pl.panels > 0 ? pl.panels : 1;
+    const int nblk = pl.split_nblk;
+
+    MultiParams mp;
+    memset(&mp, 0, sizeof(mp));
+    ElboParams& p = mp.e;
+    p.response = response; p.mask = mask; p.row_index = row_index; p.table = table; p.item_prep = item_prep;
+    p.resp_stride = d->response_row_stride; p.mask_stride = d->mask_row_stride;
+    p.B = d->num_person; p.I = I; p.A = A; p.D = pl.D; p.DP = pl.DP;
+    p.mask_dtype = d->mask_dtype; p.missing_mode = d->missing_mode; p.reg_mode = d->reg_mode;
+    p.flow = flow; p.n_flows = d->n_flows; p.lay = pl.lay; p.I_total = I; p.primary = 1;
+    mp.item_sstride = (long long)(prep / 4);
+    mp.eps_sstride = (long long)d->num_person * A;
+    hipError_t e = hipSuccess;
+    if (pl.panels > 0) {                       // sample-independent: whole-row counts
+        int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
+        int cgrid = g_num_cu * 8;
+        if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
+        hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
+                           (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
+        e = hipGetLastError();
+        p.row_cnt = cnt;
+    }
+    if (e != hipSuccess) return hip_fail(e, "multi-sample forward: pre-pass launch");
+    const int sc_max = pl.AT <= 4 ? 4 : 2;
+    for (int s0 = 0; s0 < num_samples;) {
+        const int rem = num_samples - s0;
+        const int sc = rem >= 4 && sc_max >= 4 ? 4 : rem >= 2 ? 2 : 1;
+        for (int k = 0; k < sc; ++k)
+            hipLaunchKernelGGL(item_prep_kernel, dim3((I + 15 + 255) / 256), dim3(256), 0, s, item + (size_t)(s0 + k) * I * pl.D,
+                               item_prep + (size_t)k * (prep / 4), I, A, pl.AT, pl.D, pl.DP, d->irt_model);
+        p.eps = eps + (size_t)s0 * d->num_person * A;
+        for (int pn = 0; pn < panels && e == hipSuccess; ++pn) {
+            p.item0 = pn * 1024;
+            p.I = pl.panels > 0 ? (I - p.item0 < 1024 ? I - p.item0 : 1024) : I;
+            p.primary = pn == 0 ? 1 : 0;
+            p.partial = partial + (size_t)pn * nblk * pl.lay.stride;
+            e = launch_elbo_multi(mp, pl.AT, d->irt_model, sc, (p.I + 255) / 256, nblk, s);
+        }
+        if (e != hipSuccess) return hip_fail(e, "multi-sample forward launch");
+        hipLaunchKernelGGL(multi_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, out_scalars + (size_t)s0 * VIBO_NUM_SCALARS,
+                           panels * nblk, pl.lay.stride, sc, d->reg_mode);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "multi-sample finalize launch");
+        s0 += sc;
+    }
     return 0;
 }
 

@@ -43,7 +43,8 @@ class ViboDesc(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
-                    'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal')
+                    'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
+                    'vibo_elbo_multi_forward')
 
 _lib = None
 
@@ -86,6 +87,10 @@ def load():
     lib.vibo_train_epilogue.argtypes = [dp, ctypes.c_int] + [fp] * 6 + [vp] + [fp] * 8 + [vp]
     lib.vibo_fill_normal.restype = ctypes.c_int
     lib.vibo_fill_normal.argtypes = [fp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_uint32, vp]
+    lib.vibo_multi_workspace_bytes.restype = ctypes.c_size_t
+    lib.vibo_multi_workspace_bytes.argtypes = [dp, ctypes.c_int]
+    lib.vibo_elbo_multi_forward.restype = ctypes.c_int
+    lib.vibo_elbo_multi_forward.argtypes = [dp, ctypes.c_int, fp, vp, i64p, fp, fp, fp, fp, fp, vp, ctypes.c_size_t, vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

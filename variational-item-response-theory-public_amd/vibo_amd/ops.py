@@ -194,6 +194,29 @@ def _hip_launch_elbo(spec, response, mask, mask_code, row_index, table, item, ep
                    ability_k=ability_k, ability_ladj=ladj)
 
 
+def _hip_multi_forward(spec, response, mask, mask_code, row_index, table, items, eps, flow, reg_mode, num_person):
+    """vibo_elbo_multi_forward: S forward evaluations in one pass.  items [S,I,D], eps [S,B,A] -> scalars [S,8], or
+    None when the configuration is not on the row-split path (the caller then loops over single launches)."""
+    lib = _lib.load()
+    _require_device(response, mask, table, items, eps)
+    S, B, I = int(items.shape[0]), int(num_person), response.shape[1]
+    d = _make_desc(spec, B, I, mask_code, reg_mode, False, response.stride(0), mask.stride(0) if mask is not None else 0)
+    ws_bytes = lib.vibo_multi_workspace_bytes(ctypes.byref(d), S)
+    if ws_bytes == 0:
+        return None
+    dev = response.device
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(S, _lib.NUM_SCALARS, dtype=torch.float32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.vibo_elbo_multi_forward(ctypes.byref(d), S, _ptr(response), _ptr(mask), _ptr(row_index), _ptr(table),
+                                     _ptr(items), _ptr(eps), _ptr(flow), _ptr(out), _ptr(ws), ctypes.c_size_t(ws_bytes),
+                                     stream)
+    if rc == -8:
+        return None
+    _lib.check(rc, 'vibo_elbo_multi_forward')
+    return out
+
+
 def _hip_encode(spec, response, mask, mask_code, row_index, table, num_person):
     lib = _lib.load()
     _require_device(response, mask, table)
@@ -223,7 +246,7 @@ def _hip_decode(spec, ability, item):
 
 # The three entry points of the native library.  tests/ swap these for the CPU
 # oracle to exercise the host logic without a GPU (never done by product code).
-_BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode}
+_BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward}
 
 
 class FusedELBO(torch.autograd.Function):

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib
+from .. import _lib, ops
 from ..ops import ElboSpec, decode_probs, encode_posterior, fused_elbo, item_feat_dim
 
 LOG_2PI = math.log(2.0 * math.pi)
@@ -332,19 +332,60 @@ class VIBO_1PL(nn.Module):
         log_p_d = _std_normal_logpdf(item_feat).sum()
         return -(ll + log_p_d - reg - log_q_d)
 
-    def log_marginal(self, response, mask, num_samples=100):
-        """Importance-weighted bound with batch-level weights (models.py:445-504)."""
+    def log_marginal(self, response, mask, num_samples=100, eps_item=None, eps_ability=None):
+        """Importance-weighted bound with batch-level weights (models.py:445-504).  eps_item [S,I,D] / eps_ability
+        [S,B,A] replay a fixed noise sequence (tests); by default it is drawn item-then-ability per sample like the
+        reference's loop.  Unconditional posterior: the S forwards share one pass over the responses
+        (vibo_elbo_multi_forward); otherwise one forward launch per sample."""
         with torch.no_grad():
+            S = int(num_samples)
+            if not self.conditional_posterior:
+                log_w = self._log_weights_multi(response, mask, S, eps_item, eps_ability)
+                if log_w is not None:
+                    return torch.logsumexp(log_w, 0) - math.log(S)
             log_w = []
-            for _ in range(num_samples):
-                ctx = self._run_fused(response, mask, reg_mode=_lib.REG_SAMPLED)
+            for s in range(S):
+                ctx = self._run_fused(response, mask, reg_mode=_lib.REG_SAMPLED,
+                                      eps_item=None if eps_item is None else eps_item[s],
+                                      eps_ability=None if eps_ability is None else eps_ability[s])
                 log_q_d = _normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum()
                 if ctx.item_ladj is not None:
                     log_q_d = log_q_d - ctx.item_ladj.sum()
                 log_p_d = _std_normal_logpdf(ctx.item_k).sum()
                 log_w.append(ctx.ll + log_p_d - ctx.reg - log_q_d)
             log_w = torch.stack(log_w)
-            return torch.logsumexp(log_w, 0) - math.log(num_samples)
+            return torch.logsumexp(log_w, 0) - math.log(S)
+
+    def _log_weights_multi(self, response, mask, S, eps_item, eps_ability):
+        """log w_s for s < S through the multi-sample forward kernel, or None if the configuration is not covered."""
+        response = ops.prepare_response(response)
+        mask2, code = ops.prepare_mask(mask)
+        if code == _lib.MASK_I64:
+            return None
+        B = response.shape[0]
+        item_mu, item_lv = self.item_encoder()
+        items, log_qd, log_pd, eps_ab = [], [], [], []
+        for s in range(S):                      # draw order of the reference's loop: item eps, then ability eps
+            e_i = self._randn(item_mu.shape, item_mu, self._item_gen) if eps_item is None else eps_item[s]
+            item_feat = e_i * torch.exp(0.5 * item_lv) + item_mu
+            lq = _normal_logpdf(item_feat, item_mu, item_lv).sum()
+            item_k = item_feat
+            if self.n_norm_flows > 0:
+                item_k, item_ladj = self.item_norm_flows(item_feat)
+                lq = lq - item_ladj.sum()
+            items.append(item_k)
+            log_qd.append(lq)
+            log_pd.append(_std_normal_logpdf(item_k).sum())
+            eps_ab.append(self._randn((B, self.ability_dim), item_mu, self._ability_gen)
+                          if eps_ability is None else eps_ability[s])
+        table = self.ability_encoder.expert_table(None)
+        flow_packed = self.ability_norm_flows.packed() if self.n_norm_flows > 0 else None
+        sc = ops._BACKEND['multi'](self.spec, response, mask2, code, None, table.contiguous(),
+                                   torch.stack(items).contiguous(), torch.stack(eps_ab).contiguous(), flow_packed,
+                                   _lib.REG_SAMPLED, B)
+        if sc is None:
+            return None
+        return sc[:, _lib.S_LL] - sc[:, _lib.S_REG] + torch.stack(log_pd) - torch.stack(log_qd)
 
     # ---- fast path for training loops (no tuple round trip) -------------------
     def elbo_step(self, response, mask, annealing_factor=1.0, row_index=None):
