@@ -28,16 +28,10 @@ def dev():
     return torch.device('cuda:0')
 
 
-def kernel_supports(meta):
-    return True
-
-
 # ---------------------------------------------------------------------------
 # (1) goldens from the reference
 # ---------------------------------------------------------------------------
 def test_golden_through_module(golden):
-    if not kernel_supports(golden.meta):
-        pytest.skip('configuration not in the fused kernel yet')
     d = dev()
     model = build_model(golden).to(d)
     golden.response, golden.mask = golden.response.to(d), golden.mask.to(d)
@@ -48,8 +42,6 @@ def test_golden_through_module(golden):
 
 def test_golden_adam_trajectory(golden):
     """3 Adam steps through the HIP path land on the reference's parameters."""
-    if not kernel_supports(golden.meta):
-        pytest.skip('configuration not in the fused kernel yet')
     d = dev()
     model = build_model(golden).to(d)
     golden.response, golden.mask = golden.response.to(d), golden.mask.to(d)
@@ -115,15 +107,15 @@ SHAPES = [
     (2, 1, 200, 1000, 0.2),
     (2, 8, 130, 1000, 0.1),
     (2, 8, 64, 1024, 0.0),
-    (2, 4, 70, 600, 0.3),       # 16-wave geometry, partial item blocks
+    (2, 4, 70, 600, 0.3),       # 3 waves per row, last wave partly empty
     (2, 2, 33, 1016, 0.1),
-    (2, 2, 300, 304, 0.1),      # 4-wave geometry
-    (2, 8, 150, 144, 0.2),      # 2-wave geometry, red buffer > code tile
-    (2, 3, 257, 100, 0.2),      # 2-wave geometry, A padded 3 -> 4
+    (2, 2, 300, 304, 0.1),      # 2 waves per row
+    (2, 8, 150, 144, 0.2),      # 1 wave per row
+    (2, 3, 257, 100, 0.2),      # A padded 3 -> 4
     (2, 5, 65, 512, 0.0),       # A padded 5 -> 8
-    (2, 1, 31, 95, 0.2),        # ragged rows (I % 4 != 0): scalar load path
+    (2, 1, 31, 95, 0.2),        # ragged contiguous rows (I % 4 != 0): tiled kernel, scalar load path
     (2, 7, 100, 130, 0.1),
-    (2, 1, 5, 1, 0.0),          # single item
+    (2, 1, 5, 1, 0.0),          # single item (tiled kernel)
     (2, 2, 1, 7, 0.0),          # single person
     (1, 1, 100, 1000, 0.1),
     (1, 4, 77, 333, 0.2),
@@ -131,7 +123,7 @@ SHAPES = [
     (3, 8, 90, 640, 0.0),
     (3, 2, 50, 95, 0.3),
     (3, 6, 64, 1003, 0.1),
-    # row-split kernel (A >= 3, 1PL/2PL, 192 <= I <= 1024, I % 4 == 0): 1..4 waves per row
+    # more row-split shapes: 1..4 waves per row, batch tails
     (2, 3, 257, 256, 0.2),
     (2, 6, 41, 260, 0.1),
     (2, 8, 1001, 768, 0.1),
@@ -170,7 +162,8 @@ def test_mask_dtypes(mask_dtype, I):
 
 
 GENERAL_SHAPES = [
-    # irt, A, B, I, missing, cond, n_flows      (wave-per-person kernel: conditional / flows / > 1024 items)
+    # irt, A, B, I, missing, cond, n_flows      (conditional / flows / > 1024 items: row-split paths where the rows
+    # are 16-byte chunkable, wave-per-person kernel otherwise)
     (2, 1, 70, 1500, 0.2, False, 0),
     (2, 8, 33, 2048, 0.1, False, 0),
     (3, 2, 40, 1203, 0.1, False, 0),
