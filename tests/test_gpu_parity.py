@@ -70,10 +70,10 @@ def random_problem(irt, A, B, I, missing, seed, cond=False, scale=1.0):
 
 
 def run_kernel(spec, resp, mask, table, item, eps, reg_mode=_lib.REG_KL, mask_dtype=torch.bool,
-               row_index=None, want_grad=True):
+               row_index=None, want_grad=True, keep_int64=False):
     d = dev()
     r = ops.prepare_response(resp.to(d))
-    m, code = ops.prepare_mask(mask.to(d).to(mask_dtype) if mask is not None else None)
+    m, code = ops.prepare_mask(mask.to(d).to(mask_dtype) if mask is not None else None, keep_int64=keep_int64)
     ri = row_index.to(d) if row_index is not None else None
     B = int(ri.numel()) if ri is not None else r.shape[0]
     raw = ops._hip_launch_elbo(spec, r, m, code, ri, table.to(d).contiguous(), item.to(d).contiguous(),
@@ -148,17 +148,32 @@ def test_raw_kernel_vs_oracle(irt, A, B, I, missing, drop):
     compare_raw(raw, ref, (I, spec.item_dim))
 
 
-@pytest.mark.parametrize('mask_dtype', [torch.bool, torch.int64, torch.uint8, None])
-@pytest.mark.parametrize('I', [1000, 95])
-def test_mask_dtypes(mask_dtype, I):
-    irt, A, B = 2, 2, 150
+@pytest.mark.parametrize('mask_dtype,keep_int64', [(torch.bool, False), (torch.int64, False), (torch.int64, True),
+                                                   (torch.uint8, False), (None, False)])
+@pytest.mark.parametrize('I,A', [(1000, 2), (95, 2), (600, 5)])
+def test_mask_dtypes(mask_dtype, keep_int64, I, A):
+    """bool / uint8 in place; int64 narrowed once by ops.prepare_mask, or handed to the library as VIBO_MASK_I64
+    (wave-per-row kernel for A <= 2, tiled kernel otherwise)."""
+    irt, B = 2, 150
     spec = ElboSpec(irt_model=irt, ability_dim=A)
     resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.0 if mask_dtype is None else 0.25, seed=7)
     ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(),
                            irt_model=irt, ability_dim=A, mode='kl')
     raw = run_kernel(spec, resp, None if mask_dtype is None else mask, table, item, eps,
-                     mask_dtype=mask_dtype or torch.bool)
+                     mask_dtype=mask_dtype or torch.bool, keep_int64=keep_int64)
     compare_raw(raw, ref, (I, spec.item_dim))
+
+
+def test_int64_mask_is_narrowed_once_per_tensor():
+    d = dev()
+    mask = (torch.rand(64, 100, device=d) > 0.2).long()
+    a, code = ops.prepare_mask(mask)
+    b, _ = ops.prepare_mask(mask)
+    assert code == _lib.MASK_U8 and a.dtype == torch.uint8 and a.data_ptr() == b.data_ptr()      # cached
+    mask[0, 0] = 1 - mask[0, 0]                                                                    # in-place edit
+    c, _ = ops.prepare_mask(mask)
+    assert c.data_ptr() != a.data_ptr() and int(c[0, 0]) == int(mask[0, 0])
+    assert ops.prepare_mask(mask, keep_int64=True)[1] == _lib.MASK_I64
 
 
 GENERAL_SHAPES = [

@@ -9,6 +9,7 @@ produces the expert table, the item-side reparameterisation / flows / KL, the
 optimizer.  Everything O(B x I) is inside the HIP kernel.
 """
 import ctypes
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -82,10 +83,16 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def prepare_mask(mask):
-    """-> (2-D mask tensor the kernel can read, VIBO_MASK_* code).  bool / int64
-    masks are read in place (datasets.py:938 yields bool, vibo.py:240 converts to
-    int64); other dtypes are normalised to bool once."""
+_I64_MASK_CACHE = []       # [(weakref to the int64 tensor, its _version, uint8 copy)], newest last, at most 4
+
+
+def prepare_mask(mask, keep_int64=False):
+    """-> (2-D mask tensor the kernel can read, VIBO_MASK_* code).
+
+    bool / uint8 masks (datasets.py:938 yields bool) are read in place, strided rows included.  int64 masks (the
+    reference loop converts with `.long()`, vibo.py:240) cost 8 B per cell and are only understood by the fallback
+    kernels, so they are narrowed to uint8 once per tensor (identity-cached: a resident mask is converted a single
+    time); `keep_int64=True` hands them to the library unchanged (VIBO_MASK_I64)."""
     if mask is None:
         return None, _lib.MASK_NONE
     if mask.dim() == 3:
@@ -95,8 +102,16 @@ def prepare_mask(mask):
         if mask.stride(-1) != 1:
             mask = mask.contiguous()
         return (mask if mask.dtype == torch.uint8 else mask.view(torch.uint8)), _lib.MASK_U8
-    if mask.dtype == torch.int64:
+    if mask.dtype == torch.int64 and keep_int64:
         return mask.contiguous(), _lib.MASK_I64
+    if mask.dtype == torch.int64:
+        for ref, version, m8 in _I64_MASK_CACHE:
+            if ref() is mask and version == mask._version:
+                return m8, _lib.MASK_U8
+        m8 = (mask != 0).contiguous().view(torch.uint8)
+        _I64_MASK_CACHE[:] = [e for e in _I64_MASK_CACHE if e[0]() is not None and e[0]() is not mask][-3:]
+        _I64_MASK_CACHE.append((weakref.ref(mask), mask._version, m8))
+        return m8, _lib.MASK_U8
     return (mask != 0).contiguous().view(torch.uint8), _lib.MASK_U8
 
 
