@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box: rocprofv3 kernel-trace summaries of the non-headline kernel paths (tools/profile_kernel.py).
+# Writes gpurun_out/paths_profile.txt (text only).
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+S=$OUT/paths_profile.txt
+: > $S
+run() {
+  rm -rf /tmp/kt
+  echo "# rocprofv3 --kernel-trace --stats -- python tools/profile_kernel.py --iters 3 $*" >> $S
+  rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/tools/profile_kernel.py --iters 3 $* > /tmp/kt.log 2>&1
+  grep "terms/s" /tmp/kt.log >> $S
+  python $R/tools/rocpd_summary.py /tmp/kt/kt_results.db vibo | cut -c1-150 >> $S
+  echo >> $S
+}
+run --persons 1000000 --items 1000 --ability-dim 1 --irt 3
+run --persons 1000000 --items 1000 --ability-dim 1 --flows 4
+run --persons 1000000 --items 1000 --ability-dim 1 --cond
+run --persons 100000 --items 10000 --ability-dim 1
+run --persons 100000 --items 10000 --ability-dim 1 --irt 3 --cond --flows 4
+run --persons 535596 --items 96 --ability-dim 1 --missing 0.2
+run --persons 1000000 --items 1000 --ability-dim 8 --no-grad
+rm -rf /tmp/kt
+echo "wrote $S"

@@ -283,16 +283,19 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------
 // finalize: fixed-order sum of the per-block partial records (fp64 accumulate)
 // ---------------------------------------------------------------------------
-constexpr int kFinSlices = 16;       // slices of the block list per output (1024 threads = 64 outputs x 16 slices)
-__global__ __launch_bounds__(64 * kFinSlices) void finalize_kernel(const FinalizeParams f) {
+// 1024 threads = OUT outputs x (1024 / OUT) slices of the block list; OUT = 64 normally, 16 when there are many small
+// records (one-wave workgroups of the row-split kernel: up to 8 per CU)
+template <int OUT>
+__global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeParams f) {
+    constexpr int SLICES = 1024 / OUT;
     // element e of the logical output vector: [0,8) scalars | table grads | flow grads | item grads
     const int n_tab = 8 * f.A;
     const int n_flow = 2 * f.n_flows * (2 * f.A + 1);
     const int n_item = f.I * f.D;
     const int n_out = 8 + (f.want_grad ? n_tab + n_flow + n_item : 0);
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    __shared__ double part[kFinSlices][64];
+    const int lane = threadIdx.x % OUT, slice = threadIdx.x / OUT;
+    const int e = blockIdx.x * OUT + lane;
+    __shared__ double part[SLICES][OUT];
     double acc = 0.0;
     if (e < n_out) {
         int src, b0 = 0, b1 = f.nblk;
@@ -306,15 +309,15 @@ __global__ __launch_bounds__(64 * kFinSlices) void finalize_kernel(const Finaliz
             b0 = panel * f.bpp;
             b1 = b0 + f.bpp;
         }
-        // fixed order: slice s sums blocks s, s+16, ... in fp64, then the slices are summed in order
-        for (int b = b0 + slice; b < b1; b += kFinSlices) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
+        // fixed order: slice s sums blocks s, s+SLICES, ... in fp64, then the slices are summed in order
+        for (int b = b0 + slice; b < b1; b += SLICES) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
     }
     part[slice][lane] = acc;
     __syncthreads();
     if (slice == 0 && e < n_out) {
         double t = 0.0;
 #pragma unroll
-        for (int s = 0; s < kFinSlices; ++s) t += part[s][lane];
+        for (int s = 0; s < SLICES; ++s) t += part[s][lane];
         if (e < 8) {
             // partial scalars: 0 ll, 1 kl, 2 logq0, 3 logp, 4 ladj, 5 nobs
             part[0][lane] = t;
@@ -631,7 +634,8 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
     f.panel_items = panel_items; f.bpp = bpp ? bpp : nblk_used;
     const int n_out = 8 + (grad ? 8 * A + 2 * d->n_flows * (2 * A + 1) + I * pl.D : 0);
-    hipLaunchKernelGGL(finalize_kernel, dim3((n_out + 63) / 64), dim3(64 * kFinSlices), 0, s, f);
+    if (f.bpp >= 1024) hipLaunchKernelGGL(finalize_kernel<16>, dim3((n_out + 15) / 16), dim3(1024), 0, s, f);
+    else hipLaunchKernelGGL(finalize_kernel<64>, dim3((n_out + 63) / 64), dim3(1024), 0, s, f);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "finalize launch");
     return 0;
