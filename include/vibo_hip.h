@@ -159,6 +159,16 @@ int vibo_encode(const vibo_desc* d,
 int vibo_decode(const vibo_desc* d, const float* ability, const float* item,
                 float* response_mu, void* stream);
 
+/*
+ * Posterior-predictive mean: the mean over num_samples posterior draws of decode() (the S decode calls of
+ * sample_posterior_predictive, vibo.py:363-390, reduced the way the imputation-accuracy step consumes them,
+ * vibo.py:504-548) without materialising the [S][B][I] stack:
+ *     response_mu_mean[b][i] = (1/S) sum_s P(response = 1 | ability[s][b], item[s][i])
+ *  ability [S][B][A], item [S][I][D], response_mu_mean [B][I].
+ */
+int vibo_decode_mean(const vibo_desc* d, int num_samples, const float* ability, const float* item,
+                     float* response_mu_mean, void* stream);
+
 
 /*
  * Fused O(I) part of one VIBO train step (unconditional posterior, no flows), for trainers that want the whole

@@ -74,7 +74,11 @@ def install(ops):
     def multi(spec, response, mask, mask_code, row_index, table, items, eps, flow, reg_mode, num_person):
         return None          # "not covered": the module then loops over single forward launches
 
-    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi)
+    def decode_mean(spec, abilities, items):
+        from oracle.vibo_oracle import irt_link
+        return torch.stack([irt_link(spec.irt_model, abilities[s], items[s]) for s in range(abilities.shape[0])]).mean(0)
+
+    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean)
 
     def restore():
         ops._BACKEND.update(saved)

@@ -504,3 +504,15 @@ def test_log_marginal_golden_through_module(name):
                               num_samples=g.meta['num_samples'], eps_item=g.eps_item.to(d), eps_ability=g.eps_ability.to(d))
     ref = float(g.out['logp'])
     assert abs(float(logp) - ref) < 1e-4 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize('irt,A,B,I,S', [(2, 1, 100, 95, 7), (3, 2, 33, 200, 3), (1, 4, 9, 1000, 5), (2, 8, 17, 64, 2)])
+def test_decode_mean_kernel(irt, A, B, I, S):
+    """vibo_decode_mean = mean over S draws of decode (posterior predictive, vibo.py:363-390 / 504-548)."""
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    g = torch.Generator().manual_seed(B + I)
+    ab = torch.randn(S, B, A, generator=g)
+    it = torch.randn(S, I, spec.item_dim, generator=g)
+    ref = torch.stack([O.irt_link(irt, ab[s].double(), it[s].double()) for s in range(S)]).mean(0)
+    out = ops.decode_probs_mean(spec, ab.to(dev()), it.to(dev())).cpu().double()
+    assert float((out - ref).abs().max()) < 2e-6

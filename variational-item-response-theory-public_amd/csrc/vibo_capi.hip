@@ -461,6 +461,52 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ a
     out[b * I + i] = pr;
 }
 
+// posterior-predictive mean: thread = one item x 8 persons; per sample the item row is loaded once and reused for the
+// 8 persons (ability rows are wave-uniform scalar loads)
+__global__ __launch_bounds__(256) void decode_mean_kernel_strided(const float* __restrict__ ability, const float* __restrict__ item,
+                                                                  float* __restrict__ out, int S, int B, int B_total, int I, int A,
+                                                                  int D, int irt) {
+    constexpr int RB = 8;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b0 = (long long)blockIdx.y * RB;
+    float acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+    const bool ok = i < I;
+    for (int s = 0; s < S; ++s) {
+        const float* it = item + ((size_t)s * I + (ok ? i : 0)) * D;
+        float a[VIBO_MAX_ABILITY_DIM];
+#pragma unroll
+        for (int k = 0; k < VIBO_MAX_ABILITY_DIM; ++k) a[k] = (irt != 1 && k < A) ? it[k] : 0.f;
+        const float bb = irt == 1 ? it[0] : it[A];
+        float g = 0.f;
+        if (irt == 3) g = 1.0f / (1.0f + expf(-it[A + 1]));
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const long long b = b0 + r;
+            if (b >= B) break;
+            const float* th = ability + ((size_t)s * B_total + b) * A;      // sample stride = all persons
+            float logit = bb;
+            if (irt == 1) {
+                for (int k = 0; k < A; ++k) logit += th[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < VIBO_MAX_ABILITY_DIM; ++k)
+                    if (k < A) logit = fmaf(-a[k], th[k], logit);
+            }
+            float pr = 1.0f / (1.0f + expf(-logit));
+            if (irt == 3) pr = g + (1.0f - g) * pr;
+            acc[r] += pr;
+        }
+    }
+    if (ok) {
+        const float inv = 1.0f / (float)S;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (b0 + r < B) out[(b0 + r) * I + i] = acc[r] * inv;
+    }
+}
+
 }  // namespace vibo
 
 using namespace vibo;
@@ -733,6 +779,30 @@ int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* re
         if (e != hipSuccess) return hip_fail(e, "multi-sample finalize launch");
         s0 += sc;
     }
+    return 0;
+}
+
+int vibo_decode_mean(const vibo_desc* d, int num_samples, const float* ability, const float* item,
+                     float* response_mu_mean, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (num_samples < 1) return fail(-3, "num_samples must be >= 1");
+    if (!ability || !item || !response_mu_mean) return fail(-5, "null required pointer");
+    const int I = d->num_item, A = d->ability_dim, D = item_feat_dim(d->irt_model, A);
+    const long long B = d->num_person;
+    const long long by = (B + 7) / 8;
+    if (by > 65535LL * 32768) return fail(-3, "num_person too large");
+    // grid.y is limited to 65535: loop in chunks of 65535 * 8 persons
+    for (long long y0 = 0; y0 < by; y0 += 65535) {
+        const int ny = (int)((by - y0 < 65535) ? (by - y0) : 65535);
+        const long long p0 = y0 * 8;
+        const int nb = (int)((B - p0 < (long long)ny * 8) ? (B - p0) : (long long)ny * 8);
+        // ability rows of sample s start at ability + s * B * A: pass the full B as the sample stride via a shifted base
+        hipLaunchKernelGGL(decode_mean_kernel_strided, dim3((I + 255) / 256, ny), dim3(256), 0, (hipStream_t)stream,
+                           ability + p0 * A, item, response_mu_mean + p0 * I, num_samples, nb, (int)B, I, A, D, d->irt_model);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "decode_mean launch");
     return 0;
 }
 

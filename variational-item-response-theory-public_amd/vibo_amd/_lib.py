@@ -44,7 +44,7 @@ class ViboDesc(ctypes.Structure):
 
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
-                    'vibo_elbo_multi_forward')
+                    'vibo_elbo_multi_forward', 'vibo_decode_mean')
 
 _lib = None
 
@@ -91,6 +91,8 @@ def load():
     lib.vibo_multi_workspace_bytes.argtypes = [dp, ctypes.c_int]
     lib.vibo_elbo_multi_forward.restype = ctypes.c_int
     lib.vibo_elbo_multi_forward.argtypes = [dp, ctypes.c_int, fp, vp, i64p, fp, fp, fp, fp, fp, vp, ctypes.c_size_t, vp]
+    lib.vibo_decode_mean.restype = ctypes.c_int
+    lib.vibo_decode_mean.argtypes = [dp, ctypes.c_int, fp, fp, fp, vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

@@ -259,9 +259,23 @@ def _hip_decode(spec, ability, item):
     return out
 
 
+def _hip_decode_mean(spec, abilities, items):
+    """vibo_decode_mean: abilities [S,B,A], items [S,I,D] -> mean over S of P(response = 1) [B,I]."""
+    lib = _lib.load()
+    _require_device(abilities, items)
+    S, B, I = int(abilities.shape[0]), int(abilities.shape[1]), int(items.shape[1])
+    out = torch.empty(B, I, dtype=torch.float32, device=abilities.device)
+    d = _make_desc(spec, B, I, _lib.MASK_NONE, _lib.REG_KL, False, I, 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(abilities.device).cuda_stream)
+    rc = lib.vibo_decode_mean(ctypes.byref(d), S, _ptr(abilities), _ptr(items), _ptr(out), stream)
+    _lib.check(rc, 'vibo_decode_mean')
+    return out
+
+
 # The three entry points of the native library.  tests/ swap these for the CPU
 # oracle to exercise the host logic without a GPU (never done by product code).
-_BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward}
+_BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward,
+            'decode_mean': _hip_decode_mean}
 
 
 class FusedELBO(torch.autograd.Function):
@@ -339,6 +353,12 @@ def encode_posterior(spec, table, response, mask, row_index=None):
     mask, code = prepare_mask(mask)
     B = int(row_index.numel()) if row_index is not None else response.shape[0]
     return _BACKEND['encode'](spec, response, mask, code, row_index, table.detach().contiguous(), B)
+
+
+def decode_probs_mean(spec, abilities, items):
+    """Mean over S posterior draws of P(response = 1): abilities [S,B,A], items [S,I,D] -> [B,I]
+    (vibo.py:363-390 reduced as at :504-548, without the [S,B,I] stack)."""
+    return _BACKEND['decode_mean'](spec, abilities.detach().contiguous().float(), items.detach().contiguous().float())
 
 
 def decode_probs(spec, ability, item):

@@ -207,16 +207,12 @@ def posterior_predictive(model, data, args, batch_size, keep_samples):
             _, amu, alv, _, imu, ilv = model.encode(data.response, data.mask, row_index=rows)
             a_s = amu + torch.exp(0.5 * alv) * torch.randn((S,) + amu.shape, device=amu.device)
             i_s = imu + torch.exp(0.5 * ilv) * torch.randn((S,) + imu.shape, device=imu.device)
-            acc = torch.zeros(rows.numel(), data.num_item, device=data.device)
-            per = []
-            for s in range(S):
-                pr = model.decode(a_s[s], i_s[s]).squeeze(2)
-                acc += pr
-                if keep_samples:
-                    per.append(pr.cpu())
-            means.append((acc / S).cpu())
             if keep_samples:
+                per = [model.decode(a_s[s], i_s[s]).squeeze(2).cpu() for s in range(S)]
                 stacks.append(torch.stack(per))
+                means.append(stacks[-1].mean(0))
+            else:        # one kernel: mean over the S draws, no [S,B,I] intermediate (vibo_decode_mean)
+                means.append(ops.decode_probs_mean(model.spec, a_s, i_s).cpu())
     if keep_samples:
         return {'response': torch.cat(stacks, dim=1).unsqueeze(3)}
     return {'response': torch.cat(means, dim=0).unsqueeze(0).unsqueeze(3)}
