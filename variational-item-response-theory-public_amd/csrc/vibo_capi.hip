@@ -97,8 +97,9 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->panels = 0;
     pl->cond = false;
     const bool is_cond = d->posterior == VIBO_POSTERIOR_CONDITIONAL;
-    if (I >= 4 && I <= 65535 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
-        // panel mode: one row-split launch per 1024 items (the backward is linear in d LL/d theta, so the panels
+    if (I >= 4 && I <= 32767 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
+        // panel mode (item counts up to 32767: the whole-row counts are packed as n_correct << 16 | n_observed in an
+        // int): one row-split launch per 1024 items (the backward is linear in d LL/d theta, so the panels
         // backpropagate their partial sums independently).  Unconditional posterior: a row-count pass supplies the
         // whole-row counts.  Conditional posterior (any item count): cond_pre_kernel supplies the product-of-experts
         // sums, cond_post_kernel scatters the table gradient (vibo_cond.hip).  The wave-per-person kernel remains
