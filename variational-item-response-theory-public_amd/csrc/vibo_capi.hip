@@ -111,7 +111,7 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
         }
         pl->panels = (I + 1023) / 1024;
         pl->cond = is_cond;
-        const int at_min = d->irt_model == 3 ? 4 : 2;
+        const int at_min = 2;
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
         pl->split_nq = 4;
@@ -189,8 +189,8 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     // which stays for int64 masks.
     pl->split_ok = split_shape;
     pl->split_nq = (I + 255) / 256;
-    if (pl->split_ok) {       // the row-split kernel's narrowest template is 2 wide (4 for 3PL)
-        const int at_min = d->irt_model == 3 ? 4 : 2;
+    if (pl->split_ok) {       // the row-split kernel's narrowest template is 2 wide
+        const int at_min = 2;
         if (pl->AT < at_min) {
             pl->AT = at_min;
             pl->DP = prepped_item_width(d->irt_model, at_min);

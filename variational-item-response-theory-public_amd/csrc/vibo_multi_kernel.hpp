@@ -295,8 +295,7 @@ static hipError_t launch_multi_at(const MultiParams& mp, int irt, int sc, int nq
 #define VIBO_MULTI_IRT(SCV)                                                              \
     if (irt == 1) return launch_multi_flows<AT, 1, SCV>(mp, nq, grid, s);                  \
     if (irt == 2) return launch_multi_flows<AT, 2, SCV>(mp, nq, grid, s);                  \
-    if constexpr (AT >= 4) return launch_multi_flows<AT, 3, SCV>(mp, nq, grid, s);         \
-    return hipErrorInvalidValue;
+    return launch_multi_flows<AT, 3, SCV>(mp, nq, grid, s);
     if (sc == 1) { VIBO_MULTI_IRT(1) }
     if (sc == 2) { VIBO_MULTI_IRT(2) }
     if constexpr (AT <= 4) {

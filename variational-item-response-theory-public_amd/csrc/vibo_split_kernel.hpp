@@ -109,7 +109,10 @@ inline size_t split_lds_bytes(int nq, bool flows) {
 template <int AT, int IRT, bool GRAD, bool FLOWS, int NQT>
 __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
     constexpr int R = kSplitRows;
-    constexpr int RPB = 8 / AT > R ? R : 8 / AT;   // rows per d LL/d theta reduction group
+    // rows per d LL/d theta reduction group: 8 / AT fills the 8-value reduction; 3PL at width 2 takes half of that
+    // (its longer per-term math would otherwise keep 16 terms' temporaries live and spill)
+    constexpr int RPB = (IRT == 3 && AT == 2) ? 2 : 8 / AT;
+    constexpr int NVG = RPB * AT;                  // partial sums per group (<= 8)
     constexpr int G = R / RPB;
     constexpr int NE = R * AT;                     // (row, dim) lanes used by the per-person math
     constexpr int H = AT / 2;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
             t += dpp_f<0xb1>(t);                     // quad_perm [1,0,3,2]
             t += dpp_f<0x4e>(t);                     // quad_perm [2,3,0,1]
             t += dpp_f<0x141>(t);                    // row_half_mirror
-            if ((lane & 7) == 0) wl.gthp[g * 8 + (lane >> 3)] = t;
+            if ((lane & 7) == 0 && (lane >> 3) < NVG) wl.gthp[g * NVG + (lane >> 3)] = t;
         };
         auto do_group = [&](const int g, const GroupIn& gi, GroupIn& nxt) {
             if (g + 1 < G) fetch_group(g + 1, nxt);
@@ -642,12 +645,7 @@ template <int AT>
 static hipError_t launch_split_at(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s) {
     if (irt == 1) return grad ? launch_split_flows<AT, 1, true>(p, nq, grid, s) : launch_split_flows<AT, 1, false>(p, nq, grid, s);
     if (irt == 2) return grad ? launch_split_flows<AT, 2, true>(p, nq, grid, s) : launch_split_flows<AT, 2, false>(p, nq, grid, s);
-    // 3PL at template width 2 would unroll 4 rows x 4 items of the longer 3PL term math and spill: the planner
-    // (vibo_capi.hip make_plan) sends 3PL with ability_dim <= 2 to the width-4 template instead
-    if constexpr (AT >= 4)
-        return grad ? launch_split_flows<AT, 3, true>(p, nq, grid, s) : launch_split_flows<AT, 3, false>(p, nq, grid, s);
-    else
-        return hipErrorInvalidValue;
+    return grad ? launch_split_flows<AT, 3, true>(p, nq, grid, s) : launch_split_flows<AT, 3, false>(p, nq, grid, s);
 }
 
 }  // namespace vibo
