@@ -210,6 +210,8 @@ GENERAL_SHAPES = [
     (1, 1, 50, 192, 0.0, True, 0),
     (2, 3, 41, 1024, 0.3, True, 0),
     (3, 1, 9, 10000, 0.2, True, 4),
+    (2, 4, 15, 64, 0.1, True, 1),          # one-wave workgroups with 9 PoE sums per row (found by tools/fuzz_parity.py)
+    (2, 3, 64, 8, 0.0, True, 0),
 ]
 
 

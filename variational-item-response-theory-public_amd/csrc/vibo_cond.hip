@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
             if ((lane & 7) == 0) part[q][lane >> 3][k] = t;
         }
         __syncthreads();
-        if (tid < kCR * NV) {
-            const int r = tid / NV, k = tid % NV;
+        for (int e = tid; e < kCR * NV; e += blockDim.x) {     // (one-wave workgroups have fewer threads than outputs)
+            const int r = e / NV, k = e % NV;
             float t = 0.f;
             for (int w = 0; w < nq; ++w) t += part[w][r][k];
             const long long row = row0 + r;
