@@ -19,7 +19,8 @@ from vibo_amd.ops import ElboSpec
 ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
 ap.add_argument('--seed', type=int, default=0)
-ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed" of a reported failure')
+ap.add_argument('--target', choices=['elbo', 'multi'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
+ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only" of a reported failure')
 a = ap.parse_args()
 rng = random.Random(a.seed)
 d = torch.device('cuda:0')
@@ -29,6 +30,45 @@ def rel(x, y):
     x, y = torch.as_tensor(x, dtype=torch.float64), torch.as_tensor(y, dtype=torch.float64)
     return float((x - y).abs().max() / y.abs().max().clamp_min(1e-30))
 
+
+def fuzz_multi():
+    t0, n, worst = time.time(), 0, 0.0
+    while time.time() - t0 < a.seconds:
+        irt = rng.choice([1, 2, 2, 3])
+        A = rng.choice([1, 2, 3, 4, 5, 8])
+        I = rng.choice([4, 64, 100, 256, 260, 512, 1000, 1024, 1028, 2500])
+        B = rng.choice([1, 8, 9, 17, 64, 130])
+        S = rng.choice([1, 2, 3, 4, 5, 7, 9])
+        n_flows = rng.choice([0, 0, 2, 4])
+        missing = rng.choice([0.0, 0.2])
+        spec = ElboSpec(irt_model=irt, ability_dim=A, n_flows=n_flows)
+        g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+        resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=missing)
+        table = torch.randn(2, 2 * A, generator=g) * 0.7
+        items = torch.randn(S, I, spec.item_dim, generator=g) * 0.6
+        eps = torch.randn(S, B, A, generator=g)
+        fl = (torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5).to(d) if n_flows else None
+        r_, m_ = ops.pad_rows(resp.to(d), mask.bool().to(d))
+        r = ops.prepare_response(r_)
+        m, code = ops.prepare_mask(m_)
+        sc = ops._hip_multi_forward(spec, r, m, code, None, table.to(d), items.to(d), eps.to(d), fl, _lib.REG_SAMPLED, B)
+        assert sc is not None
+        for s_ in range(S):
+            one = ops._hip_launch_elbo(spec, r, m, code, None, table.to(d), items[s_].to(d).contiguous(), eps[s_].to(d).contiguous(),
+                                       fl, _lib.REG_SAMPLED, False, B)
+            x, y = sc[s_, :7].cpu().double(), one.scalars[:7].cpu().double()
+            e = float((x - y).abs().max()) / max(1.0, float(y.abs().max()))
+            worst = max(worst, e)
+            if not e < 3e-6:
+                print(f'FAIL multi irt={irt} A={A} B={B} I={I} S={S} flows={n_flows} missing={missing} sample={s_}: {e} {x} {y}')
+                sys.exit(1)
+        n += 1
+    print(f'fuzz multi ok: {n} random configurations, worst relative error {worst:.2e}')
+
+
+if a.target == 'multi':
+    fuzz_multi()
+    sys.exit(0)
 
 t0, n, worst = time.time(), 0, 0.0
 while time.time() - t0 < a.seconds:
@@ -46,16 +86,24 @@ while time.time() - t0 < a.seconds:
     # where single cells carry O(1) gradients, so keep 3PL and wide abilities away from it
     scale = rng.choice([0.5, 1.0, 3.0]) if (irt != 3 and A <= 2) else rng.choice([0.3, 0.6])
     dataseed = rng.randrange(1 << 30)
+    gather = rng.random() < 0.3          # minibatch as a row-index vector over a larger resident matrix
+    no_mask = missing == 0.0 and rng.random() < 0.3
+    fwd_only = rng.random() < 0.2
     if a.replay:
         f = a.replay.split()
         irt, A, B, I, n_flows, dataseed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])
         cond, drop, pad, missing, scale = f[4] == 'True', f[6] == 'True', f[8] == 'True', float(f[7]), float(f[9])
+        gather, no_mask, fwd_only = f[11] == 'True', f[12] == 'True', f[13] == 'True'
     spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, drop_missing=drop, n_flows=n_flows)
     g = torch.Generator().manual_seed(dataseed)
-    resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=missing)
+    P = B + rng.choice([3, 50]) if gather else B
+    resp_all, mask_all = O.simulate_responses(irt, P, I, A, generator=g, missing_frac=missing)
+    rows = torch.randint(0, P, (B,), generator=g) if gather else None
+    resp, mask = (resp_all[rows], mask_all[rows]) if gather else (resp_all, mask_all)
     if drop and missing > 0:
-        mask[:, 0] = 1
-        resp[:, 0] = resp[:, 0].clamp(min=0)
+        mask_all[:, 0] = 1
+        resp_all[:, 0] = resp_all[:, 0].clamp(min=0)
+        resp, mask = (resp_all[rows], mask_all[rows]) if gather else (resp_all, mask_all)
     D = O.item_feat_dim(irt, A)
     table = torch.randn((2, I, 2 * A) if cond else (2, 2 * A), generator=g) * 0.7
     item = torch.randn(I, D, generator=g) * scale
@@ -72,12 +120,12 @@ while time.time() - t0 < a.seconds:
     mode = 'sampled' if n_flows else 'kl'
     ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt, ability_dim=A,
                            conditional_posterior=cond, replace_missing_with_prior=not drop, mode=mode, flow_uhat_w_b=flows)
-    r_, m_ = (ops.pad_rows(resp.to(d), mask.bool().to(d)) if pad else (resp.to(d), mask.bool().to(d)))
+    r_, m_ = (ops.pad_rows(resp_all.to(d), mask_all.bool().to(d)) if pad else (resp_all.to(d), mask_all.bool().to(d)))
     r = ops.prepare_response(r_)
-    m, code = ops.prepare_mask(m_)
-    raw = ops._hip_launch_elbo(spec, r, m, code, None, table.to(d).contiguous(), item.to(d).contiguous(), eps.to(d).contiguous(),
-                               flow.to(d).contiguous() if flow is not None else None,
-                               _lib.REG_SAMPLED if n_flows else _lib.REG_KL, True, B)
+    m, code = ops.prepare_mask(None if no_mask else m_)
+    raw = ops._hip_launch_elbo(spec, r, m, code, rows.to(d) if gather else None, table.to(d).contiguous(), item.to(d).contiguous(),
+                               eps.to(d).contiguous(), flow.to(d).contiguous() if flow is not None else None,
+                               _lib.REG_SAMPLED if n_flows else _lib.REG_KL, not fwd_only, B)
     torch.cuda.synchronize()
     sc = raw.scalars.cpu()
     errs = {
@@ -85,12 +133,13 @@ while time.time() - t0 < a.seconds:
         'reg': abs(float(sc[_lib.S_REG]) - float(ref['reg'])) / max(1.0, abs(float(ref['reg']))),
         'mu': float((raw.ability_mu.cpu() - ref['ability_mu'].float()).abs().max()) / max(1.0, float(ref['ability_mu'].abs().max())),
         'theta': float((raw.ability.cpu() - ref['ability'].float()).abs().max()) / max(1.0, float(ref['ability'].abs().max())),
-        'g_item': rel(raw.grad_item((I, D)).cpu(), ref['g_item']),
     }
-    for s_ in range(2):
+    if not fwd_only:
+        errs['g_item'] = rel(raw.grad_item((I, D)).cpu(), ref['g_item'])
+    for s_ in range(0 if fwd_only else 2):
         if float(ref['g_table'][s_].abs().max()) > 0:
             errs[f'g_table{s_}'] = rel(raw.grad_table(s_).cpu(), ref['g_table'][s_])
-    if n_flows:
+    if n_flows and not fwd_only:
         for s_ in range(2):
             gref = torch.cat([torch.cat(gf) for gf in ref['g_flow'][s_]]).float()
             if float(gref.abs().max()) > 0:
@@ -103,7 +152,7 @@ while time.time() - t0 < a.seconds:
         print('replayed:', errs)
         sys.exit(1 if bad else 0)
     if bad:
-        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad}: {bad}')
+        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only}: {bad}')
         print(f'replay: --replay "{irt} {A} {B} {I} {cond} {n_flows} {drop} {missing} {pad} {scale} {dataseed}"')
         sys.exit(1)
 print(f'fuzz ok: {n} random configurations, worst relative error {worst:.2e}')

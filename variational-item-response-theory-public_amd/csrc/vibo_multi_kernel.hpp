@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256, 2) void multi_forward_kernel(const MultiParams
     float s_log[SC], s_logq0[SC], s_logp[SC], s_ladj[SC];
 #pragma unroll
     for (int s = 0; s < SC; ++s) s_log[s] = s_logq0[s] = s_logp[s] = s_ladj[s] = 0.f;
-    float s_corr = 0.f, s_kl = 0.f, s_nobs = 0.f;
+    float s_kl = 0.f, s_nobs = 0.f;
+    int unobs = 0;
     __syncthreads();
     const float tau0 = cl.ctab[(0 * 2 + 0) * AT + ed], tau1 = cl.ctab[(0 * 2 + 1) * AT + ed];
     const float mt0 = cl.ctab[(1 * 2 + 0) * AT + ed], mt1 = cl.ctab[(1 * 2 + 1) * AT + ed];
@@ -149,9 +150,12 @@ __global__ __launch_bounds__(256, 2) void multi_forward_kernel(const MultiParams
         __builtin_amdgcn_sched_barrier(0);
         {
             const int tot = bfly8(pk, lane);
-            if ((lane & 7) == 0) {
-                wl.cntp[par][lane >> 3] = tot;
-                if constexpr (IRT != 3) s_corr += (float)(256 - (tot & 0xffff));   // log2(1 + 2^0) of unobserved cells
+            if ((lane & 7) == 0) wl.cntp[par][lane >> 3] = tot;
+            if constexpr (IRT != 3) {      // this lane's unobserved cells: each adds exactly log2(1 + 2^0) = 1 below
+                int obs8 = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) obs8 += pk[r];
+                unobs += 4 * R - (obs8 & 0xffff);
             }
         }
         __syncthreads();
@@ -262,11 +266,10 @@ __global__ __launch_bounds__(256, 2) void multi_forward_kernel(const MultiParams
 
     // ================= workgroup reduction -> partial record: 8 scalars per sample ======
     float* out = p.partial + (size_t)blockIdx.x * p.lay.stride;
-    const float t_corr = wave_total(s_corr), t_kl = wave_total(s_kl), t_no = wave_total(s_nobs);
+    const float t_kl = wave_total(s_kl), t_no = wave_total(s_nobs);
 #pragma unroll
     for (int s = 0; s < SC; ++s) {
-        const float tl = wave_total(s_log[s]);
-        const float ll = (IRT == 3) ? kLn2 * tl : -kLn2 * (tl - t_corr);
+        const float ll = (IRT == 3) ? kLn2 * wave_total(s_log[s]) : -kLn2 * wave_total(s_log[s] - (float)unobs);
         const float t_q0 = wave_total(s_logq0[s]), t_lp = wave_total(s_logp[s]), t_la = wave_total(s_ladj[s]);
         if (lane == 0) {
             wl.red[s][0] = ll; wl.red[s][1] = t_kl; wl.red[s][2] = t_q0; wl.red[s][3] = t_lp; wl.red[s][4] = t_la;

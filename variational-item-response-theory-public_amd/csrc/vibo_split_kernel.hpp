@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc_t[k] = 0.f;
     float s_log = 0.f, s_kl = 0.f, s_logq0 = 0.f, s_logp = 0.f, s_nobs = 0.f, s_ladj = 0.f;
+    int unobs = 0;                        // unobserved cells of this lane so far (1PL/2PL log-lik correction)
     __syncthreads();
     const float tau0 = cl.ctab[(0 * 2 + 0) * AT + ed], tau1 = cl.ctab[(0 * 2 + 1) * AT + ed];
     const float mt0 = cl.ctab[(1 * 2 + 0) * AT + ed], mt1 = cl.ctab[(1 * 2 + 1) * AT + ed];
@@ -255,11 +256,15 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
         __builtin_amdgcn_sched_barrier(0);
         {
             const int tot = bfly8(pk, lane);
-            if ((lane & 7) == 0) {
-                wl.cntp[lane >> 3] = tot;
-                // 1PL/2PL: every lane-cell without an observation (missing, padding, rows past the end)
-                // contributes log2(1 + 2^0) = 1 to the running log-lik sum below: take those out, once per row
-                if constexpr (IRT != 3) s_log -= (float)(256 - (tot & 0xffff));
+            if ((lane & 7) == 0) wl.cntp[lane >> 3] = tot;
+            // 1PL/2PL: every cell of this lane without an observation (missing, padding, rows past the end) contributes
+            // exactly log2(1 + 2^0) = 1 to the lane's running log-lik sum below: count them (integers, exact) and
+            // take them out of the lane's own sum at the end, so that the sums only ever hold real contributions
+            if constexpr (IRT != 3) {
+                int obs8 = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) obs8 += pk[r];
+                unobs += 4 * R - (obs8 & 0xffff);
             }
         }
         __syncthreads();
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
     // ================= workgroup reduction -> partial record ======
     float* out = p.partial + (size_t)blockIdx.x * p.lay.stride;
     {
-        const float ll = (IRT == 3 ? kLn2 : -kLn2) * wave_total(s_log);
+        const float ll = (IRT == 3 ? kLn2 : -kLn2) * wave_total(s_log - (float)unobs);
         const float t_kl = wave_total(s_kl), t_q0 = wave_total(s_logq0), t_lp = wave_total(s_logp);
         const float t_no = wave_total(s_nobs), t_la = wave_total(s_ladj);
         if (lane == 0) {
