@@ -293,9 +293,10 @@ def test_forward_only_matches_forward_of_train(irt, A, B, I, cond, n_flows):
     torch.cuda.synchronize()
     a, b = outs
     assert rel_err(b.scalars[:7].cpu(), a.scalars[:7].cpu()) < 1e-6
-    assert torch.equal(a.ability_mu, b.ability_mu) and torch.equal(a.ability, b.ability)
+    # two template instantiations of the same source: the compiler may contract a*b+c differently, so last-bit equal
+    assert float((a.ability_mu - b.ability_mu).abs().max()) < 1e-6 and float((a.ability - b.ability).abs().max()) < 1e-6
     if n_flows:
-        assert torch.equal(a.ability_k, b.ability_k)
+        assert float((a.ability_k - b.ability_k).abs().max()) < 2e-6
 
 
 def test_all_missing_rows_and_saturated_logits():
