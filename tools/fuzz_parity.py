@@ -19,7 +19,7 @@ from vibo_amd.ops import ElboSpec
 ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
 ap.add_argument('--seed', type=int, default=0)
-ap.add_argument('--target', choices=['elbo', 'multi'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
+ap.add_argument('--target', choices=['elbo', 'multi', 'module'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
 ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only" of a reported failure')
 a = ap.parse_args()
 rng = random.Random(a.seed)
@@ -66,8 +66,98 @@ def fuzz_multi():
     print(f'fuzz multi ok: {n} random configurations, worst relative error {worst:.2e}')
 
 
+def fuzz_module():
+    """Drop-in modules on the GPU (forward -> elbo -> backward, the reference call pattern) vs autograd through the
+    op-by-op CPU oracle in fp64, on random configurations: loss and every parameter gradient."""
+    from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
+    t0, n, worst = time.time(), 0, 0.0
+    while time.time() - t0 < a.seconds:
+        irt = rng.choice([1, 2, 2, 3])
+        A = rng.choice([1, 1, 2, 3, 4, 8])
+        I = rng.choice([8, 95, 100, 256, 260, 1000, 1028, 2500])
+        B = rng.choice([1, 8, 9, 17, 64])
+        cond = rng.random() < 0.3
+        n_flows = rng.choice([0, 0, 2, 4])
+        drop = rng.random() < 0.3
+        missing = rng.choice([0.0, 0.2])
+        beta = rng.choice([1.0, 0.5])
+        if irt == 3:          # 3PL: clamp-band chaos grows with the logit spread (see above): narrow abilities, no flows
+            A, n_flows = min(A, 2), 0
+        use_kl = n_flows == 0 and rng.random() < 0.7
+        seed = rng.randrange(1 << 30)
+        if a.replay:      # "irt A B I cond flows drop missing beta use_kl seed"
+            f = a.replay.split()
+            irt, A, B, I, n_flows, seed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])
+            cond, drop, use_kl, missing, beta = f[4] == 'True', f[6] == 'True', f[9] == 'True', float(f[7]), float(f[8])
+        torch.manual_seed(seed)
+        cls = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt]
+        model = cls(A, I, hidden_dim=16, ability_merge='product', conditional_posterior=cond,
+                    replace_missing_with_prior=not drop, n_norm_flows=n_flows)
+        with torch.no_grad():      # keep the logits out of the Bernoulli clamp band (fp32 decisions there are chaotic,
+            # in the reference as well: the saturation golden pins the exact 1PL/2PL semantics separately)
+            model.item_encoder.mu_lookup.weight.mul_(0.3)
+            model.item_encoder.logvar_lookup.weight.mul_(0.3).sub_(2.0)
+            for name, prm in model.named_parameters():       # small posterior means, well-conditioned flows: |logit| < ~8
+                if name.endswith('mlp.4.weight'):
+                    prm.mul_(0.2)
+                elif '_norm_flows' in name and name.endswith('.w'):      # uhat ~ w / |w|^2: keep |w| away from 0
+                    prm.copy_(torch.sign(prm) * (0.5 + prm.abs()) / prm.numel() ** 0.5)
+                elif '_norm_flows' in name and name.endswith('.u'):
+                    prm.mul_(0.5)
+        g = torch.Generator().manual_seed(seed + 1)
+        resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=missing)
+        if drop and missing > 0:
+            mask[:, 0] = 1
+            resp[:, 0] = resp[:, 0].clamp(min=0)
+        eps_item = torch.randn(I, O.item_feat_dim(irt, A), generator=g)
+        eps_ab = torch.randn(B, A, generator=g)
+        cfg = dict(irt_model=irt, ability_dim=A, conditional_posterior=cond, replace_missing_with_prior=not drop,
+                   n_norm_flows=n_flows, annealing_factor=beta, use_kl_divergence=use_kl)
+        # fp32 like the reference: the Bernoulli probability clamp (eps of the dtype) is part of the semantics, an
+        # fp64 oracle would clamp at |logit| = 36 instead of 15.94
+        params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        ref_out, ref_grads = O.elbo_loss_and_grads(params, resp, mask, eps_item, eps_ab, **cfg)
+        ref_loss = ref_out['loss']
+        model = model.to(d)
+        outs = model(resp.to(d).unsqueeze(2), mask.to(d).bool().unsqueeze(2), eps_item=eps_item.to(d), eps_ability=eps_ab.to(d))
+        if n_flows > 0:
+            (r, k, rmu, ak, a0, amu, alv, aladj, ik, i0, imu, ilv, iladj) = outs
+            loss = model.elbo(r, k, rmu, a0, amu, alv, i0, imu, ilv, annealing_factor=beta, use_kl_divergence=False,
+                              ability_k=ak, item_feat_k=ik, ability_logabsdetjac=aladj, item_logabsdetjac=iladj)
+        else:
+            loss = model.elbo(*outs, annealing_factor=beta, use_kl_divergence=use_kl)
+        loss.backward()
+        # the fp32 oracle carries the reference's own noise (log(1-p) at |logit| ~ 10, clamp-band decisions), so this
+        # sweep looks for gross host-logic errors: gradients are compared per parameter group, relative to the group's
+        # largest entry
+        errs = {'loss': rel(loss.detach().cpu(), ref_loss)}
+        groups = {}
+        for name, prm in model.named_parameters():
+            grp = name.split('.')[0]
+            e, m = groups.get(grp, (0.0, 0.0))
+            groups[grp] = (max(e, float((prm.grad.cpu().double() - ref_grads[name].double()).abs().max())),
+                           max(m, float(ref_grads[name].abs().max())))
+        for grp, (e, m) in groups.items():
+            if m > 1e-12:
+                errs[grp] = e / m
+        bad = {k: v for k, v in errs.items() if not (v < (5e-4 if k == 'loss' else 1e-2))}
+        worst = max(worst, max(errs.values()))
+        n += 1
+        if a.replay:
+            print('replayed module:', {k: float(f'{v:.3g}') for k, v in errs.items()})
+            sys.exit(0)
+        if bad:
+            print(f'FAIL module irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} beta={beta} '
+                  f'use_kl={use_kl} seed={seed}: {bad}')
+            sys.exit(1)
+    print(f'fuzz module ok: {n} random configurations, worst relative error {worst:.2e}')
+
+
 if a.target == 'multi':
     fuzz_multi()
+    sys.exit(0)
+if a.target == 'module':
+    fuzz_module()
     sys.exit(0)
 
 t0, n, worst = time.time(), 0, 0.0
