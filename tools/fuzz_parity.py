@@ -19,7 +19,7 @@ from vibo_amd.ops import ElboSpec
 ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
 ap.add_argument('--seed', type=int, default=0)
-ap.add_argument('--target', choices=['elbo', 'multi', 'module'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
+ap.add_argument('--target', choices=['elbo', 'multi', 'module', 'trainer'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
 ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only" of a reported failure')
 a = ap.parse_args()
 rng = random.Random(a.seed)
@@ -153,8 +153,75 @@ def fuzz_module():
     print(f'fuzz module ok: {n} random configurations, worst relative error {worst:.2e}')
 
 
+def fuzz_trainer():
+    """FusedTrainer (prologue / fused ELBO / epilogue+Adam kernels) vs module + autograd + torch.optim.Adam under the same
+    noise, 3 steps: losses and every parameter after the steps."""
+    import copy
+    from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
+    from vibo_amd.trainer import FusedTrainer
+    t0, n, worst = time.time(), 0, 0.0
+    while time.time() - t0 < a.seconds:
+        irt = rng.choice([1, 2, 2, 3])
+        A = rng.choice([1, 2, 3, 5, 8])
+        I = rng.choice([4, 37, 95, 100, 255, 256, 257, 1000, 1028])
+        B = rng.choice([1, 9, 64, 130])
+        hidden = rng.choice([4, 16, 33, 64, 100, 256])
+        beta = rng.choice([1.0, 0.5, 0.0])
+        lr = rng.choice([5e-3, 1e-2])
+        gather = rng.random() < 0.3
+        cls = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt]
+        seed = rng.randrange(1 << 30)
+        g = torch.Generator().manual_seed(seed)
+        P = B + 40 if gather else B
+        resp, mask = O.simulate_responses(irt, P, I, A, generator=g, missing_frac=rng.choice([0.0, 0.15]))
+        rows = torch.randint(0, P, (B,), generator=g).to(d) if gather else None
+        resp, mask = ops.pad_rows(resp.to(d), mask.bool().to(d))
+        torch.manual_seed(seed)
+        ref = cls(A, I, hidden_dim=hidden, ability_merge='product').to(d)
+        fus = copy.deepcopy(ref)
+        opt = torch.optim.Adam(ref.parameters(), lr=lr)
+        trainer = FusedTrainer(fus, lr=lr)
+        for step in range(3):
+            torch.manual_seed(100 + step)
+            opt.zero_grad()
+            loss_ref = ref.elbo_step(resp, mask, annealing_factor=beta, row_index=rows)
+            loss_ref.backward()
+            opt.step()
+            torch.manual_seed(100 + step)
+            loss_fus = trainer.step(resp, mask, beta=beta, row_index=rows)
+            e = abs(float(loss_fus) - float(loss_ref.detach())) / max(1.0, abs(float(loss_ref.detach())))
+            worst = max(worst, e) if step == 0 else worst
+            if step == 0:
+                # after ONE step the first moments are 0.1 x gradient: the sharp check of prologue / kernel / epilogue
+                # (later steps see Adam's m / sqrt(v) amplify 1e-7 parameter differences chaotically)
+                mlp = ref.ability_encoder.mlp
+                ref_m = torch.cat([opt.state[p_]['exp_avg'].reshape(-1) for p_ in (mlp[0].weight, mlp[0].bias, mlp[2].weight,
+                                                                                 mlp[2].bias, mlp[4].weight, mlp[4].bias)])
+                ref_im = torch.cat([opt.state[ref.item_encoder.mu_lookup.weight]['exp_avg'].reshape(-1),
+                                    opt.state[ref.item_encoder.logvar_lookup.weight]['exp_avg'].reshape(-1)])
+                for name, x, y in (('mlp exp_avg', trainer.mlp_m, ref_m), ('item exp_avg', trainer.item_m, ref_im)):
+                    em = float((x - y).abs().max()) / max(1e-1, float(y.abs().max()))     # (0.1 g; vanishing gradients: absolute floor)
+                    worst = max(worst, em)
+                    if not em < 1e-4:
+                        print(f'FAIL trainer {name} irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed}: {em}')
+                        sys.exit(1)
+            if not e < (5e-5 if step == 0 else 3e-2):
+                print(f'FAIL trainer loss irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed} step={step}: {e}')
+                sys.exit(1)
+        for (k, x), (_, y) in zip(ref.state_dict().items(), fus.state_dict().items()):
+            e = float((x - y).abs().max())
+            if not e < 6.0 * lr:      # boundedness only (3 steps x lr each way): later steps are chaotic, see above
+                print(f'FAIL trainer param {k} irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed}: {e}')
+                sys.exit(1)
+        n += 1
+    print(f'fuzz trainer ok: {n} random configurations, worst error {worst:.2e}')
+
+
 if a.target == 'multi':
     fuzz_multi()
+    sys.exit(0)
+if a.target == 'trainer':
+    fuzz_trainer()
     sys.exit(0)
 if a.target == 'module':
     fuzz_module()
