@@ -143,7 +143,9 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d,
 /*
  * Forward-only ability posterior q(theta | responses[, items]) for B persons
  * (model.encode under no_grad: vibo.py:363-364, 406-407, 434-435; models.py:356-371).
- * Arguments as above; writes ability_mu / ability_logvar [B][A].
+ * Arguments as above; writes ability_mu / ability_logvar [B][A].  With a workspace of vibo_workspace_bytes(d) and
+ * 16-byte chunkable rows it runs as a row-statistics pass at HBM speed + a per-person finish; without (workspace
+ * null / too small, int64 masks, ...) as one wave per person.
  */
 int vibo_encode(const vibo_desc* d,
                 const float* response, const void* mask, const int64_t* row_index,

@@ -355,8 +355,11 @@ def test_saturation_golden_through_kernel():
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize('cond', [False, True])
 @pytest.mark.parametrize('drop', [False, True])
-def test_encode_kernel(cond, drop):
-    irt, A, B, I = 2, 3, 101, 333
+@pytest.mark.parametrize('A,B,I', [(3, 101, 333), (1, 100, 1000), (8, 77, 600), (4, 33, 2500), (2, 9, 96), (5, 50, 1028)])
+def test_encode_kernel(cond, drop, A, B, I):
+    """model.encode's kernel: wave-per-person (ragged rows, conditional with A > 4) and the row-statistics fast path
+    (row_count / cond_pre + per-person finish), with and without row gather."""
+    irt = 2
     spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, drop_missing=drop)
     resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.2, seed=21, cond=cond)
     mask[:, 0] = 1
@@ -366,8 +369,11 @@ def test_encode_kernel(cond, drop):
                            mode='kl', want_grad=False)
     d = dev()
     mu, lv = ops.encode_posterior(spec, table.to(d), resp.to(d), mask.bool().to(d))
-    assert (mu.cpu() - ref['ability_mu'].float()).abs().max() < 2e-5
-    assert (lv.cpu() - ref['ability_logvar'].float()).abs().max() < 2e-5
+    assert (mu.cpu() - ref['ability_mu'].float()).abs().max() < 2e-5 * max(1.0, float(ref['ability_mu'].abs().max()))
+    assert (lv.cpu() - ref['ability_logvar'].float()).abs().max() < 2e-5 * max(1.0, float(ref['ability_logvar'].abs().max()))
+    rows = torch.randperm(B)[:max(1, B // 2)]
+    mu2, lv2 = ops.encode_posterior(spec, table.to(d), resp.to(d), mask.bool().to(d), row_index=rows.to(d))
+    assert (mu2.cpu() - mu.cpu()[rows]).abs().max() < 1e-6 and (lv2.cpu() - lv.cpu()[rows]).abs().max() < 1e-6
 
 
 @pytest.mark.parametrize('irt', [1, 2, 3])

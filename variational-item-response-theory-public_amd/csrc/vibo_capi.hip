@@ -31,6 +31,7 @@ static int hip_fail(hipError_t e, const char* what) {
     return (int)e > 0 ? (int)e : 999;
 }
 
+static bool rows_chunkable(const vibo_desc* d);
 static int item_feat_dim(int irt, int A) { return irt == 1 ? 1 : (irt == 2 ? A + 1 : A + 2); }
 
 static int check_desc(const vibo_desc* d) {
@@ -462,6 +463,48 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ a
     out[b * I + i] = pr;
 }
 
+// forward-only posterior from whole-row statistics: thread = (person, ability dim).  stats = packed counts of
+// row_count_kernel (unconditional: the experts are the two table rows) or the per-panel sums of cond_pre_kernel.
+__global__ __launch_bounds__(256) void encode_finish_kernel(const int* __restrict__ cnt, const float* __restrict__ pre, int panels,
+                                                            const float* __restrict__ table, float* __restrict__ ability_mu,
+                                                            float* __restrict__ ability_logvar, long long B, int I, int A,
+                                                            int missing_mode) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * A) return;
+    const long long row = e / A;
+    const int a = (int)(e % A);
+    float lam, smu, nobs;
+    if (cnt) {
+        const int c = cnt[row];
+        const float n1 = (float)(c >> 16);
+        nobs = (float)(c & 0xffff);
+        const float n0 = nobs - n1;
+        const float tau0 = 1.0f / (expf(table[A + a]) + kPoeEps), tau1 = 1.0f / (expf(table[2 * A + A + a]) + kPoeEps);
+        lam = n0 * tau0 + n1 * tau1;
+        smu = n0 * table[a] * tau0 + n1 * table[2 * A + a] * tau1;
+    } else {
+        lam = smu = nobs = 0.f;
+        for (int pn = 0; pn < panels; ++pn) {
+            const float* st = pre + ((size_t)pn * B + row) * (2 * A + 1);
+            lam += st[a]; smu += st[A + a]; nobs += st[2 * A];
+        }
+    }
+    if (missing_mode == VIBO_MISSING_PRIOR) lam += ((float)I - nobs) * (1.0f / (1.0f + kPoeEps));
+    ability_mu[e] = smu / lam;
+    ability_logvar[e] = logf(1.0f / lam);
+}
+
+// scratch the fast encode path needs (0: not applicable -> wave-per-person encode_kernel)
+static size_t encode_scratch_bytes(const vibo_desc* d) {
+    const int I = d->num_item, A = d->ability_dim;
+    if (I < 4 || I > 32767 || !rows_chunkable(d) || d->mask_dtype == VIBO_MASK_I64) return 0;
+    if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) {
+        if (A > 4) return 0;
+        return (size_t)((I + 1023) / 1024) * d->num_person * (2 * A + 1) * 4 + 256;
+    }
+    return (size_t)d->num_person * 4 + 256;
+}
+
 // posterior-predictive mean: thread = one item x 8 persons; per sample the item row is loaded once and reused for the
 // 8 persons (ability rows are wave-uniform scalar loads)
 __global__ __launch_bounds__(256) void decode_mean_kernel_strided(const float* __restrict__ ability, const float* __restrict__ item,
@@ -522,7 +565,8 @@ size_t vibo_workspace_bytes(const vibo_desc* d) {
     if (check_desc(d) != 0) return 0;
     Plan pl;
     if (make_plan(d, &pl) < 0) return 0;
-    return pl.total_bytes;
+    const size_t enc = encode_scratch_bytes(d);
+    return pl.total_bytes > enc ? pl.total_bytes : enc;
 }
 
 int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index,
@@ -810,11 +854,60 @@ int vibo_decode_mean(const vibo_desc* d, int num_samples, const float* ability, 
 int vibo_encode(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index,
                 const float* table, float* ability_mu, float* ability_logvar, void* workspace,
                 size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;
     int rc = check_desc(d);
     if (rc) return rc;
     if (!response || !table || !ability_mu || !ability_logvar) return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
+    {
+        // fast path: the row statistics of the row-split pipeline (16-byte row chunks at HBM speed) + a per-person finish
+        const int I = d->num_item, A = d->ability_dim;
+        const size_t need = encode_scratch_bytes(d);
+        bool vec = need > 0 && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
+        if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
+        if (vec && workspace && workspace_bytes >= need && (((uintptr_t)workspace & 255) == 0)) {
+            hipStream_t s = (hipStream_t)stream;
+            if (g_num_cu == 0) {
+                int dev = 0, n = 0;
+                g_num_cu = (hipGetDevice(&dev) == hipSuccess &&
+                            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+            }
+            const long long BA = (long long)d->num_person * A;
+            hipError_t e = hipSuccess;
+            if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) {
+                float* pre = static_cast<float*>(workspace);
+                const int panels = (I + 1023) / 1024;
+                int grid = g_num_cu * 3;
+                if (grid > (d->num_person + 7) / 8) grid = (d->num_person + 7) / 8;
+                CondParams cp;
+                memset(&cp, 0, sizeof(cp));
+                cp.response = response; cp.mask = mask; cp.row_index = row_index; cp.table = table;
+                cp.resp_stride = d->response_row_stride; cp.mask_stride = d->mask_row_stride;
+                cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;
+                for (int pn = 0; pn < panels && e == hipSuccess; ++pn) {
+                    cp.item0 = pn * 1024;
+                    cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
+                    cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
+                    e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, grid, s);
+                }
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(encode_finish_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, s, nullptr, pre, panels,
+                                       table, ability_mu, ability_logvar, (long long)d->num_person, I, A, d->missing_mode);
+                    e = hipGetLastError();
+                }
+            } else {
+                int* cnt = static_cast<int*>(workspace);
+                int cgrid = g_num_cu * 8;
+                if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
+                hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
+                                   (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
+                hipLaunchKernelGGL(encode_finish_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, s, cnt, nullptr, 0, table,
+                                   ability_mu, ability_logvar, (long long)d->num_person, I, A, d->missing_mode);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) return hip_fail(e, "encode (fast path) launch");
+            return 0;
+        }
+    }
     EncodeParams p;
     memset(&p, 0, sizeof(p));
     p.response = response; p.mask = mask; p.row_index = row_index; p.table = table;

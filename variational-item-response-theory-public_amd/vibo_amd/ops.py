@@ -241,8 +241,10 @@ def _hip_encode(spec, response, mask, mask_code, row_index, table, num_person):
     d = _make_desc(spec, B, I, mask_code, _lib.REG_KL, False, response.stride(0),
                    mask.stride(0) if mask is not None else 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ws_bytes = lib.vibo_workspace_bytes(ctypes.byref(d))          # scratch for the row statistics of the fast path
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
     rc = lib.vibo_encode(ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(table),
-                         _ptr(out[0]), _ptr(out[1]), ctypes.c_void_p(0), ctypes.c_size_t(0), stream)
+                         _ptr(out[0]), _ptr(out[1]), _ptr(ws), ctypes.c_size_t(ws_bytes), stream)
     _lib.check(rc, 'vibo_encode')
     return out[0], out[1]
 
