@@ -525,3 +525,20 @@ def test_decode_mean_kernel(irt, A, B, I, S):
     ref = torch.stack([O.irt_link(irt, ab[s].double(), it[s].double()) for s in range(S)]).mean(0)
     out = ops.decode_probs_mean(spec, ab.to(dev()), it.to(dev())).cpu().double()
     assert float((out - ref).abs().max()) < 2e-6
+
+
+def test_encode_and_decode_on_a_flow_model():
+    """model.encode / decode / posterior-predictive mean do not involve the flows, but must accept a flow model's spec
+    (found by tools/fuzz_parity.py: the descriptor used to be rejected)."""
+    irt, A, B, I = 2, 2, 50, 200
+    spec = ElboSpec(irt_model=irt, ability_dim=A, n_flows=4)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.1, seed=4)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt, ability_dim=A,
+                           mode='kl', want_grad=False)
+    d = dev()
+    mu, lv = ops.encode_posterior(spec, table.to(d), resp.to(d), mask.bool().to(d))
+    assert (mu.cpu() - ref['ability_mu'].float()).abs().max() < 2e-5
+    pr = ops.decode_probs(spec, ref['ability'].float().to(d), item.to(d)).cpu()
+    assert (pr - O.irt_link(irt, ref['ability'].float(), item)).abs().max() < 2e-6
+    prm = ops.decode_probs_mean(spec, ref['ability'].float().to(d)[None], item.to(d)[None]).cpu()
+    assert (prm - pr).abs().max() < 2e-6

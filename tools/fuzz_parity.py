@@ -301,7 +301,11 @@ while time.time() - t0 < a.seconds:
             gref = torch.cat([torch.cat(gf) for gf in ref['g_flow'][s_]]).float()
             if float(gref.abs().max()) > 0:
                 errs[f'g_flow{s_}'] = rel(raw.grad_flow(s_).cpu(), gref)
-    lim = {'ll': 3e-5, 'reg': 3e-5, 'mu': 3e-5, 'theta': 6e-5}
+    # model.encode's kernel on the same rows (row-statistics fast path or wave-per-person fallback)
+    emu, elv = ops.encode_posterior(spec, table.to(d), r_, None if no_mask else m_, row_index=rows.to(d) if gather else None)
+    errs['enc_mu'] = float((emu.cpu() - ref['ability_mu'].float()).abs().max()) / max(1.0, float(ref['ability_mu'].abs().max()))
+    errs['enc_lv'] = float((elv.cpu() - ref['ability_logvar'].float()).abs().max()) / max(1.0, float(ref['ability_logvar'].abs().max()))
+    lim = {'ll': 3e-5, 'reg': 3e-5, 'mu': 3e-5, 'theta': 6e-5, 'enc_mu': 3e-5, 'enc_lv': 3e-5}
     bad = {k: v for k, v in errs.items() if not (v < lim.get(k, 6e-4))}
     worst = max(worst, max(errs.values()))
     n += 1

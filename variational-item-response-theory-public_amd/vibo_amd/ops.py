@@ -238,7 +238,8 @@ def _hip_encode(spec, response, mask, mask_code, row_index, table, num_person):
     dev = response.device
     B, I, A = int(num_person), response.shape[1], spec.ability_dim
     out = torch.empty(2, B, A, dtype=torch.float32, device=dev)
-    d = _make_desc(spec, B, I, mask_code, _lib.REG_KL, False, response.stride(0),
+    # (the posterior does not depend on the flows; the descriptor only has to be self-consistent)
+    d = _make_desc(spec, B, I, mask_code, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, False, response.stride(0),
                    mask.stride(0) if mask is not None else 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     ws_bytes = lib.vibo_workspace_bytes(ctypes.byref(d))          # scratch for the row statistics of the fast path
@@ -254,7 +255,7 @@ def _hip_decode(spec, ability, item):
     _require_device(ability, item)
     B, I = ability.shape[0], item.shape[0]
     out = torch.empty(B, I, dtype=torch.float32, device=ability.device)
-    d = _make_desc(spec, B, I, _lib.MASK_NONE, _lib.REG_KL, False, I, 0)
+    d = _make_desc(spec, B, I, _lib.MASK_NONE, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, False, I, 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(ability.device).cuda_stream)
     rc = lib.vibo_decode(ctypes.byref(d), _ptr(ability), _ptr(item), _ptr(out), stream)
     _lib.check(rc, 'vibo_decode')
@@ -267,7 +268,7 @@ def _hip_decode_mean(spec, abilities, items):
     _require_device(abilities, items)
     S, B, I = int(abilities.shape[0]), int(abilities.shape[1]), int(items.shape[1])
     out = torch.empty(B, I, dtype=torch.float32, device=abilities.device)
-    d = _make_desc(spec, B, I, _lib.MASK_NONE, _lib.REG_KL, False, I, 0)
+    d = _make_desc(spec, B, I, _lib.MASK_NONE, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, False, I, 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(abilities.device).cuda_stream)
     rc = lib.vibo_decode_mean(ctypes.byref(d), S, _ptr(abilities), _ptr(items), _ptr(out), stream)
     _lib.check(rc, 'vibo_decode_mean')
