@@ -83,3 +83,29 @@ def test_fused_trainer_native_rng_trains():
     losses = [float(tr.step(resp, mask, beta=1.0)) for _ in range(60)]
     assert all(l == l for l in losses)
     assert sum(losses[-5:]) < 0.9 * sum(losses[:5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('extra', [[], ['--no-graph'], ['--artificial-missing-perc', '0.2', '--conditional-posterior'],
+                                   ['--n-norm-flows', '2', '--irt-model', '3pl', '--dataset', '3pl_simulation'],
+                                   ['--num-item', '95', '--ability-dim', '3']])
+def test_cli_end_to_end_on_the_gpu(tmp_path, monkeypatch, extra):
+    """The drop-in CLI with --cuda: fused trainer replayed from a hipGraph (or eager / module + torch.optim for the
+    conditional posterior and flows), resident padded rows, post-hoc enrichment; same checkpoint layout as on CPU."""
+    import os
+    import numpy as np
+    from vibo_amd import config
+    from vibo_amd.torch_core import vibo as cli
+    monkeypatch.setattr(config, 'DATA_DIR', str(tmp_path / 'data'))
+    monkeypatch.setattr(config, 'OUT_DIR', str(tmp_path / 'out'))
+    argv = ['--irt-model', '2pl', '--dataset', '2pl_simulation', '--num-person', '600', '--num-item', '12',
+            '--epochs', '4', '--batch-size', '16', '--num-posterior-samples', '3', '--cuda',
+            '--out-dir', str(tmp_path / 'out')] + extra
+    cli.main(argv)
+    (run_dir,) = os.listdir(tmp_path / 'out')
+    ck = torch.load(tmp_path / 'out' / run_dir / 'checkpoint.pth.tar', weights_only=False)
+    assert {'model_state_dict', 'epoch', 'args', 'train_logp', 'test_logp'} <= set(ck)
+    losses = np.load(tmp_path / 'out' / run_dir / 'train_losses.npy')
+    assert losses.shape == (4,) and np.isfinite(losses).all() and losses[-1] < losses[0]
+    if '--artificial-missing-perc' in extra:
+        assert 0.0 <= ck['missing_imputation_accuracy'] <= 1.0
