@@ -36,7 +36,15 @@ enum { VIBO_MISSING_PRIOR = 0,   /* missing cell -> N(0,1) prior expert (models.
        VIBO_MISSING_DROP = 1 };  /* --drop-missing: expert removed      (vibo.py:217)       */
 enum { VIBO_MASK_U8 = 0,         /* torch.bool / uint8, 1 byte per cell (datasets.py:938)   */
        VIBO_MASK_I64 = 1,        /* mask.long() as the reference train loop passes it (vibo.py:240) */
-       VIBO_MASK_NONE = 2 };     /* mask == NULL: every cell observed                        */
+       VIBO_MASK_NONE = 2,       /* mask == NULL: every cell observed                        */
+       VIBO_MASK_CODES = 3 };    /* "Format P" (SURVEY 8f-3): `mask` points at one byte per cell holding the whole cell,
+                                    0 = answered wrong, 1 = answered right, 2 = missing; `response` is ignored (NULL
+                                    allowed) and mask_row_stride is the stride of the code rows.  1 B/cell of HBM
+                                    traffic instead of 5.  Produced by vibo_pack_codes from the reference's layout
+                                    (fp32 responses with -1 for missing + a separate mask, datasets.py:928-940).
+                                    Row-split paths only: 4..32767 items, code rows 4-byte aligned with a stride that
+                                    is a multiple of 4 (cells past num_item are ignored); the conditional posterior
+                                    additionally needs ability_dim <= 4.  Anything else returns -8.            */
 enum { VIBO_REG_KL = 0,          /* elbo(use_kl_divergence=True): analytic KL (models.py:427-430) */
        VIBO_REG_SAMPLED = 1 };   /* use_kl_divergence=False / flows: log q - log p at the sample
                                     (models.py:406-424, 432-441)                             */
@@ -152,6 +160,15 @@ int vibo_encode(const vibo_desc* d,
                 const float* table,
                 float* ability_mu, float* ability_logvar,
                 void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Repack B rows from the reference's layout (fp32 `response`, `mask` per d->mask_dtype U8 / I64 / NONE, strides from d)
+ * into 1-byte cell codes for VIBO_MASK_CODES: codes[row * codes_row_stride + i], i < num_item; the cells between
+ * num_item and codes_row_stride are written as "missing".  One pass, done once for a device-resident dataset
+ * (replaces the per-step `.float()` / `.long()` conversions of vibo.py:239-240 for good).
+ */
+int vibo_pack_codes(const vibo_desc* d, const float* response, const void* mask, uint8_t* codes, int64_t codes_row_stride,
+                    void* stream);
 
 /*
  * decode(): P(response = 1) for every (person, item) -> response_mu [B][I]

@@ -17,6 +17,16 @@ def _gather(t, row_index):
     return t[row_index] if row_index is not None else t
 
 
+def _rows(response, mask, mask_code, row_index):
+    """(response fp32, mask uint8) of the call's rows; mask_code 3 = 1-byte cell codes (0 wrong / 1 right / 2 missing)."""
+    if mask_code == 3:
+        codes = _gather(mask, row_index)
+        return (codes == 1).float(), (codes != 2).to(torch.uint8)
+    resp = _gather(response, row_index)
+    msk = _gather(mask, row_index) if mask is not None else torch.ones_like(resp, dtype=torch.uint8)
+    return resp, msk
+
+
 def _cfg(spec, reg_mode):
     return dict(irt_model=spec.irt_model, ability_dim=spec.ability_dim,
                 conditional_posterior=spec.conditional,
@@ -29,8 +39,7 @@ def install(ops):
     saved = dict(ops._BACKEND)
 
     def elbo(spec, response, mask, mask_code, row_index, table, item, eps, flow, reg_mode, want_grad, num_person):
-        resp = _gather(response, row_index)
-        msk = _gather(mask, row_index) if mask is not None else torch.ones_like(resp, dtype=torch.uint8)
+        resp, msk = _rows(response, mask, mask_code, row_index)
         A = spec.ability_dim
         flows = None
         if flow is not None:
@@ -59,8 +68,7 @@ def install(ops):
         return raw
 
     def encode(spec, response, mask, mask_code, row_index, table, num_person):
-        resp = _gather(response, row_index)
-        msk = _gather(mask, row_index) if mask is not None else torch.ones_like(resp, dtype=torch.uint8)
+        resp, msk = _rows(response, mask, mask_code, row_index)
         B, A = resp.shape[0], spec.ability_dim
         dummy_item = torch.zeros(resp.shape[1], spec.item_dim)
         out = T.fused_elbo_ref(table, dummy_item, resp, msk, torch.zeros(B, A), want_grad=False,

@@ -101,6 +101,33 @@ def test_mask_dtypes_equivalent(cpu_ops, golden):
     assert float(l_i64.detach()) == float(l_bool.detach()) == float(l_u8.detach())
 
 
+def test_cell_codes_rows_match_golden(cpu_ops, golden):
+    """Format P host plumbing (ops.CellCodes -> prepare_rows -> VIBO_MASK_CODES): the goldens fed as one byte per cell."""
+    model = build_model(golden)
+    mask = golden.mask != 0
+    I = golden.response.shape[1]
+    padded = torch.full((golden.response.shape[0], (I + 3) // 4 * 4), 2, dtype=torch.uint8)
+    padded[:, :I] = torch.where(mask, (golden.response == 1).to(torch.uint8), torch.full_like(mask, 2, dtype=torch.uint8))
+    codes = ops.CellCodes(padded[:, :I])
+    r2, m2 = codes.unpack()
+    assert torch.equal(m2, mask) and torch.equal(r2[m2], golden.response[m2])
+    assert torch.equal(codes.rows(torch.tensor([1, 0])).codes, codes.codes[[1, 0]])
+    with pytest.raises(ValueError):
+        ops.prepare_rows(codes, mask)
+    with pytest.raises(ValueError):
+        ops.CellCodes(padded[:, :I].float())
+    m = golden.meta
+    outs = model(codes, None, eps_item=golden.eps_item, eps_ability=golden.eps_ability)
+    if m['n_norm_flows'] > 0:
+        (r, k, rmu, ak, a0, amu, alv, aladj, ik, i0, imu, ilv, iladj) = outs
+        loss = model.elbo(r, k, rmu, a0, amu, alv, i0, imu, ilv, annealing_factor=m['annealing_factor'],
+                          use_kl_divergence=False, ability_k=ak, item_feat_k=ik,
+                          ability_logabsdetjac=aladj, item_logabsdetjac=iladj)
+    else:
+        loss = model.elbo(*outs, annealing_factor=m['annealing_factor'], use_kl_divergence=m['use_kl_divergence'])
+    check_against_golden(model, golden, outs, loss)
+
+
 def test_decode_and_deferred_response_mu(cpu_ops, golden):
     model = build_model(golden)
     outs, _ = run_reference_pattern(model, golden)

@@ -22,6 +22,8 @@ ap.add_argument('--no-grad', action='store_true')
 ap.add_argument('--cond', action='store_true')
 ap.add_argument('--flows', type=int, default=0)
 ap.add_argument('--missing', type=float, default=0.1)
+ap.add_argument('--gather', action='store_true', help='rows through a random row_index permutation (shuffled minibatch)')
+ap.add_argument('--codes', action='store_true', help='rows as 1-byte cell codes (VIBO_MASK_CODES, Format P) instead of fp32 + mask')
 ap.add_argument('--cached-rows', type=int, default=0, help='gather rows from the first N rows only (L2-resident): compute-only timing')
 a = ap.parse_args()
 d = torch.device('cuda:0')
@@ -37,7 +39,12 @@ reg = _lib.REG_SAMPLED if a.flows else _lib.REG_KL
 item = torch.randn(I, D, device=d, generator=g)
 eps = torch.randn(P, A, device=d, generator=g)
 m, code = ops.prepare_mask(mask)
+if a.codes:
+    resp, m, code = ops.prepare_rows(ops.pack_cell_codes(resp, mask), None)
+    del mask
 ridx = (torch.arange(P, device=d) % a.cached_rows) if a.cached_rows else None
+if a.gather:
+    ridx = torch.randperm(P, device=d)
 for _ in range(a.iters):
     raw = ops._hip_launch_elbo(spec, resp, m, code, ridx, table, item, eps, flow, reg, not a.no_grad, P)
 torch.cuda.synchronize()
@@ -48,5 +55,5 @@ for _ in range(a.iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
-print(f'P={P} I={I} A={A} irt={a.irt} cond={a.cond} flows={a.flows} grad={not a.no_grad}: {ms:.3f} ms/call, {P*I/ms/1e9:.3f} T terms/s, '
-      f'{(5+12*A/I)*P*I/ms/1e6:.0f} GB/s algorithmic, ll={float(raw.scalars[0]):.1f}')
+print(f'P={P} I={I} A={A} irt={a.irt} cond={a.cond} flows={a.flows} grad={not a.no_grad} gather={ridx is not None}: {ms:.3f} ms/call, {P*I/ms/1e9:.3f} T terms/s, '
+      f'{((1 if a.codes else 5)+12*A/I)*P*I/ms/1e6:.0f} GB/s algorithmic{" (1 B/cell codes)" if a.codes else ""}, ll={float(raw.scalars[0]):.1f}')

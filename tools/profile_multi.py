@@ -19,6 +19,8 @@ ap.add_argument('--items', type=int, default=1000)
 ap.add_argument('--ability-dim', type=int, default=1)
 ap.add_argument('--samples', type=int, default=16)
 ap.add_argument('--irt', type=int, default=2)
+ap.add_argument('--codes', action='store_true', help='rows as 1-byte cell codes (VIBO_MASK_CODES)')
+ap.add_argument('--gather', action='store_true')
 a = ap.parse_args()
 d = torch.device('cuda:0')
 g = torch.Generator(device=d).manual_seed(0)
@@ -30,14 +32,17 @@ table = torch.randn(2, 2 * A, device=d, generator=g) * 0.5
 items = torch.randn(S, I, spec.item_dim, device=d, generator=g)
 eps = torch.randn(S, P, A, device=d, generator=g)
 m, code = ops.prepare_mask(mask)
+if a.codes:
+    resp, m, code = ops.prepare_rows(ops.pack_cell_codes(resp, mask), None)
+ridx = torch.randperm(P, device=d) if a.gather else None
 
 
 def multi():
-    return ops._hip_multi_forward(spec, resp, m, code, None, table, items, eps, None, _lib.REG_SAMPLED, P)
+    return ops._hip_multi_forward(spec, resp, m, code, ridx, table, items, eps, None, _lib.REG_SAMPLED, P)
 
 
 def singles():
-    return [ops._hip_launch_elbo(spec, resp, m, code, None, table, items[s], eps[s], None, _lib.REG_SAMPLED, False, P).scalars
+    return [ops._hip_launch_elbo(spec, resp, m, code, ridx, table, items[s], eps[s], None, _lib.REG_SAMPLED, False, P).scalars
             for s in range(S)]
 
 
@@ -49,5 +54,5 @@ for name, f in (('multi-sample kernel', multi), ('one launch per sample', single
         f()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print(f'P={P} I={I} A={A} S={S} {name:24s}: {dt * 1e3:8.3f} ms = {dt * 1e3 / S:6.3f} ms per sample, '
+    print(f'P={P} I={I} A={A} S={S} codes={a.codes} gather={a.gather} {name:24s}: {dt * 1e3:8.3f} ms = {dt * 1e3 / S:6.3f} ms per sample, '
           f'{P * I * S / dt / 1e12:.3f} T sample-terms/s')

@@ -45,7 +45,7 @@ static int check_desc(const vibo_desc* d) {
     if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL && d->posterior != VIBO_POSTERIOR_CONDITIONAL)
         return fail(-3, "bad posterior");
     if (d->missing_mode != VIBO_MISSING_PRIOR && d->missing_mode != VIBO_MISSING_DROP) return fail(-3, "bad missing_mode");
-    if (d->mask_dtype < 0 || d->mask_dtype > 2) return fail(-3, "bad mask_dtype");
+    if (d->mask_dtype < 0 || d->mask_dtype > VIBO_MASK_CODES) return fail(-3, "bad mask_dtype");
     if (d->reg_mode != VIBO_REG_KL && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "bad reg_mode");
     if (d->n_flows < 0 || d->n_flows > VIBO_MAX_FLOWS) return fail(-3, "n_flows outside 0..%d", VIBO_MAX_FLOWS);
     if (d->n_flows > 0 && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "flows need reg_mode SAMPLED");
@@ -71,15 +71,43 @@ struct Plan {
 
 static int g_num_cu = 0;
 
+static hipError_t launch_split(const ElboParams& p, int AT, bool codes, int irt, bool grad, int nq, int grid, hipStream_t s) {
+    if (codes)
+        return AT <= 2   ? launch_elbo_split_c2(p, irt, grad, nq, grid, s)
+               : AT == 4 ? launch_elbo_split_c4(p, irt, grad, nq, grid, s)
+                         : launch_elbo_split_c8(p, irt, grad, nq, grid, s);
+    if (p.row_index)
+        return AT <= 2   ? launch_elbo_split_g2(p, irt, grad, nq, grid, s)
+               : AT == 4 ? launch_elbo_split_g4(p, irt, grad, nq, grid, s)
+                         : launch_elbo_split_g8(p, irt, grad, nq, grid, s);
+    return AT <= 2   ? launch_elbo_split_a2(p, irt, grad, nq, grid, s)
+           : AT == 4 ? launch_elbo_split_a4(p, irt, grad, nq, grid, s)
+                     : launch_elbo_split_a8(p, irt, grad, nq, grid, s);
+}
+
 // 16-byte row chunks need I % 4 == 0, or row strides that pad every row to a multiple of 4 cells (the cells past
 // the row's end are read but masked out in the kernels)
 static bool rows_chunkable(const vibo_desc* d) {
     const int I = d->num_item;
     if (I % 4 == 0) return true;
     const long long i4 = (I + 3) & ~3;
-    if (d->response_row_stride < i4) return false;
-    if (d->mask_dtype == VIBO_MASK_U8 && d->mask_row_stride < i4) return false;
+    if (d->mask_dtype != VIBO_MASK_CODES && d->response_row_stride < i4) return false;
+    if ((d->mask_dtype == VIBO_MASK_U8 || d->mask_dtype == VIBO_MASK_CODES) && d->mask_row_stride < i4) return false;
     return true;
+}
+
+// rows can be read in aligned chunks of 4 cells (16 B of responses + 4 B of mask, or 4 B of cell codes)
+static bool rows_vec_ok(const vibo_desc* d, const float* response, const void* mask) {
+    bool vec = rows_chunkable(d);
+    if (d->mask_dtype != VIBO_MASK_CODES) vec = vec && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
+    if (d->mask_dtype == VIBO_MASK_U8 || d->mask_dtype == VIBO_MASK_CODES)
+        vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
+    if (d->mask_dtype == VIBO_MASK_I64) vec = vec && (d->mask_row_stride % 2 == 0) && (((uintptr_t)mask & 15) == 0);
+    return vec;
+}
+static int codes_unsupported() {
+    return fail(-8, "cell codes (VIBO_MASK_CODES) need the row-split paths: 4..32767 items, rows 4-byte aligned with a "
+                    "stride that pads them to a multiple of 4 cells, ability_dim <= 4 with the conditional posterior");
 }
 
 static int make_plan(const vibo_desc* d, Plan* pl) {
@@ -116,7 +144,7 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
         pl->split_nq = 4;
-        pl->split_nblk = g_num_cu * (d->want_grad ? 2 : 3);
+        pl->split_nblk = g_num_cu * ((d->want_grad && !(d->mask_dtype == VIBO_MASK_CODES && pl->AT <= 2)) ? 2 : 3);
         if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
         pl->nblk = 0;
         pl->lds_main = 0;
@@ -197,7 +225,7 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
             pl->DP = prepped_item_width(d->irt_model, at_min);
         }
     }
-    pl->split_nblk = g_num_cu * ((d->want_grad ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
+    pl->split_nblk = g_num_cu * (((d->want_grad && !(d->mask_dtype == VIBO_MASK_CODES && pl->AT <= 2)) ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
     if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * 4;
     const int n4 = (I + 3) >> 2;
+    const bool cell_codes = mask_dtype == VIBO_MASK_CODES;
     for (long long row = wave_id; row < B; row += n_waves) {
         const long long src = row_index ? row_index[row] : row;
         const float4* rp = reinterpret_cast<const float4*>(response + src * resp_stride);
@@ -262,23 +291,49 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
         int packed = 0;
         for (int c0 = lane; c0 < n4; c0 += 256) {          // 4 chunks per lane in flight
             float4 x[4];
-            uint32_t m[4];
+            uint32_t m[4], keep[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = c0 + 64 * u;
                 x[u] = float4{0.f, 0.f, 0.f, 0.f};
                 m[u] = 0u;
+                keep[u] = 0u;
                 if (c < n4) {
-                    x[u] = rp[c];
-                    m[u] = mask_dtype == 0 ? mp[c] : 0x01010101u;
-                    if ((I & 3) && c == (I >> 2)) m[u] &= (1u << (8 * (I & 3))) - 1u;      // padded tail of the row
+                    if (!cell_codes) x[u] = rp[c];
+                    m[u] = (mask_dtype == 0 || cell_codes) ? mp[c] : 0x01010101u;
+                    keep[u] = ((I & 3) && c == (I >> 2)) ? (1u << (8 * (I & 3))) - 1u : 0xFFFFFFFFu;      // padded tail of the row
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) (void)pack_codes4(x[u], m[u], packed);
+            for (int u = 0; u < 4; ++u) {
+                if (cell_codes) (void)pack_cell_codes4(m[u], keep[u], packed);
+                else (void)pack_codes4(x[u], m[u] & keep[u], packed);
+            }
         }
         const int tot = lane63(wave_sum63(packed));
         if (lane == 0) cnt[row] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Format P: response (fp32) + mask (u8 / int64 / none) -> 1-byte cell codes, rows padded with "missing" up to the
+// code stride (datasets.py:928-940 stores responses as fp32 with -1 for missing and a separate mask)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict__ response, const void* __restrict__ mask,
+                                                         uint8_t* __restrict__ codes, long long resp_stride, long long mask_stride,
+                                                         long long code_stride, long long B, int I, int mask_dtype) {
+    const long long n = B * code_stride;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long row = e / code_stride;
+        const int i = (int)(e - row * code_stride);
+        uint8_t c = 2;
+        if (i < I) {
+            bool k = true;
+            if (mask_dtype == VIBO_MASK_U8) k = static_cast<const uint8_t*>(mask)[row * mask_stride + i] != 0;
+            else if (mask_dtype == VIBO_MASK_I64) k = static_cast<const int64_t*>(mask)[row * mask_stride + i] != 0;
+            if (k) c = response[row * resp_stride + i] == 1.0f ? 1 : 0;
+        }
+        codes[e] = c;
     }
 }
 
@@ -576,7 +631,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                       float* grad_flow, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!response || !table || !item || !eps || !out_scalars || !ability_mu || !ability_logvar || !ability)
+    if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !table || !item || !eps || !out_scalars || !ability_mu || !ability_logvar || !ability)
         return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
     if (d->want_grad && (!grad_table || !grad_item)) return fail(-5, "want_grad needs grad_table and grad_item");
@@ -591,9 +646,9 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     hipStream_t s = (hipStream_t)stream;
     const int I = d->num_item, A = d->ability_dim;
     // 16-byte row loads need aligned rows
-    bool vec = rows_chunkable(d) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
-    if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
-    if (d->mask_dtype == VIBO_MASK_I64) vec = vec && (d->mask_row_stride % 2 == 0) && (((uintptr_t)mask & 15) == 0);
+    const bool vec = rows_vec_ok(d, response, mask);
+    const bool codes = d->mask_dtype == VIBO_MASK_CODES;
+    if (codes && !(vec && !pl.general && (pl.panels > 0 || pl.split_ok))) return codes_unsupported();
 
     if (pl.general || (d->n_flows > 0 && !(pl.split_ok && vec) && pl.panels == 0) || (pl.panels > 0 && !vec)) {
         const size_t n_table = (size_t)(d->posterior == VIBO_POSTERIOR_CONDITIONAL ? 2 * I * 2 * A : 2 * 2 * A);
@@ -684,9 +739,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             p.partial = partial + (size_t)pn * pl.split_nblk * pl.lay.stride;
             p.post_coef = (pl.cond && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
             const int nq = (p.I + 255) / 256;
-            e = pl.AT <= 2   ? launch_elbo_split_a2(p, d->irt_model, grad, nq, pl.split_nblk, s)
-                : pl.AT == 4 ? launch_elbo_split_a4(p, d->irt_model, grad, nq, pl.split_nblk, s)
-                             : launch_elbo_split_a8(p, d->irt_model, grad, nq, pl.split_nblk, s);
+            e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s);
         }
         if (pl.cond && grad) {
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
@@ -702,9 +755,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         bpp = pl.split_nblk;
     } else if (pl.split_ok && vec) {
         nblk_used = pl.split_nblk;
-        e = pl.AT <= 2   ? launch_elbo_split_a2(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
-            : pl.AT == 4 ? launch_elbo_split_a4(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s)
-                         : launch_elbo_split_a8(p, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
+        e = launch_split(p, pl.AT, codes, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
     } else if (pl.row_ok && vec && I % 4 == 0 && pl.AT == A) {
         nblk_used = pl.row_nblk;
         e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);
@@ -760,7 +811,7 @@ int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* re
     int rc = check_desc(d);
     if (rc) return rc;
     if (num_samples < 1) return fail(-3, "num_samples must be >= 1");
-    if (!response || !table || !item || !eps || !out_scalars) return fail(-5, "null required pointer");
+    if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !table || !item || !eps || !out_scalars) return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
     if (d->n_flows > 0 && !flow) return fail(-5, "flows need flow");
     vibo_desc d0;
@@ -771,9 +822,7 @@ int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* re
     if (!workspace || workspace_bytes < pl.total_bytes + 4 * prep) return fail(-7, "workspace too small");
     if ((uintptr_t)workspace & 255) return fail(-7, "workspace must be 256-byte aligned");
     const int I = d->num_item, A = d->ability_dim;
-    bool vec = rows_chunkable(d) && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
-    if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
-    if (!vec) return fail(-8, "multi-sample forward: rows are not 16-byte chunkable");
+    if (!rows_vec_ok(d, response, mask)) return fail(-8, "multi-sample forward: rows are not 16-byte chunkable");
     hipStream_t s = (hipStream_t)stream;
     char* wsb = static_cast<char*>(workspace);
     float* partial = reinterpret_cast<float*>(wsb + pl.off_partial);
@@ -856,14 +905,13 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
                 size_t workspace_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!response || !table || !ability_mu || !ability_logvar) return fail(-5, "null required pointer");
+    if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !table || !ability_mu || !ability_logvar) return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
     {
         // fast path: the row statistics of the row-split pipeline (16-byte row chunks at HBM speed) + a per-person finish
         const int I = d->num_item, A = d->ability_dim;
         const size_t need = encode_scratch_bytes(d);
-        bool vec = need > 0 && (d->response_row_stride % 4 == 0) && (((uintptr_t)response & 15) == 0);
-        if (d->mask_dtype == VIBO_MASK_U8) vec = vec && (d->mask_row_stride % 4 == 0) && (((uintptr_t)mask & 3) == 0);
+        const bool vec = need > 0 && rows_vec_ok(d, response, mask);
         if (vec && workspace && workspace_bytes >= need && (((uintptr_t)workspace & 255) == 0)) {
             hipStream_t s = (hipStream_t)stream;
             if (g_num_cu == 0) {
@@ -908,6 +956,7 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
             return 0;
         }
     }
+    if (d->mask_dtype == VIBO_MASK_CODES) return codes_unsupported();      // (or the workspace is missing / too small)
     EncodeParams p;
     memset(&p, 0, sizeof(p));
     p.response = response; p.mask = mask; p.row_index = row_index; p.table = table;
@@ -919,6 +968,25 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
     hipLaunchKernelGGL(encode_kernel, dim3((d->num_person + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "encode launch");
+    return 0;
+}
+
+int vibo_pack_codes(const vibo_desc* d, const float* response, const void* mask, uint8_t* codes, int64_t codes_row_stride,
+                    void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (d->mask_dtype == VIBO_MASK_CODES) return fail(-3, "vibo_pack_codes: the source rows are already cell codes");
+    if (!response || !codes) return fail(-5, "null required pointer");
+    if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
+    if (codes_row_stride < d->num_item) return fail(-3, "codes_row_stride %lld < num_item", (long long)codes_row_stride);
+    const long long n = (long long)d->num_person * codes_row_stride;
+    long long grid = (n + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(pack_codes_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, response, mask, codes,
+                       (long long)d->response_row_stride, (long long)d->mask_row_stride, (long long)codes_row_stride,
+                       (long long)d->num_person, d->num_item, d->mask_dtype);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pack_codes launch");
     return 0;
 }
 

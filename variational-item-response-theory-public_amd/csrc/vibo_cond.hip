@@ -60,20 +60,25 @@ struct RowBatch {
 __device__ __forceinline__ void load_rows(const CondParams& p, const long long bt, const int chunk, const bool chunk_ok,
                                           RowBatch& rb) {
     const long long row0 = bt * kCR;
+    const bool cell_codes = p.mask_dtype == 3;          // VIBO_MASK_CODES: 1-byte cell codes through p.mask
 #pragma unroll
     for (int r = 0; r < kCR; ++r) {
         const long long row = row0 + r;
         rb.x[r] = float4{0.f, 0.f, 0.f, 0.f};
-        rb.m[r] = 0u;
+        rb.m[r] = cell_codes ? kAllMissing4 : 0u;
         if (row < p.B && chunk_ok) {
             const long long src = p.row_index ? p.row_index[row] : row;
-            rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
-            if (p.mask_dtype == 0)
+            if (!cell_codes) rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
+            if (p.mask_dtype == 0 || cell_codes)
                 rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
             else
                 rb.m[r] = 0x01010101u;
         }
     }
+}
+// fp8 codes of row r of the batch (either row format)
+__device__ __forceinline__ uint32_t row_codes(const CondParams& p, const RowBatch& rb, const int r, const uint32_t tail_mask, int& pk) {
+    return p.mask_dtype == 3 ? pack_cell_codes4(rb.m[r], tail_mask, pk) : pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
 }
 
 // ---------------------------------------------------------------------------
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
             int pk = 0;
-            const uint32_t cw = pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
+            const uint32_t cw = row_codes(p, rb, r, tail_mask, pk);
             const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, false);
             const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, true);
             const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const C
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
             int pk = 0;
-            cw[r] = pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
+            cw[r] = row_codes(p, rb, r, tail_mask, pk);
         }
         if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
         // this batch's coefficients (sum over the panels' shares), wave-private copy

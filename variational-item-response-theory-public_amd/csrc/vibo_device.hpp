@@ -83,4 +83,15 @@ __device__ __forceinline__ uint32_t pack_codes4(const float4 x, const uint32_t m
     return code;
 }
 
+// Format P: 4 one-byte cell codes (0 = answered wrong, 1 = answered right, 2 = missing; VIBO_MASK_CODES) -> the same
+// fp8 codes / packed counts.  `keep` = 0xFF for the bytes that belong to the row (padding past the row's end is dropped).
+__device__ __forceinline__ uint32_t pack_cell_codes4(const uint32_t w, const uint32_t keep, int& packed) {
+    const uint32_t xb = w & 0x01010101u;
+    const uint32_t m = (((w >> 1) & 0x01010101u) ^ 0x01010101u) & keep;
+    const uint32_t code = (0xB8B8B8B8u ^ (xb << 7)) & ((m << 8) - m);
+    packed += __builtin_popcount(m) + (__builtin_popcount(xb & m) << 16);
+    return code;
+}
+constexpr uint32_t kAllMissing4 = 0x02020202u;
+
 }  // namespace vibo

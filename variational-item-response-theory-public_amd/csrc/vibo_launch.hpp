@@ -26,5 +26,13 @@ hipError_t launch_elbo_rows(const ElboParams& p, int irt, bool grad, int grid, h
 hipError_t launch_elbo_split_a2(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
 hipError_t launch_elbo_split_a4(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
 hipError_t launch_elbo_split_a8(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+// the same kernels gathering the fp32 rows through row_index
+hipError_t launch_elbo_split_g2(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+hipError_t launch_elbo_split_g4(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+hipError_t launch_elbo_split_g8(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+// the same kernels reading 1-byte cell codes (VIBO_MASK_CODES)
+hipError_t launch_elbo_split_c2(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+hipError_t launch_elbo_split_c4(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
+hipError_t launch_elbo_split_c8(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
 
 }  // namespace vibo

@@ -108,20 +108,29 @@ __global__ __launch_bounds__(256, 2) void multi_forward_kernel(const MultiParams
     const float mt0 = cl.ctab[(1 * 2 + 0) * AT + ed], mt1 = cl.ctab[(1 * 2 + 1) * AT + ed];
 
     const long long n_batches = ((long long)p.B + R - 1) / R;
+    const bool cell_codes = p.mask_dtype == 3;          // VIBO_MASK_CODES: 1-byte cell codes through p.mask
     float4 x[R];
     uint32_t m[R];
     float epn[SC];
     auto load_batch = [&](const long long bt) {
         const long long row0 = bt * R;
+        long long srcs[R];               // (row indices first: see the row-split kernel)
+#pragma unroll
+        for (int r = 0; r < R; ++r) srcs[r] = row0 + r;
+        if (p.row_index) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (row0 + r < p.B) srcs[r] = p.row_index[row0 + r];
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long row = row0 + r;
             x[r] = float4{0.f, 0.f, 0.f, 0.f};
-            m[r] = 0u;
+            m[r] = cell_codes ? kAllMissing4 : 0u;
             if (row < p.B && chunk_ok) {
-                const long long src = p.row_index ? p.row_index[row] : row;
-                x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
-                if (p.mask_dtype == 0)
+                const long long src = srcs[r];
+                if (!cell_codes) x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
+                if (p.mask_dtype == 0 || cell_codes)
                     m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
                 else
                     m[r] = 0x01010101u;
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void multi_forward_kernel(const MultiParams
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             pk[r] = 0;
-            wl.codes[r][lane] = pack_codes4(x[r], m[r] & tail_mask, pk[r]);
+            wl.codes[r][lane] = cell_codes ? pack_cell_codes4(m[r], tail_mask, pk[r]) : pack_codes4(x[r], m[r] & tail_mask, pk[r]);
         }
         float eps_c[SC];
 #pragma unroll

@@ -1,0 +1,8 @@
+// row-split ELBO kernel gathering fp32 rows through row_index (shuffled minibatches), template ability width 2
+#include "vibo_split_kernel.hpp"
+#include "vibo_launch.hpp"
+namespace vibo {
+hipError_t launch_elbo_split_g2(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s) {
+    return launch_split_at<2, 1>(p, irt, grad, nq, grid, s);
+}
+}  // namespace vibo

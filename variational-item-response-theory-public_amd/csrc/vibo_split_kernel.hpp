@@ -106,8 +106,13 @@ inline size_t split_lds_bytes(int nq, bool flows) {
 // AT = template ability width (2, 4 or 8; runtime p.A <= AT); blockDim.x = 64 nq, nq = ceil(I / 256).
 // NQT = nq as a compile-time constant with static LDS (4: the 768 < I <= 1024 shapes the benchmarks use), or 0 for
 // a runtime nq with dynamic LDS.
-template <int AT, int IRT, bool GRAD, bool FLOWS, int NQT>
-__global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
+// RM (row mode): 0 = fp32 responses + mask bytes, rows in order; 1 = the same through p.row_index (shuffled minibatch);
+// 2 = 1-byte cell codes (VIBO_MASK_CODES, read through p.mask), with or without p.row_index.  Without the 40 row
+// registers of the fp32 layout the width-2 kernels fit 3 waves per SIMD (a few spills; 1.11 -> 0.95 ms on 1M x 1k 2PL,
+// 1.73 -> 1.38 ms 3PL); the fp32 layout at 3 waves spills ~100 registers (2.7 ms).
+template <int AT, int IRT, bool GRAD, bool FLOWS, int NQT, int RM = 0>
+__global__ __launch_bounds__(256, (RM == 2 && AT <= 2) ? 3 : 2) void split_kernel(const ElboParams p) {
+    constexpr bool CODES = RM == 2, GATHER = RM == 1;
     constexpr int R = kSplitRows;
     // rows per d LL/d theta reduction group: 8 / AT fills the 8-value reduction; 3PL at width 2 takes half of that
     // (its longer per-term math would otherwise keep 16 terms' temporaries live and spill)
@@ -216,23 +221,61 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
     const float mt0 = cl.ctab[(1 * 2 + 0) * AT + ed], mt1 = cl.ctab[(1 * 2 + 1) * AT + ed];
 
     const long long n_batches = ((long long)p.B + R - 1) / R;
-    float4 x[R];
+    float4 x[CODES ? 1 : R];
     uint32_t m[R];
     float epn = 0.f;
     auto load_batch = [&](const long long bt) {
         const long long row0 = bt * R;
+        if constexpr (CODES) {
+            // gathered rows: all 8 (wave-uniform) row indices first, then the row loads back to back (an index load in
+            // front of every row load makes each row wait for the previous one's data)
+            long long src[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const long long row = row0 + r;
-            x[r] = float4{0.f, 0.f, 0.f, 0.f};
-            m[r] = 0u;
-            if (row < p.B && chunk_ok) {
-                const long long src = p.row_index ? p.row_index[row] : row;
-                x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
-                if (p.mask_dtype == 0)
-                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
-                else
-                    m[r] = 0x01010101u;
+            for (int r = 0; r < R; ++r) src[r] = row0 + r;
+            if (p.row_index) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (row0 + r < p.B) src[r] = p.row_index[row0 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                m[r] = kAllMissing4;
+                if (row0 + r < p.B && chunk_ok)
+                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src[r] * p.mask_stride + p.item0)[chunk];
+            }
+        } else if constexpr (GATHER) {
+            // the 8 row indices (wave-uniform, < 2^31) first, parked in scalar registers
+            int src[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) src[r] = row0 + r < p.B ? (int)p.row_index[row0 + r] : 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) src[r] = __builtin_amdgcn_readfirstlane(src[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                x[r] = float4{0.f, 0.f, 0.f, 0.f};
+                m[r] = 0u;
+                if (row0 + r < p.B && chunk_ok) {
+                    x[r] = reinterpret_cast<const float4*>(p.response + (long long)src[r] * p.resp_stride + p.item0)[chunk];
+                    if (p.mask_dtype == 0)
+                        m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + (long long)src[r] * p.mask_stride + p.item0)[chunk];
+                    else
+                        m[r] = 0x01010101u;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const long long row = row0 + r;
+                x[r] = float4{0.f, 0.f, 0.f, 0.f};
+                m[r] = 0u;
+                if (row < p.B && chunk_ok) {
+                    const long long src = p.row_index ? p.row_index[row] : row;
+                    x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
+                    if (p.mask_dtype == 0)
+                        m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
+                    else
+                        m[r] = 0x01010101u;
+                }
             }
         }
         const long long erow = row0 + er;
@@ -249,7 +292,8 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             pk[r] = 0;
-            wl.codes[r][lane] = pack_codes4(x[r], m[r] & tail_mask, pk[r]);   // mask at use: the loads stay in flight
+            if constexpr (CODES) wl.codes[r][lane] = pack_cell_codes4(m[r], tail_mask, pk[r]);
+            else wl.codes[r][lane] = pack_codes4(x[r], m[r] & tail_mask, pk[r]);   // mask at use: the loads stay in flight
         }
         const float eps_c = epn;
         if (bt + gridDim.x < n_batches) load_batch(bt + gridDim.x);
@@ -632,25 +676,25 @@ __global__ __launch_bounds__(256, 2) void split_kernel(const ElboParams p) {
     }
 }
 
-template <int AT, int IRT, bool GRAD>
+template <int AT, int IRT, bool GRAD, int RM>
 static hipError_t launch_split_flows(const ElboParams& p, int nq, int grid, hipStream_t s) {
     const bool flows = p.n_flows > 0;
     const size_t lds = split_lds_bytes(nq, flows);
     if (nq == 4) {
-        if (flows) hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, true, 4>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, false, 4>), dim3(grid), dim3(256), 0, s, p);
+        if (flows) hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, true, 4, RM>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, false, 4, RM>), dim3(grid), dim3(256), 0, s, p);
     } else {
-        if (flows) hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, true, 0>), dim3(grid), dim3(64 * nq), lds, s, p);
-        else hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, false, 0>), dim3(grid), dim3(64 * nq), lds, s, p);
+        if (flows) hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, true, 0, RM>), dim3(grid), dim3(64 * nq), lds, s, p);
+        else hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, false, 0, RM>), dim3(grid), dim3(64 * nq), lds, s, p);
     }
     return hipGetLastError();
 }
 
-template <int AT>
+template <int AT, int RM = 0>
 static hipError_t launch_split_at(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s) {
-    if (irt == 1) return grad ? launch_split_flows<AT, 1, true>(p, nq, grid, s) : launch_split_flows<AT, 1, false>(p, nq, grid, s);
-    if (irt == 2) return grad ? launch_split_flows<AT, 2, true>(p, nq, grid, s) : launch_split_flows<AT, 2, false>(p, nq, grid, s);
-    return grad ? launch_split_flows<AT, 3, true>(p, nq, grid, s) : launch_split_flows<AT, 3, false>(p, nq, grid, s);
+    if (irt == 1) return grad ? launch_split_flows<AT, 1, true, RM>(p, nq, grid, s) : launch_split_flows<AT, 1, false, RM>(p, nq, grid, s);
+    if (irt == 2) return grad ? launch_split_flows<AT, 2, true, RM>(p, nq, grid, s) : launch_split_flows<AT, 2, false, RM>(p, nq, grid, s);
+    return grad ? launch_split_flows<AT, 3, true, RM>(p, nq, grid, s) : launch_split_flows<AT, 3, false, RM>(p, nq, grid, s);
 }
 
 }  // namespace vibo

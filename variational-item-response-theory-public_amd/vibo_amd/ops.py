@@ -115,6 +115,71 @@ def prepare_mask(mask, keep_int64=False):
     return (mask != 0).contiguous().view(torch.uint8), _lib.MASK_U8
 
 
+class CellCodes:
+    """"Format P" rows: one byte per cell holding the whole cell (0 = answered wrong, 1 = answered right, 2 = missing;
+    VIBO_MASK_CODES of include/vibo_hip.h) instead of an fp32 response plus a mask byte -- 1 B instead of 5 B of HBM
+    per cell.  `codes` is a [P, I] uint8 view of rows padded to a multiple of 4 cells.  Passed wherever a `response`
+    tensor goes (with mask=None): model.forward / elbo_step / encode / log_marginal, FusedTrainer.step, fused_elbo."""
+    __slots__ = ('codes',)
+
+    def __init__(self, codes):
+        if codes.dtype != torch.uint8 or codes.dim() != 2 or codes.stride(1) != 1 or codes.stride(0) % 4 != 0:
+            raise ValueError('CellCodes: [P, I] uint8 rows with a stride that is a multiple of 4 (see pack_cell_codes)')
+        self.codes = codes
+
+    shape = property(lambda self: self.codes.shape)
+    device = property(lambda self: self.codes.device)
+
+    def dim(self):
+        return 2
+
+    def __len__(self):
+        return self.codes.shape[0]
+
+    def rows(self, index):
+        """CellCodes of the persons `index` (a copy, rows still padded to a multiple of 4 cells)."""
+        c = self.codes
+        stride = c.stride(0)
+        padded = c.as_strided((c.shape[0], stride), (stride, 1)) if c.shape[1] != stride else c
+        return CellCodes(padded[index][:, :c.shape[1]])
+
+    def unpack(self):
+        """-> (response fp32 [P, I] with -1 at missing cells, mask bool [P, I]) as the reference stores them
+        (datasets.py:928-940)."""
+        c = self.codes
+        mask = c != 2
+        return torch.where(mask, c.float(), c.new_full((), -1, dtype=torch.float32)), mask
+
+
+def pack_cell_codes(response, mask):
+    """Repack device-resident [P, I(,1)] responses (+ mask or None) into CellCodes with vibo_pack_codes (one pass)."""
+    lib = _lib.load()
+    response = prepare_response(response)
+    mask, code = prepare_mask(mask, keep_int64=True)
+    _require_device(response, mask)
+    P, I = response.shape
+    I4 = (I + 3) // 4 * 4
+    codes = torch.empty(P, I4, dtype=torch.uint8, device=response.device)
+    spec = ElboSpec(irt_model=1, ability_dim=1)
+    d = _make_desc(spec, P, I, code, _lib.REG_KL, False, response.stride(0), mask.stride(0) if mask is not None else 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(response.device).cuda_stream)
+    rc = lib.vibo_pack_codes(ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(codes), ctypes.c_int64(I4), stream)
+    _lib.check(rc, 'vibo_pack_codes')
+    return CellCodes(codes[:, :I])
+
+
+def prepare_rows(response, mask, keep_int64=False):
+    """-> (response tensor, mask tensor or None, VIBO_MASK_* code) as the library reads them.  CellCodes rows come back
+    as (codes, codes, MASK_CODES): the library ignores the response pointer then."""
+    if isinstance(response, CellCodes):
+        if mask is not None:
+            raise ValueError('CellCodes rows carry their own missingness: pass mask=None')
+        return response.codes, response.codes, _lib.MASK_CODES
+    response = prepare_response(response)
+    mask, code = prepare_mask(mask, keep_int64=keep_int64)
+    return response, mask, code
+
+
 def pad_rows(response, mask):
     """Device-resident copies of a [P, I] response / mask pair whose row strides are padded to a multiple of 4
     cells, returned as [P, I] views.  With I % 4 != 0 (CritLangAcq: 95 items) this keeps every row 16-byte aligned
@@ -336,8 +401,7 @@ def fused_elbo(spec, table, item, flow, response, mask, eps, *, reg_mode=_lib.RE
     table per ElboSpec.table_shape, item [I,D], eps [B,A], flow [n_flows,2A+1] or None.
     With row_index (int64 [B]) the rows response[row_index] / mask[row_index] are
     gathered inside the kernel (device-resident dataset, shuffled minibatches)."""
-    response = prepare_response(response)
-    mask, code = prepare_mask(mask)
+    response, mask, code = prepare_rows(response, mask)
     I = response.shape[1]
     spec.check_supported(I)
     B = int(row_index.numel()) if row_index is not None else response.shape[0]
@@ -352,8 +416,7 @@ def fused_elbo(spec, table, item, flow, response, mask, eps, *, reg_mode=_lib.RE
 
 def encode_posterior(spec, table, response, mask, row_index=None):
     """Forward-only q(ability | responses): (mu, logvar) [B,A] (models.py:356-371 under no_grad)."""
-    response = prepare_response(response)
-    mask, code = prepare_mask(mask)
+    response, mask, code = prepare_rows(response, mask)
     B = int(row_index.numel()) if row_index is not None else response.shape[0]
     return _BACKEND['encode'](spec, response, mask, code, row_index, table.detach().contiguous(), B)
 

@@ -340,9 +340,15 @@ class VIBO_1PL(nn.Module):
         with torch.no_grad():
             S = int(num_samples)
             if not self.conditional_posterior:
-                log_w = self._log_weights_multi(response, mask, S, eps_item, eps_ability)
+                if not isinstance(response, ops.CellCodes):
+                    response = ops.prepare_response(response)
+                    if response.shape[1] % 4 != 0 and response.stride(0) < (response.shape[1] + 3) // 4 * 4:
+                        # (a compact copy of e.g. 95-item rows: pad the minibatch so the multi-sample kernel applies)
+                        response, mask = ops.pad_rows(response, ops.prepare_mask(mask)[0])
+                log_w, eps_item, eps_ability = self._log_weights_multi(response, mask, S, eps_item, eps_ability)
                 if log_w is not None:
                     return torch.logsumexp(log_w, 0) - math.log(S)
+                # not covered (fewer than 4 items, ...): the loop below replays the noise already drawn
             log_w = []
             for s in range(S):
                 ctx = self._run_fused(response, mask, reg_mode=_lib.REG_SAMPLED,
@@ -358,15 +364,15 @@ class VIBO_1PL(nn.Module):
 
     def _log_weights_multi(self, response, mask, S, eps_item, eps_ability):
         """log w_s for s < S through the multi-sample forward kernel, or None if the configuration is not covered."""
-        response = ops.prepare_response(response)
-        mask2, code = ops.prepare_mask(mask)
+        response, mask2, code = ops.prepare_rows(response, mask)
         if code == _lib.MASK_I64:
-            return None
+            return None, eps_item, eps_ability
         B = response.shape[0]
         item_mu, item_lv = self.item_encoder()
-        items, log_qd, log_pd, eps_ab = [], [], [], []
+        items, log_qd, log_pd, eps_ab, drawn_items = [], [], [], [], []
         for s in range(S):                      # draw order of the reference's loop: item eps, then ability eps
             e_i = self._randn(item_mu.shape, item_mu, self._item_gen) if eps_item is None else eps_item[s]
+            drawn_items.append(e_i)
             item_feat = e_i * torch.exp(0.5 * item_lv) + item_mu
             lq = _normal_logpdf(item_feat, item_mu, item_lv).sum()
             item_k = item_feat
@@ -384,8 +390,8 @@ class VIBO_1PL(nn.Module):
                                    torch.stack(items).contiguous(), torch.stack(eps_ab).contiguous(), flow_packed,
                                    _lib.REG_SAMPLED, B)
         if sc is None:
-            return None
-        return sc[:, _lib.S_LL] - sc[:, _lib.S_REG] + torch.stack(log_pd) - torch.stack(log_qd)
+            return None, (torch.stack(drawn_items) if eps_item is None else eps_item), torch.stack(eps_ab)
+        return sc[:, _lib.S_LL] - sc[:, _lib.S_REG] + torch.stack(log_pd) - torch.stack(log_qd), eps_item, eps_ability
 
     # ---- fast path for training loops (no tuple round trip) -------------------
     def elbo_step(self, response, mask, annealing_factor=1.0, row_index=None):

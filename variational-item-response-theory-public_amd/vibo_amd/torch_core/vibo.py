@@ -70,6 +70,11 @@ def build_parser():
     # additive (not in the reference)
     p.add_argument('--torch-optimizer', action='store_true', default=False,
                    help='use autograd + torch.optim.Adam for the O(I) part instead of the fused HIP trainer kernels')
+    p.add_argument('--row-format', choices=['auto', 'f32', 'codes'], default='auto',
+                   help="device-resident rows: 'f32' = the reference's fp32 responses + mask bytes (5 B/cell), 'codes' = "
+                        "one byte per cell (same results, a fifth of the memory and HBM traffic); 'auto' = codes "
+                        "whenever the fused kernels support them (--cuda, 4..32767 items, ability dim <= 4 with "
+                        "--conditional-posterior)")
     p.add_argument('--no-graph', action='store_true', default=False,
                    help='launch every fused train step eagerly instead of replaying a hipGraph (single-GPU runs)')
     p.add_argument('--store-predictive-samples', action='store_true', default=False,
@@ -107,16 +112,26 @@ def out_dir_name(args):
 
 
 class ResidentSplit:
-    """One dataset split resident on the device: response f32 [P,I], mask bool [P,I]."""
+    """One dataset split resident on the device: response f32 [P,I] + mask bool [P,I] (the reference's layout, 5 B per
+    cell), or with row_format='codes' one byte per cell (ops.CellCodes; mask is None then)."""
 
-    def __init__(self, dataset, device, row_slice=None):
+    def __init__(self, dataset, device, row_slice=None, row_format='f32'):
         r, m = dataset.matrix()
         if row_slice is not None:
             r, m = r[row_slice], m[row_slice]
         # rows padded to 16 bytes when the item count is not a multiple of 4 (vector loads of the row-split kernel)
-        self.response, self.mask = ops.pad_rows(torch.from_numpy(r).to(device), torch.from_numpy(m).to(device))
+        if row_format == 'codes':
+            self.response, self.mask = ops.pack_cell_codes(torch.from_numpy(r).to(device), torch.from_numpy(m).to(device)), None
+        else:
+            self.response, self.mask = ops.pad_rows(torch.from_numpy(r).to(device), torch.from_numpy(m).to(device))
         self.num_person, self.num_item = self.response.shape
         self.device = device
+
+    def rows(self, index):
+        """(response, mask) of the persons `index` as their own small matrices."""
+        if isinstance(self.response, ops.CellCodes):
+            return self.response.rows(index), None
+        return self.response[index], self.mask[index]
 
     def num_batches(self, batch_size):
         return (self.num_person + batch_size - 1) // batch_size
@@ -211,7 +226,7 @@ def log_marginal_density(model, data, args, batch_size):
     meter = AverageMeter()
     with torch.no_grad():
         for rows in data.batches(batch_size, shuffle=False):
-            r, m = data.response[rows], data.mask[rows]
+            r, m = data.rows(rows)
             marginal = model.log_marginal(r, m, num_samples=args.num_posterior_samples)
             meter.update(float(torch.mean(marginal)), rows.numel())
     print('====> Marginal: {:.4f}'.format(meter.avg))
@@ -315,8 +330,14 @@ def main(argv=None):
     # persons are sharded in contiguous blocks over the ranks
     def shard(n):
         return slice(rank * n // world, (rank + 1) * n // world) if world > 1 else None
-    train = ResidentSplit(train_dataset, device, shard(train_dataset.num_person))
-    test = ResidentSplit(test_dataset, device, shard(test_dataset.num_person))
+    row_format = args.row_format
+    codes_ok = bool(args.cuda) and 4 <= num_item <= 32767 and not (args.conditional_posterior and args.ability_dim > 4)
+    if row_format == 'auto':
+        row_format = 'codes' if codes_ok else 'f32'
+    elif row_format == 'codes' and not codes_ok:
+        raise SystemExit('--row-format codes needs --cuda, 4..32767 items and ability dim <= 4 with --conditional-posterior')
+    train = ResidentSplit(train_dataset, device, shard(train_dataset.num_person), row_format)
+    test = ResidentSplit(test_dataset, device, shard(test_dataset.num_person), row_format)
     local_bs = max(1, args.batch_size // world)
     n_batches = train.num_batches(local_bs)
     if args.max_iters != -1:
@@ -366,7 +387,7 @@ def main(argv=None):
         dist.barrier()
     if rank == 0:      # post-hoc enrichment (rank 0, on the whole split)
         if world > 1:
-            train, test = ResidentSplit(train_dataset, device), ResidentSplit(test_dataset, device)
+            train, test = ResidentSplit(train_dataset, device, None, row_format), ResidentSplit(test_dataset, device, None, row_format)
             local_bs = args.batch_size
         for name in ('checkpoint.pth.tar', 'model_best.pth.tar'):
             path = os.path.join(args.out_dir, name)

@@ -87,8 +87,7 @@ class FusedTrainer:
         if beta is not None:
             self.set_beta(beta)
         model, spec, lib = self.model, self.model.spec, _lib.load()
-        response = ops.prepare_response(response)
-        mask, code = ops.prepare_mask(mask)
+        response, mask, code = ops.prepare_rows(response, mask)
         B = int(row_index.numel()) if row_index is not None else response.shape[0]
         I = response.shape[1]
         dev = response.device
