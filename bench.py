@@ -57,6 +57,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=8)
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
+    ap.add_argument('--no-format-p', action='store_true', help='skip the extra Format P (1-byte cell codes) measurement of the same step')
     ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
     ap.add_argument('--rng', choices=['native', 'torch'], default='native', help='reparameterisation noise: vibo_fill_normal (Philox, in the C ABI) or torch.randn')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
@@ -158,10 +159,13 @@ def main():
     from vibo_amd import ops
     from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
 
-    def measure(A):
+    def measure(A, codes=False):
         """-> dict(dt, kern_ms, final_loss, graph) for ability_dim A on this rank's shard."""
         P, I = args.persons, args.items
         resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
+        if codes:           # Format P: the same matrix as one byte per cell (VIBO_MASK_CODES)
+            resp, mask = ops.pack_cell_codes(resp, mask), None
+            torch.cuda.empty_cache()
         torch.manual_seed(args.seed)
         model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge='product').to(dev)
         if dist is not None:
@@ -305,6 +309,18 @@ def main():
                 'roofline_frac': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 8000.0,
                 'roofline_frac_of_measured_copy_peak': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 6290.0}
 
+    format_p = None
+    if not args.no_format_p:
+        m3 = measure(A, codes=True)
+        b3 = 1.0 + 12.0 * A / I
+        format_p = {'workload': 'same matrix and step as the headline, rows stored as 1-byte cell codes (Format P, VIBO_MASK_CODES): '
+                                'reported separately, its own bytes figure, never mixed with the headline roofline',
+                    'value': float(P) * I * args.steps * world / m3['dt'], 'unit': 'terms/s', 'ms_per_step': m3['dt'] / args.steps * 1e3,
+                    'kernel_ms': m3['kern_ms'], 'bytes_per_term': b3,
+                    'roofline_achieved_GBps': b3 * P * I / (m3['kern_ms'] * 1e-3) / 1e9,
+                    'roofline_frac': b3 * P * I / (m3['kern_ms'] * 1e-3) / 1e9 / 8000.0,
+                    'bound': 'valu (latency / issue), not hbm', 'final_loss_per_term': m3['final_loss'] / (P * I * world)}
+
     # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of
     # MI355X_MICROARCH.md) cannot be collected from inside this process; for the default workload the value
     # recorded in profiles/r01_bench_profile.txt is reported, otherwise null.
@@ -338,6 +354,8 @@ def main():
         }
         if also is not None:
             line['also'] = also
+        if format_p is not None:
+            line['format_p'] = format_p
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, irt)
         print(json.dumps(line))

@@ -20,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
 ap.add_argument('--seed', type=int, default=0)
 ap.add_argument('--target', choices=['elbo', 'multi', 'module', 'trainer'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
-ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only" of a reported failure')
+ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only codes" of a reported failure')
 a = ap.parse_args()
 rng = random.Random(a.seed)
 d = torch.device('cuda:0')
@@ -246,11 +246,13 @@ while time.time() - t0 < a.seconds:
     gather = rng.random() < 0.3          # minibatch as a row-index vector over a larger resident matrix
     no_mask = missing == 0.0 and rng.random() < 0.3
     fwd_only = rng.random() < 0.2
+    codes = rng.random() < 0.35 and not no_mask and not (cond and A > 4)      # rows as 1-byte cell codes (Format P)
     if a.replay:
         f = a.replay.split()
         irt, A, B, I, n_flows, dataseed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])
         cond, drop, pad, missing, scale = f[4] == 'True', f[6] == 'True', f[8] == 'True', float(f[7]), float(f[9])
         gather, no_mask, fwd_only = f[11] == 'True', f[12] == 'True', f[13] == 'True'
+        codes = len(f) > 14 and f[14] == 'True'
     spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, drop_missing=drop, n_flows=n_flows)
     g = torch.Generator().manual_seed(dataseed)
     P = B + rng.choice([3, 50]) if gather else B
@@ -278,8 +280,9 @@ while time.time() - t0 < a.seconds:
     ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt, ability_dim=A,
                            conditional_posterior=cond, replace_missing_with_prior=not drop, mode=mode, flow_uhat_w_b=flows)
     r_, m_ = (ops.pad_rows(resp_all.to(d), mask_all.bool().to(d)) if pad else (resp_all.to(d), mask_all.bool().to(d)))
-    r = ops.prepare_response(r_)
-    m, code = ops.prepare_mask(None if no_mask else m_)
+    if codes:
+        r_, m_ = ops.pack_cell_codes(resp_all.to(d), mask_all.bool().to(d)), None
+    r, m, code = ops.prepare_rows(r_, None if no_mask else m_)
     raw = ops._hip_launch_elbo(spec, r, m, code, rows.to(d) if gather else None, table.to(d).contiguous(), item.to(d).contiguous(),
                                eps.to(d).contiguous(), flow.to(d).contiguous() if flow is not None else None,
                                _lib.REG_SAMPLED if n_flows else _lib.REG_KL, not fwd_only, B)
@@ -313,7 +316,7 @@ while time.time() - t0 < a.seconds:
         print('replayed:', errs)
         sys.exit(1 if bad else 0)
     if bad:
-        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only}: {bad}')
-        print(f'replay: --replay "{irt} {A} {B} {I} {cond} {n_flows} {drop} {missing} {pad} {scale} {dataseed}"')
+        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only} codes={codes}: {bad}')
+        print(f'replay: --replay "{irt} {A} {B} {I} {cond} {n_flows} {drop} {missing} {pad} {scale} {dataseed} {gather} {no_mask} {fwd_only} {codes}"')
         sys.exit(1)
 print(f'fuzz ok: {n} random configurations, worst relative error {worst:.2e}')

@@ -97,8 +97,10 @@ def main():
         g = torch.Generator().manual_seed(rng.randrange(1 << 30))
         resp, mask = O.simulate_responses(irt, B + 5, I, A, generator=g, missing_frac=rng.choice([0.0, 0.2]))
         r_, m_ = ops.pad_rows(resp.to(d), mask.bool().to(d))
-        r = ops.prepare_response(r_)
-        m, code = ops.prepare_mask(m_)
+        use_codes = rng.random() < 0.4 and not (cond and A > 4) and I >= 4
+        if use_codes:
+            r_, m_ = ops.pack_cell_codes(r_, m_), None
+        r, m, code = ops.prepare_rows(r_, m_)
         rows = torch.randperm(B + 5, generator=g)[:B].to(d) if rng.random() < 0.5 else None
         if rows is None:
             r, m = r[:B], m[:B]
@@ -108,7 +110,7 @@ def main():
         eps = torch.randn(B, A, generator=g).to(d)
         fl = (torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5).to(d) if n_flows else None
         reg = _lib.REG_SAMPLED if n_flows else rng.choice([_lib.REG_KL, _lib.REG_SAMPLED])
-        cfg = (irt, A, B, I, cond, n_flows, rows is not None, reg)
+        cfg = (irt, A, B, I, cond, n_flows, rows is not None, reg, use_codes)
         exact = (not cond) and 4 <= I <= 1024      # row-split path: partial records + fp64 finalize, no atomics
         for want_grad in (False, True):
             res = []

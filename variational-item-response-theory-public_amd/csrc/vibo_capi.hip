@@ -110,6 +110,11 @@ static int codes_unsupported() {
                     "stride that pads them to a multiple of 4 cells, ability_dim <= 4 with the conditional posterior");
 }
 
+// cell-code rows leave room for a third wave per SIMD in the narrower row-split kernels (see split_kernel's launch bounds)
+static bool codes_three_waves(const vibo_desc* d, int AT) {
+    return d->mask_dtype == VIBO_MASK_CODES && (AT <= 2 || (AT == 4 && d->irt_model <= 2));
+}
+
 static int make_plan(const vibo_desc* d, Plan* pl) {
     const int I = d->num_item, A = d->ability_dim;
     pl->AT = padded_ability_dim(A);
@@ -144,7 +149,7 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
         pl->split_nq = 4;
-        pl->split_nblk = g_num_cu * ((d->want_grad && !(d->mask_dtype == VIBO_MASK_CODES && pl->AT <= 2)) ? 2 : 3);
+        pl->split_nblk = g_num_cu * ((d->want_grad && !codes_three_waves(d, pl->AT)) ? 2 : 3);
         if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
         pl->nblk = 0;
         pl->lds_main = 0;
@@ -225,7 +230,7 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
             pl->DP = prepped_item_width(d->irt_model, at_min);
         }
     }
-    pl->split_nblk = g_num_cu * (((d->want_grad && !(d->mask_dtype == VIBO_MASK_CODES && pl->AT <= 2)) ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
+    pl->split_nblk = g_num_cu * (((d->want_grad && !codes_three_waves(d, pl->AT)) ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
     if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;

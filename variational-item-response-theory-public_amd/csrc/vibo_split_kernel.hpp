@@ -111,7 +111,7 @@ inline size_t split_lds_bytes(int nq, bool flows) {
 // registers of the fp32 layout the width-2 kernels fit 3 waves per SIMD (a few spills; 1.11 -> 0.95 ms on 1M x 1k 2PL,
 // 1.73 -> 1.38 ms 3PL); the fp32 layout at 3 waves spills ~100 registers (2.7 ms).
 template <int AT, int IRT, bool GRAD, bool FLOWS, int NQT, int RM = 0>
-__global__ __launch_bounds__(256, (RM == 2 && AT <= 2) ? 3 : 2) void split_kernel(const ElboParams p) {
+__global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))) ? 3 : 2) void split_kernel(const ElboParams p) {
     constexpr bool CODES = RM == 2, GATHER = RM == 1;
     constexpr int R = kSplitRows;
     // rows per d LL/d theta reduction group: 8 / AT fills the 8-value reduction; 3PL at width 2 takes half of that
@@ -227,21 +227,22 @@ __global__ __launch_bounds__(256, (RM == 2 && AT <= 2) ? 3 : 2) void split_kerne
     auto load_batch = [&](const long long bt) {
         const long long row0 = bt * R;
         if constexpr (CODES) {
-            // gathered rows: all 8 (wave-uniform) row indices first, then the row loads back to back (an index load in
-            // front of every row load makes each row wait for the previous one's data)
-            long long src[R];
+            // gathered rows: all 8 (wave-uniform, < 2^31) row indices first, parked in scalar registers, then the row
+            // loads back to back (an index load in front of every row load makes each row wait for the previous one)
+            int src[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) src[r] = row0 + r;
+            for (int r = 0; r < R; ++r) src[r] = (int)row0 + r;
             if (p.row_index) {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (row0 + r < p.B) src[r] = p.row_index[row0 + r];
+                for (int r = 0; r < R; ++r) src[r] = row0 + r < p.B ? (int)p.row_index[row0 + r] : 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) src[r] = __builtin_amdgcn_readfirstlane(src[r]);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 m[r] = kAllMissing4;
                 if (row0 + r < p.B && chunk_ok)
-                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src[r] * p.mask_stride + p.item0)[chunk];
+                    m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + (long long)src[r] * p.mask_stride + p.item0)[chunk];
             }
         } else if constexpr (GATHER) {
             // the 8 row indices (wave-uniform, < 2^31) first, parked in scalar registers
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, (RM == 2 && AT <= 2) ? 3 : 2) void split_kerne
                 x[r] = float4{0.f, 0.f, 0.f, 0.f};
                 m[r] = 0u;
                 if (row < p.B && chunk_ok) {
-                    const long long src = p.row_index ? p.row_index[row] : row;
+                    const long long src = row;          // (rows through p.row_index take the RM = 1 instantiation)
                     x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
                     if (p.mask_dtype == 0)
                         m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
