@@ -14,7 +14,9 @@ S=$OUT/profile_summary.txt
 echo "# command: rocprofv3 --kernel-trace --stats -- $B"
 rocprofv3 --kernel-trace --stats -d $W/kt -o kt -- $B > $W/kt.log 2>&1
 echo "# bench line under the profiler:"; grep "^{" $W/kt.log
-python $R/tools/rocpd_summary.py $W/kt/kt_results.db | head -12
+python $R/tools/rocpd_summary.py $W/kt/kt_results.db | head -14
+echo "# the library's own kernels:"
+python $R/tools/rocpd_summary.py $W/kt/kt_results.db vibo
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   n=$(echo $pass | cut -d' ' -f1)
   echo; echo "# command: rocprofv3 --pmc $pass -- $B     (per-dispatch averages, vibo kernels only)"

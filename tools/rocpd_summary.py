@@ -44,4 +44,4 @@ if n:
         short = name.split('(')[0][-70:]
         if flt and flt not in short:
             continue
-        print(f'  {short[-40:]:40s} {ctr:28s} {val / nd[short]:16.0f}')
+        print(f'  {short[-52:]:52s} {ctr:28s} {val / nd[short]:16.0f}')

@@ -53,23 +53,25 @@ __device__ __forceinline__ uint32_t chunk_tail_mask(const CondParams& p, const i
     return ((p.I & 3) && chunk == (p.I >> 2)) ? ((1u << (8 * (p.I & 3))) - 1u) : 0xFFFFFFFFu;
 }
 
+// CODES: the rows are 1-byte cell codes (VIBO_MASK_CODES through p.mask): no fp32 row registers
+template <bool CODES>
 struct RowBatch {
-    float4 x[kCR];
+    float4 x[CODES ? 1 : kCR];
     uint32_t m[kCR];
 };
+template <bool CODES>
 __device__ __forceinline__ void load_rows(const CondParams& p, const long long bt, const int chunk, const bool chunk_ok,
-                                          RowBatch& rb) {
+                                          RowBatch<CODES>& rb) {
     const long long row0 = bt * kCR;
-    const bool cell_codes = p.mask_dtype == 3;          // VIBO_MASK_CODES: 1-byte cell codes through p.mask
 #pragma unroll
     for (int r = 0; r < kCR; ++r) {
         const long long row = row0 + r;
-        rb.x[r] = float4{0.f, 0.f, 0.f, 0.f};
-        rb.m[r] = cell_codes ? kAllMissing4 : 0u;
+        if constexpr (!CODES) rb.x[r] = float4{0.f, 0.f, 0.f, 0.f};
+        rb.m[r] = CODES ? kAllMissing4 : 0u;
         if (row < p.B && chunk_ok) {
             const long long src = p.row_index ? p.row_index[row] : row;
-            if (!cell_codes) rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
-            if (p.mask_dtype == 0 || cell_codes)
+            if constexpr (!CODES) rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
+            if (CODES || p.mask_dtype == 0)
                 rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
             else
                 rb.m[r] = 0x01010101u;
@@ -77,13 +79,15 @@ __device__ __forceinline__ void load_rows(const CondParams& p, const long long b
     }
 }
 // fp8 codes of row r of the batch (either row format)
-__device__ __forceinline__ uint32_t row_codes(const CondParams& p, const RowBatch& rb, const int r, const uint32_t tail_mask, int& pk) {
-    return p.mask_dtype == 3 ? pack_cell_codes4(rb.m[r], tail_mask, pk) : pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
+template <bool CODES>
+__device__ __forceinline__ uint32_t row_codes(const RowBatch<CODES>& rb, const int r, const uint32_t tail_mask, int& pk) {
+    if constexpr (CODES) return pack_cell_codes4(rb.m[r], tail_mask, pk);
+    else return pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
 }
 
 // ---------------------------------------------------------------------------
-template <int AT>
-__global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
+template <int AT, bool CODES>
+__global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const CondParams p) {
     constexpr int NV = 2 * AT + 1;
     __shared__ float part[4][kCR][NV];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
             }
         }
     const long long n_batches = ((long long)p.B + kCR - 1) / kCR;
-    RowBatch rb;
+    RowBatch<CODES> rb;
     long long bt = blockIdx.x;
     if (bt < n_batches) load_rows(p, bt, chunk, chunk_ok, rb);
     for (; bt < n_batches; bt += gridDim.x) {
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
             int pk = 0;
-            const uint32_t cw = row_codes(p, rb, r, tail_mask, pk);
+            const uint32_t cw = row_codes(rb, r, tail_mask, pk);
             const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, false);
             const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, true);
             const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256, 2) void cond_pre_kernel(const CondParams p) {
 }
 
 // ---------------------------------------------------------------------------
-template <int AT>
-__global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const CondParams p) {
+template <int AT, bool CODES>
+__global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_kernel(const CondParams p) {
     constexpr int NC = 4 * AT;                       // coefficients per person: [head][P1|P2][dim]
     __shared__ __attribute__((aligned(16))) float cbuf[4][kCR][NC];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const C
 #pragma unroll
             for (int k = 0; k < NC; ++k) S[j][c][k] = 0.f;
     const long long n_batches = ((long long)p.B + kCR - 1) / kCR;
-    RowBatch rb;
+    RowBatch<CODES> rb;
     long long bt = blockIdx.x;
     if (bt < n_batches) load_rows(p, bt, chunk, chunk_ok, rb);
     for (; bt < n_batches; bt += gridDim.x) {
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? 2 : 1) void cond_post_kernel(const C
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
             int pk = 0;
-            cw[r] = row_codes(p, rb, r, tail_mask, pk);
+            cw[r] = row_codes(rb, r, tail_mask, pk);
         }
         if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
         // this batch's coefficients (sum over the panels' shares), wave-private copy
@@ -280,13 +284,25 @@ __global__ __launch_bounds__(1024) void cond_finalize_kernel(const float* __rest
 }
 
 hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
-    if (at <= 2) hipLaunchKernelGGL(cond_pre_kernel<2>, dim3(grid), dim3(64 * nq), 0, s, p);
-    else hipLaunchKernelGGL(cond_pre_kernel<4>, dim3(grid), dim3(64 * nq), 0, s, p);
+    const bool codes = p.mask_dtype == 3;      // VIBO_MASK_CODES
+    if (at <= 2) {
+        if (codes) hipLaunchKernelGGL((cond_pre_kernel<2, true>), dim3(grid), dim3(64 * nq), 0, s, p);
+        else hipLaunchKernelGGL((cond_pre_kernel<2, false>), dim3(grid), dim3(64 * nq), 0, s, p);
+    } else {
+        if (codes) hipLaunchKernelGGL((cond_pre_kernel<4, true>), dim3(grid), dim3(64 * nq), 0, s, p);
+        else hipLaunchKernelGGL((cond_pre_kernel<4, false>), dim3(grid), dim3(64 * nq), 0, s, p);
+    }
     return hipGetLastError();
 }
 hipError_t launch_cond_post(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
-    if (at <= 2) hipLaunchKernelGGL(cond_post_kernel<2>, dim3(grid), dim3(64 * nq), 0, s, p);
-    else hipLaunchKernelGGL(cond_post_kernel<4>, dim3(grid), dim3(64 * nq), 0, s, p);
+    const bool codes = p.mask_dtype == 3;
+    if (at <= 2) {
+        if (codes) hipLaunchKernelGGL((cond_post_kernel<2, true>), dim3(grid), dim3(64 * nq), 0, s, p);
+        else hipLaunchKernelGGL((cond_post_kernel<2, false>), dim3(grid), dim3(64 * nq), 0, s, p);
+    } else {
+        if (codes) hipLaunchKernelGGL((cond_post_kernel<4, true>), dim3(grid), dim3(64 * nq), 0, s, p);
+        else hipLaunchKernelGGL((cond_post_kernel<4, false>), dim3(grid), dim3(64 * nq), 0, s, p);
+    }
     return hipGetLastError();
 }
 hipError_t launch_cond_finalize(const float* partial, float* grad_table, int I, int A, int panels, int bpp, int rec_stride,
