@@ -31,7 +31,13 @@ extern "C" {
 #define VIBO_ABI_VERSION 1
 
 enum { VIBO_IRT_1PL = 1, VIBO_IRT_2PL = 2, VIBO_IRT_3PL = 3 };
-enum { VIBO_POSTERIOR_UNCONDITIONAL = 0, VIBO_POSTERIOR_CONDITIONAL = 1 };
+enum { VIBO_POSTERIOR_UNCONDITIONAL = 0, VIBO_POSTERIOR_CONDITIONAL = 1,
+       VIBO_POSTERIOR_GIVEN = 2 };   /* q(theta_p) = N(mu_p, exp(logvar_p)) computed by the caller: `table` is [B][2A]
+                                        (mu | logvar per person) and `grad_table` comes back as [2][B][2A].  This is
+                                        the --ability-merge mean encoder (models.py:584-594, 631-650): its per-person
+                                        input is the mean of two feature vectors weighted by the counts of
+                                        vibo_row_counts, followed by a dense [B,H]x[H,H] MLP that stays with the
+                                        caller's GEMM library.  Row-split path only (4..32767 items, chunkable rows). */
 enum { VIBO_MISSING_PRIOR = 0,   /* missing cell -> N(0,1) prior expert (models.py:613-620) */
        VIBO_MISSING_DROP = 1 };  /* --drop-missing: expert removed      (vibo.py:217)       */
 enum { VIBO_MASK_U8 = 0,         /* torch.bool / uint8, 1 byte per cell (datasets.py:938)   */
@@ -118,6 +124,7 @@ size_t vibo_workspace_bytes(const vibo_desc* d);
  *  mask       [B rows x I] u8 or i64 per d->mask_dtype, nonzero = observed; NULL iff MASK_NONE
  *  row_index  [B] int64 rows of response/mask to process, or NULL for rows 0..B-1
  *  table      unconditional: [2][2A]    (row c = encoder([c]):      mu[0..A) | logvar[A..2A))
+ *             given:         [B][2A]    (the caller's posterior of every person of this call)
  *             conditional:   [2][I][2A] (entry = encoder([c, item_i]))
  *  item       [I][D] item sample d_i (after item flows if any): 2PL/3PL cols 0..A-1
  *             discrimination, col A difficulty, col A+1 guess logit (3PL); 1PL col 0 difficulty
@@ -160,6 +167,14 @@ int vibo_encode(const vibo_desc* d,
                 const float* table,
                 float* ability_mu, float* ability_logvar,
                 void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * counts[p] = n_correct << 16 | n_observed over the whole row of person p (any row layout / mask dtype, up to 32767
+ * items): the sufficient statistics of a Bernoulli response row for the unconditional encoders -- the product of
+ * experts (models.py:596-629) and the masked mean of --ability-merge mean (models.py:631-650: observed cells only).
+ */
+int vibo_row_counts(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index, int32_t* counts,
+                    void* stream);
 
 /*
  * Repack B rows from the reference's layout (fp32 `response`, `mask` per d->mask_dtype U8 / I64 / NONE, strides from d)

@@ -31,7 +31,7 @@ def _cfg(spec, reg_mode):
     return dict(irt_model=spec.irt_model, ability_dim=spec.ability_dim,
                 conditional_posterior=spec.conditional,
                 replace_missing_with_prior=not spec.drop_missing,
-                mode='kl' if reg_mode == 0 else 'sampled')
+                mode='kl' if reg_mode == 0 else 'sampled', given_posterior=getattr(spec, 'given', False))
 
 
 def install(ops):
@@ -75,6 +75,11 @@ def install(ops):
                                **_cfg(spec, 0))
         return out['ability_mu'], out['ability_logvar']
 
+    def counts(response, mask, mask_code, row_index):
+        resp, msk = _rows(response, mask, mask_code, row_index)
+        k = msk != 0
+        return (((resp == 1) & k).sum(1).to(torch.int32) << 16) | k.sum(1).to(torch.int32)
+
     def decode(spec, ability, item):
         from oracle.vibo_oracle import irt_link
         return irt_link(spec.irt_model, ability, item)
@@ -86,7 +91,7 @@ def install(ops):
         from oracle.vibo_oracle import irt_link
         return torch.stack([irt_link(spec.irt_model, abilities[s], items[s]) for s in range(abilities.shape[0])]).mean(0)
 
-    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean)
+    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts)
 
     def restore():
         ops._BACKEND.update(saved)

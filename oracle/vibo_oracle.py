@@ -78,6 +78,19 @@ def ability_posterior(params, response, mask, item_feat, *, ability_dim,
     if conditional_posterior:
         feat = item_feat.unsqueeze(0).expand(B, I, item_feat.shape[1]).reshape(B * I, -1)
         x = torch.cat([x, feat], dim=1)
+    if 'ability_encoder.mlp1.0.weight' in params:
+        # --ability-merge mean (models.py:584-594, 631-650): per-term features elu(mlp1(x)), mean over the OBSERVED
+        # items of the person (plain mean when nothing is missing), then mlp2 on the [B, H] means.  The
+        # replace-with-prior switch plays no role here.
+        pre = 'ability_encoder.mlp1'
+        h = F.elu(F.linear(x, params[f'{pre}.0.weight'], params[f'{pre}.0.bias']))
+        hid = F.elu(F.linear(h, params[f'{pre}.2.weight'], params[f'{pre}.2.bias'])).reshape(B, I, -1)
+        obs = mask.to(hid.dtype).unsqueeze(2)
+        hid_mean = (hid * obs).sum(1) / obs.sum(1)
+        pre = 'ability_encoder.mlp2'
+        h2 = F.elu(F.linear(hid_mean, params[f'{pre}.0.weight'], params[f'{pre}.0.bias']))
+        mu, logvar = torch.chunk(F.linear(h2, params[f'{pre}.2.weight'], params[f'{pre}.2.bias']), 2, dim=1)
+        return mu, logvar
     out = encoder_mlp(params, x)
     mu_set, lv_set = torch.chunk(out, 2, dim=1)
     mu_set = mu_set.reshape(B, I, ability_dim).permute(1, 0, 2)   # [I,B,A]
@@ -204,7 +217,7 @@ def elbo_loss_and_grads(params, response, mask, eps_item, eps_ability, **cfg):
 
 def init_params(irt_model, ability_dim, num_item, *, hidden_dim=64,
                 conditional_posterior=False, n_norm_flows=0, generator=None,
-                dtype=torch.float32):
+                dtype=torch.float32, ability_merge='product'):
     """Random parameters with the reference's shapes and init distributions
     (xavier-normal(gain=sqrt 2) linears with zero bias, N(0,1) embeddings and
     flow u/w, flow b = 1).  NOT bit-identical to the reference's RNG order --
@@ -214,10 +227,15 @@ def init_params(irt_model, ability_dim, num_item, *, hidden_dim=64,
     in_dim = 1 + (D if conditional_posterior else 0)
     dims = [(in_dim, hidden_dim), (hidden_dim, hidden_dim), (hidden_dim, 2 * ability_dim)]
     p = {}
-    for idx, (fi, fo) in zip((0, 2, 4), dims):
+    if ability_merge == 'mean':      # models.py:584-594
+        names = [('mlp1.0', in_dim, hidden_dim), ('mlp1.2', hidden_dim, hidden_dim),
+                 ('mlp2.0', hidden_dim, hidden_dim), ('mlp2.2', hidden_dim, 2 * ability_dim)]
+    else:
+        names = [(f'mlp.{idx}', fi, fo) for idx, (fi, fo) in zip((0, 2, 4), dims)]
+    for name, fi, fo in names:
         std = math.sqrt(2.0) * math.sqrt(2.0 / (fi + fo))
-        p[f'ability_encoder.mlp.{idx}.weight'] = torch.randn(fo, fi, generator=g, dtype=dtype) * std
-        p[f'ability_encoder.mlp.{idx}.bias'] = torch.zeros(fo, dtype=dtype)
+        p[f'ability_encoder.{name}.weight'] = torch.randn(fo, fi, generator=g, dtype=dtype) * std
+        p[f'ability_encoder.{name}.bias'] = torch.zeros(fo, dtype=dtype)
     p['item_encoder.mu_lookup.weight'] = torch.randn(num_item, D, generator=g, dtype=dtype)
     p['item_encoder.logvar_lookup.weight'] = torch.randn(num_item, D, generator=g, dtype=dtype)
     for name, dim in (('ability_norm_flows', ability_dim), ('item_norm_flows', D)):

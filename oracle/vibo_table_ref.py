@@ -60,7 +60,7 @@ def flow_uhat(u, w):
 
 def fused_elbo_ref(table, item, response, mask, eps, *, irt_model, ability_dim,
                    conditional_posterior=False, replace_missing_with_prior=True,
-                   mode='kl', flow_uhat_w_b=None, want_grad=True, exact_saturation=True):
+                   mode='kl', flow_uhat_w_b=None, want_grad=True, exact_saturation=True, given_posterior=False):
     """See module docstring.  table [2,2A] | [2,I,2A]; item [I,D]; response
     [B,I] (1.0 = correct); mask [B,I] (nonzero = observed); eps [B,A];
     flow_uhat_w_b: list of (uhat[A], w[A], b[1]) or None."""
@@ -71,8 +71,12 @@ def fused_elbo_ref(table, item, response, mask, eps, *, irt_model, ability_dim,
     x = (response == 1).to(dt)
     irt_model = int(irt_model)
 
+    # ---- caller-supplied posterior (VIBO_POSTERIOR_GIVEN: table = [B,2A] mu | logvar; --ability-merge mean) ----
+    if given_posterior:
+        m = s = tau_obs = None
+        k3 = k.unsqueeze(2)
     # ---- product of experts -------------------------------------------------
-    if conditional_posterior:
+    elif conditional_posterior:
         m_tab, s_tab = table[..., :A], table[..., A:]        # [2,I,A]
         c = x.long()                                         # [B,I]
         idx = torch.arange(I).unsqueeze(0).expand(B, I)
@@ -82,18 +86,22 @@ def fused_elbo_ref(table, item, response, mask, eps, *, irt_model, ability_dim,
         m_tab, s_tab = table[:, :A], table[:, A:]            # [2,A]
         m = m_tab[x.long()]                                  # [B,I,A]
         s = s_tab[x.long()]
-    tau_obs = 1.0 / (torch.exp(s) + 1e-8)
-    k3 = k.unsqueeze(2)
-    if replace_missing_with_prior:
-        tau_prior = 1.0 / (1.0 + 1e-8)
-        tau = k3 * tau_obs + (1.0 - k3) * tau_prior
-        m_eff = k3 * m
+    if given_posterior:
+        amu, alv = table[:, :A], table[:, A:]
+        lam = torch.exp(-alv)
     else:
-        tau = k3 * tau_obs
-        m_eff = m
-    lam = tau.sum(1)                                         # [B,A]
-    amu = (m_eff * tau).sum(1) / lam
-    alv = torch.log(1.0 / lam)
+        tau_obs = 1.0 / (torch.exp(s) + 1e-8)
+        k3 = k.unsqueeze(2)
+        if replace_missing_with_prior:
+            tau_prior = 1.0 / (1.0 + 1e-8)
+            tau = k3 * tau_obs + (1.0 - k3) * tau_prior
+            m_eff = k3 * m
+        else:
+            tau = k3 * tau_obs
+            m_eff = m
+        lam = tau.sum(1)                                         # [B,A]
+        amu = (m_eff * tau).sum(1) / lam
+        alv = torch.log(1.0 / lam)
     sig = torch.exp(0.5 * alv)
     theta0 = eps * sig + amu
 
@@ -195,6 +203,9 @@ def fused_elbo_ref(table, item, response, mask, eps, *, irt_model, ability_dim,
     else:
         g_lv[1] = g_lv[1] - 0.5
 
+    if given_posterior:
+        out.update(g_table=[torch.cat([g_mu[i], g_lv[i]], dim=1) for i in range(2)], g_item=g_item, g_flow=g_flow)
+        return out
     g_table = []
     for s_idx in range(2):
         gm_p = (g_mu[s_idx] / lam).unsqueeze(1)                       # [B,1,A]

@@ -1,0 +1,183 @@
+"""--ability-merge mean (models.py:584-594, 631-650) on the GPU: the row counts (vibo_row_counts), the fused
+kernel with a caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN) against the analytic CPU oracle, and the
+drop-in module end to end.  (The reference goldens of this encoder run through tests/test_gpu_parity.py's golden tests.)"""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vibo_oracle as O
+from oracle import vibo_table_ref as T
+from vibo_amd import _lib, ops
+from vibo_amd.ops import ElboSpec
+from vibo_amd.torch_core.models import VIBO_2PL, VIBO_3PL
+
+pytestmark = pytest.mark.gpu
+dev = torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('I', [1, 3, 95, 100, 1028, 6000])
+@pytest.mark.parametrize('layout', ['bool', 'int64', 'none', 'padded', 'codes', 'gather'])
+def test_row_counts(I, layout):
+    g = torch.Generator().manual_seed(I)
+    resp, mask = O.simulate_responses(2, 41, I, 1, generator=g, missing_frac=0.3)
+    resp, mask = resp.to(dev), mask.bool().to(dev)
+    rows = None
+    if layout == 'none':
+        resp = resp.clamp(min=0)
+        args = (resp, None)
+        mask = torch.ones_like(mask)
+    elif layout == 'int64':
+        args = (resp, mask.long())
+    elif layout == 'padded':
+        args = ops.pad_rows(resp, mask)
+    elif layout == 'codes':
+        args = (ops.pack_cell_codes(resp, mask), None)
+    elif layout == 'gather':
+        rows = torch.randperm(41, generator=g)[:17].to(dev)
+        args = ops.pad_rows(resp, mask)
+    else:
+        args = (resp, mask)
+    n1, nobs = ops.row_counts(*args, row_index=rows)
+    sel = rows if rows is not None else slice(None)
+    assert torch.equal(nobs, mask[sel].sum(1).float())
+    assert torch.equal(n1, ((resp[sel] == 1) & mask[sel]).sum(1).float())
+
+
+CASES = [
+    # irt, A, B, I, flows, missing, codes, gather
+    (2, 1, 64, 100, 0, 0.2, False, False),
+    (2, 8, 130, 1000, 0, 0.1, False, True),
+    (2, 3, 77, 95, 0, 0.3, False, False),        # ragged rows, padded strides
+    (3, 2, 50, 304, 0, 0.2, True, False),
+    (1, 5, 33, 8, 0, 0.0, False, False),
+    (2, 2, 90, 1000, 4, 0.2, False, False),      # flows: REG = log q - log p at the sample
+    (3, 8, 20, 2500, 2, 0.1, True, True),        # panels + flows + cell codes + gather
+    (2, 4, 9, 10000, 0, 0.5, False, False),
+]
+
+
+@pytest.mark.parametrize('irt,A,B,I,n_flows,missing,codes,gather', CASES)
+@pytest.mark.parametrize('want_grad', [True, False])
+def test_given_posterior_kernel_vs_oracle(irt, A, B, I, n_flows, missing, codes, gather, want_grad):
+    g = torch.Generator().manual_seed(B * 7 + I + A)
+    P = B + 9 if gather else B
+    resp_all, mask_all = O.simulate_responses(irt, P, I, A, generator=g, missing_frac=missing)
+    rows = torch.randperm(P, generator=g)[:B] if gather else None
+    resp, mask = (resp_all[rows], mask_all[rows]) if gather else (resp_all, mask_all)
+    spec = ElboSpec(irt_model=irt, ability_dim=A, n_flows=n_flows, given=True)
+    post = torch.cat([torch.randn(B, A, generator=g) * 0.8, torch.randn(B, A, generator=g) * 0.5 - 1.0], dim=1)
+    item = torch.randn(I, spec.item_dim, generator=g) * 0.6
+    eps = torch.randn(B, A, generator=g)
+    flow = flows = None
+    if n_flows:
+        raw_f = torch.randn(n_flows, 2 * A + 1, generator=g) * 0.7
+        wv = raw_f[:, A:2 * A]
+        raw_f[:, A:2 * A] = torch.sign(wv) * (0.4 + wv.abs()) / (A ** 0.5)
+        flow = torch.stack([torch.cat([T.flow_uhat(f[:A], f[A:2 * A]), f[A:]]) for f in raw_f])
+        flows = [(f[:A].double(), f[A:2 * A].double(), f[2 * A:].double()) for f in flow]
+    mode = 'sampled' if n_flows else 'kl'
+    ref = T.fused_elbo_ref(post.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt, ability_dim=A,
+                           mode=mode, flow_uhat_w_b=flows, given_posterior=True, want_grad=want_grad)
+    r_, m_ = ops.pad_rows(resp_all.to(dev), mask_all.bool().to(dev))
+    if codes:
+        r_, m_ = ops.pack_cell_codes(r_, m_), None
+    r, m, code = ops.prepare_rows(r_, m_)
+    raw = ops._hip_launch_elbo(spec, r, m, code, rows.to(dev) if gather else None, post.to(dev), item.to(dev), eps.to(dev),
+                               flow.to(dev) if flow is not None else None, _lib.REG_SAMPLED if n_flows else _lib.REG_KL,
+                               want_grad, B)
+    sc = raw.scalars.cpu()
+    assert rel_err(sc[_lib.S_LL], ref['ll']) < 3e-5
+    assert abs(float(sc[_lib.S_REG]) - float(ref['reg'])) < 3e-5 * max(1.0, abs(float(ref['reg'])))
+    assert (raw.ability_mu.cpu() - post[:, :A]).abs().max() < 2e-6 * max(1.0, float(post[:, :A].abs().max()))
+    assert (raw.ability_logvar.cpu() - post[:, A:]).abs().max() < 2e-6 * max(1.0, float(post[:, A:].abs().max()))
+    assert (raw.ability.cpu() - ref['ability'].float()).abs().max() < 3e-5 * max(1.0, float(ref['ability'].abs().max()))
+    if want_grad:
+        for s in range(2):
+            assert raw.grad_table(s).shape == (B, 2 * A)
+            if float(ref['g_table'][s].abs().max()) > 0:
+                assert rel_err(raw.grad_table(s).cpu(), ref['g_table'][s]) < 3e-4, s
+        assert rel_err(raw.grad_item((I, spec.item_dim)).cpu(), ref['g_item']) < 3e-4
+        if n_flows:
+            for s in range(2):
+                gref = torch.cat([torch.cat(gf) for gf in ref['g_flow'][s]]).float()
+                if float(gref.abs().max()) > 0:
+                    assert rel_err(raw.grad_flow(s).cpu(), gref) < 6e-4, s
+
+
+def test_given_posterior_needs_the_row_split_path():
+    spec = ElboSpec(irt_model=2, ability_dim=1, given=True)
+    resp, mask = O.simulate_responses(2, 8, 3, 1, generator=torch.Generator().manual_seed(0))
+    r, m, code = ops.prepare_rows(resp.to(dev), mask.bool().to(dev))
+    with pytest.raises(RuntimeError, match='GIVEN'):
+        ops._hip_launch_elbo(spec, r, m, code, None, torch.zeros(8, 2, device=dev), torch.zeros(3, 2, device=dev),
+                             torch.zeros(8, 1, device=dev), None, _lib.REG_KL, True, 8)
+
+
+@pytest.mark.parametrize('cls,A,I,kw', [(VIBO_2PL, 2, 100, {}), (VIBO_3PL, 1, 95, {}), (VIBO_2PL, 3, 95, {'n_norm_flows': 2}),
+                                        (VIBO_2PL, 8, 1500, {})])
+def test_mean_merge_module_vs_autograd_oracle(cls, A, I, kw):
+    """forward -> elbo -> backward, encode and log_marginal of a mean-merge model against autograd through the op-by-op
+    oracle (per-term mlp1, masked mean, mlp2) under the same noise; cell codes give the same numbers."""
+    g = torch.Generator().manual_seed(3)
+    B = 48
+    resp, mask = O.simulate_responses(cls.IRT, B, I, A, generator=g, missing_frac=0.2)
+    torch.manual_seed(2)
+    model = cls(A, I, ability_merge='mean', **kw).to(dev)
+    assert {k for k in model.state_dict() if k.startswith('ability_encoder')} == {
+        f'ability_encoder.{m}.{i}.{p}' for m in ('mlp1', 'mlp2') for i in (0, 2) for p in ('weight', 'bias')}
+    eps_item = torch.randn(I, model.item_feat_dim, generator=g)
+    eps_ab = torch.randn(B, A, generator=g)
+    # a freshly initialised mean-merge encoder gives wide posteriors and logits inside the Bernoulli clamp band (where the
+    # reference's fp32 evaluation is its own definition; the goldens cover that): narrow the posteriors for the fp64 check
+    with torch.no_grad():
+        model.ability_encoder.mlp2[2].weight.mul_(0.3)
+        model.ability_encoder.mlp2[2].bias[A:] = -2.0
+        model.item_encoder.mu_lookup.weight.mul_(0.5)
+        for name, prm in model.named_parameters():
+            if 'norm_flows' in name and name.endswith('.u'):
+                prm.mul_(0.3)
+    sd = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    flows = kw.get('n_norm_flows', 0)
+    ref, gref = O.elbo_loss_and_grads(sd, resp.double(), mask, eps_item.double(), eps_ab.double(), irt_model=cls.IRT,
+                                      ability_dim=A, n_norm_flows=flows, annealing_factor=0.7,
+                                      use_kl_divergence=flows == 0)
+    r, m = resp.to(dev), mask.bool().to(dev)
+    for rows in ((r, m), (ops.pack_cell_codes(r, m), None)):
+        model.zero_grad()
+        outs = model(rows[0], rows[1], eps_item=eps_item.to(dev), eps_ability=eps_ab.to(dev))
+        if flows:
+            (rr, kk, rmu, ak, a0, amu, alv, aladj, ik, i0, imu, ilv, iladj) = outs
+            loss = model.elbo(rr, kk, rmu, a0, amu, alv, i0, imu, ilv, use_kl_divergence=False, ability_k=ak, item_feat_k=ik,
+                              ability_logabsdetjac=aladj, item_logabsdetjac=iladj)
+        else:
+            (rr, kk, rmu, a0, amu, alv, i0, imu, ilv) = outs
+            loss = model.elbo(*outs, annealing_factor=0.7)
+        loss.backward()
+        assert rel_err(loss.detach().cpu(), ref['loss']) < 2e-5
+        assert (amu.cpu() - ref['ability_mu'].float()).abs().max() < 2e-5
+        assert (alv.cpu() - ref['ability_logvar'].float()).abs().max() < 2e-5
+        for k, p in model.named_parameters():
+            assert rel_err(p.grad.cpu(), gref[k]) < 1e-3, k
+        _, emu, elv, _, _, _ = model.encode(rows[0], rows[1])
+        assert torch.allclose(emu, amu.detach(), atol=1e-6) and torch.allclose(elv, alv.detach(), atol=1e-6)
+    torch.manual_seed(9)
+    lm = model.log_marginal(r, m, num_samples=3)
+    assert torch.isfinite(lm).all()
+
+
+def test_cli_mean_merge_trains(tmp_path, monkeypatch):
+    import os
+    import numpy as np
+    from vibo_amd import config
+    from vibo_amd.torch_core import vibo as cli
+    monkeypatch.setattr(config, 'DATA_DIR', str(tmp_path / 'data'))
+    monkeypatch.setattr(config, 'OUT_DIR', str(tmp_path / 'out'))
+    cli.main(['--irt-model', '2pl', '--dataset', '2pl_simulation', '--num-person', '600', '--num-item', '30', '--ability-merge', 'mean',
+              '--artificial-missing-perc', '0.2', '--epochs', '4', '--batch-size', '16', '--num-posterior-samples', '3', '--cuda',
+              '--out-dir', str(tmp_path / 'out')])
+    (run_dir,) = os.listdir(tmp_path / 'out')
+    assert '_mean_' in run_dir
+    losses = np.load(tmp_path / 'out' / run_dir / 'train_losses.npy')
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    ck = torch.load(tmp_path / 'out' / run_dir / 'checkpoint.pth.tar', weights_only=False)
+    assert 'ability_encoder.mlp2.2.weight' in ck['model_state_dict'] and 0.0 <= ck['missing_imputation_accuracy'] <= 1.0

@@ -28,7 +28,7 @@ def cpu_ops():
 def build_model(golden):
     m = golden.meta
     model = CLS[m['irt_model']](m['ability_dim'], m['num_item'], hidden_dim=m['hidden_dim'],
-                                ability_merge='product', conditional_posterior=m['conditional_posterior'],
+                                ability_merge=m.get('ability_merge', 'product'), conditional_posterior=m['conditional_posterior'],
                                 replace_missing_with_prior=m['replace_missing_with_prior'],
                                 n_norm_flows=m['n_norm_flows'])
     model.load_state_dict(golden.sd, strict=True)      # same keys and shapes as the reference
@@ -77,7 +77,9 @@ def check_against_golden(model, golden, outs, loss, tol_loss=1e-4, tol_grad=3e-4
         if scale == 0.0:
             assert float(g.abs().max()) < 1e-6, name
         else:
-            assert rel_err(g, truth[name]) < tol_truth, name   # fp32 CPU stand-in is as noisy as the reference
+            # the fp32 CPU stand-in is as noisy as the reference (whose own fp32 gradients sit up to 1.6e-2 from fp64 on
+            # the mean-merge encoder's first layer): allow the reference's own distance from the fp64 oracle on top
+            assert rel_err(g, truth[name]) < tol_truth + rel_err(g_ref, truth[name]), name
             assert rel_err(g, g_ref) < tol_grad + rel_err(g_ref, truth[name]), name
 
 
@@ -154,25 +156,35 @@ def test_table_ref_matches_autograd_oracle(golden):
                   sd[f'ability_norm_flows.flows.{k}.w'], sd[f'ability_norm_flows.flows.{k}.b'])
                  for k in range(cfg['n_norm_flows'])]
         item_k, _ = O.planar_flows(sd, 'item_norm_flows', item_feat, cfg['n_norm_flows'])
-    table = T.encoder_table(sd, item_feat, cfg['conditional_posterior']).detach().requires_grad_(True)
+    mean = golden.meta.get('ability_merge', 'product') == 'mean'
+    if mean:      # the kernel takes the per-person posterior as given (VIBO_POSTERIOR_GIVEN): table = [B, 2A]
+        table = torch.cat(O.ability_posterior(sd, golden.response.double(), golden.mask, item_feat, ability_dim=A,
+                                              conditional_posterior=False, replace_missing_with_prior=True), dim=1)
+        table = table.detach().requires_grad_(True)
+    else:
+        table = T.encoder_table(sd, item_feat, cfg['conditional_posterior']).detach().requires_grad_(True)
     item_leaf = item_k.detach().requires_grad_(True)
     out = T.fused_elbo_ref(table.detach(), item_leaf.detach(), golden.response.double(), golden.mask,
                            golden.eps_ability.double(), irt_model=cfg['irt_model'], ability_dim=A,
                            conditional_posterior=cfg['conditional_posterior'],
                            replace_missing_with_prior=cfg['replace_missing_with_prior'], mode=mode,
-                           flow_uhat_w_b=flows, exact_saturation=False)
+                           flow_uhat_w_b=flows, exact_saturation=False, given_posterior=mean)
 
     # autograd version of the same heads from the op-by-op oracle pieces
     B, I = golden.response.shape
     resp, mask = golden.response.double(), golden.mask
     x = (resp == 1).long()
     k = (mask != 0).double().unsqueeze(2)
-    if cfg['conditional_posterior']:
+    if mean:
+        m = s = None
+    elif cfg['conditional_posterior']:
         idx = torch.arange(I).unsqueeze(0).expand(B, I)
         m, s = table[x, idx, :A], table[x, idx, A:]
     else:
         m, s = table[x][..., :A], table[x][..., A:]
-    if cfg['replace_missing_with_prior']:
+    if mean:
+        amu, alv = table[:, :A], table[:, A:]
+    elif cfg['replace_missing_with_prior']:
         amu, alv = O.product_of_experts((m * k).permute(1, 0, 2), (s * k).permute(1, 0, 2))
     else:
         amu, alv = O.product_of_experts(m.permute(1, 0, 2), s.permute(1, 0, 2), weight=k.permute(1, 0, 2))
@@ -189,6 +201,10 @@ def test_table_ref_matches_autograd_oracle(golden):
         reg = O.kl_std_normal(amu, alv).sum()
     else:
         reg = O.normal_logpdf(theta0, amu, alv).sum() - ladj.sum() - O.std_normal_logpdf(theta).sum()
+    if mean and cfg['irt_model'] == 3 and float(out['logit'].abs().max()) > 12.0:
+        # 3PL clamps p itself at fp32 eps (utils.py:46-49 through torch's Bernoulli): inside that band the fp64 autograd
+        # oracle (clamp at fp64 eps) is not the same function; the saturation golden covers the band
+        pytest.skip('saturated 3PL logits: analytic-vs-autograd identity does not apply')
     assert rel_err(out['ll'], ll.detach()) < 1e-9
     assert rel_err(out['reg'], reg.detach()) < 1e-9
     g_t0, g_i0 = torch.autograd.grad(ll, [table, item_leaf], retain_graph=True)

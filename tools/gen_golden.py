@@ -88,16 +88,23 @@ CASES = [
     ('3pl_a1_cond_flows4',       3, 1, 16, 130, True, 0.0, False, 4, 1.0, False),
     ('3pl_a1_cond_flows4_miss',  3, 1, 37, 95, True, 0.2, False, 4, 1.0, False),
     ('2pl_a8_cond_miss_prior',   2, 8, 16, 20, True, 0.2, False, 0, 1.0, True),
+    # --ability-merge mean (models.py:584-594, 631-650): 12th field
+    ('2pl_a1_uncond_mean',           2, 1, 16, 20, False, 0.0, False, 0, 1.0, True, 'mean'),
+    ('2pl_a2_uncond_mean_miss',      2, 2, 37, 95, False, 0.2, False, 0, 0.5, True, 'mean'),
+    ('3pl_a8_uncond_mean_miss',      3, 8, 16, 130, False, 0.2, False, 0, 1.0, True, 'mean'),
+    ('1pl_a3_uncond_mean_flows2',    1, 3, 16, 20, False, 0.0, False, 2, 1.0, False, 'mean'),
+    ('2pl_a1_uncond_mean_miss_nokl', 2, 1, 37, 95, False, 0.2, False, 0, 1.0, False, 'mean'),
 ]
 
 
 def run_case(ref_models, case, out_dir):
-    name, irt, A, B, I, cond, missing, drop, flows, beta, use_kl = case
+    name, irt, A, B, I, cond, missing, drop, flows, beta, use_kl = case[:11]
+    merge = case[11] if len(case) > 11 else 'product'
     seed = 1000 + sum(ord(c) for c in name)
     resp, mask = make_data(irt, B, I, A, missing, seed)
     cls = {1: ref_models.VIBO_1PL, 2: ref_models.VIBO_2PL, 3: ref_models.VIBO_3PL}[irt]
     torch.manual_seed(seed)
-    model = cls(A, I, hidden_dim=64, ability_merge='product', conditional_posterior=cond,
+    model = cls(A, I, hidden_dim=64, ability_merge=merge, conditional_posterior=cond,
                 generative_model='irt', response_dist='bernoulli',
                 replace_missing_with_prior=not drop, n_norm_flows=flows)
     D = model.item_feat_dim
@@ -135,7 +142,7 @@ def run_case(ref_models, case, out_dir):
         'meta': json.dumps(dict(name=name, irt_model=irt, ability_dim=A, num_person=B, num_item=I,
                                 conditional_posterior=cond, missing_frac=missing,
                                 replace_missing_with_prior=not drop, n_norm_flows=flows,
-                                annealing_factor=beta, use_kl_divergence=use_kl,
+                                annealing_factor=beta, use_kl_divergence=use_kl, ability_merge=merge,
                                 hidden_dim=64, torch=torch.__version__)),
         'response': resp.numpy().astype(np.int8),
         'mask': mask.numpy().astype(np.uint8),
@@ -253,16 +260,20 @@ def artificial_mask_case(out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    ap.add_argument('--only', default='', help='only (re)generate the ELBO cases whose name contains this substring')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
     ref_models, ref_utils = import_reference()
     for case in CASES:
+        if args.only and args.only not in case[0]:
+            continue
         loss = run_case(ref_models, case, out_dir)
         print(f'{case[0]:34s} loss={loss:.6f}')
-    saturation_case(ref_utils, out_dir)
-    log_marginal_case(ref_models, out_dir)
-    artificial_mask_case(out_dir)
+    if not args.only:
+        saturation_case(ref_utils, out_dir)
+        log_marginal_case(ref_models, out_dir)
+        artificial_mask_case(out_dir)
     print('wrote', out_dir)
 
 

@@ -42,7 +42,8 @@ static int check_desc(const vibo_desc* d) {
     if (d->ability_dim < 1 || d->ability_dim > VIBO_MAX_ABILITY_DIM)
         return fail(-3, "ability_dim %d outside 1..%d", d->ability_dim, VIBO_MAX_ABILITY_DIM);
     if (d->irt_model < 1 || d->irt_model > 3) return fail(-3, "irt_model must be 1, 2 or 3");
-    if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL && d->posterior != VIBO_POSTERIOR_CONDITIONAL)
+    if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL && d->posterior != VIBO_POSTERIOR_CONDITIONAL &&
+        d->posterior != VIBO_POSTERIOR_GIVEN)
         return fail(-3, "bad posterior");
     if (d->missing_mode != VIBO_MISSING_PRIOR && d->missing_mode != VIBO_MISSING_DROP) return fail(-3, "bad missing_mode");
     if (d->mask_dtype < 0 || d->mask_dtype > VIBO_MASK_CODES) return fail(-3, "bad mask_dtype");
@@ -61,6 +62,7 @@ struct Plan {
     int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
     size_t off_cnt;           // panel mode: per-person packed counts of the whole row
     bool cond;                // panel mode with the conditional posterior: cond_pre / split / cond_post per panel
+    bool given;               // panel mode with a caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN)
     size_t off_pre, off_coef, off_cpart;
     int cond_rec;             // floats per cond_post workgroup record
     int AT, D, DP, n_tiles, nblk, lds_main;
@@ -130,8 +132,13 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     pl->split_ok = false;
     pl->panels = 0;
     pl->cond = false;
+    pl->given = false;
     const bool is_cond = d->posterior == VIBO_POSTERIOR_CONDITIONAL;
-    if (I >= 4 && I <= 32767 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64 && ((is_cond && A <= 4) || (!is_cond && I > 1024))) {
+    const bool is_given = d->posterior == VIBO_POSTERIOR_GIVEN;
+    if (is_given && !(I >= 4 && I <= 32767 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64))
+        return fail(-8, "VIBO_POSTERIOR_GIVEN needs the row-split path: 4..32767 items, rows chunkable in 4 cells, no int64 mask");
+    if (I >= 4 && I <= 32767 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64 &&
+        ((is_cond && A <= 4) || is_given || (!is_cond && I > 1024))) {
         // panel mode (item counts up to 32767: the whole-row counts are packed as n_correct << 16 | n_observed in an
         // int): one row-split launch per 1024 items (the backward is linear in d LL/d theta, so the panels
         // backpropagate their partial sums independently).  Unconditional posterior: a row-count pass supplies the
@@ -145,6 +152,7 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
         }
         pl->panels = (I + 1023) / 1024;
         pl->cond = is_cond;
+        pl->given = is_given;
         const int at_min = 2;
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
@@ -170,6 +178,11 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
             off += up((size_t)pl->panels * d->num_person * 4 * A * 4);
             pl->off_cpart = off;
             off += up((size_t)pl->panels * pl->split_nblk * pl->cond_rec * 4);
+        } else if (is_given) {
+            pl->off_pre = off;
+            off += up((size_t)d->num_person * (2 * A + 1) * 4);
+            pl->off_coef = off;
+            off += up((size_t)pl->panels * d->num_person * 4 * A * 4);
         }
         pl->total_bytes = off + 256;
         pl->general = false;
@@ -318,6 +331,70 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
         const int tot = lane63(wave_sum63(packed));
         if (lane == 0) cnt[row] = tot;
     }
+}
+
+// ---------------------------------------------------------------------------
+// VIBO_POSTERIOR_GIVEN: the caller's per-person (mu | logvar) enters the row-split kernel through the hooks of the
+// conditional pipeline: precision lam = exp(-logvar), s = mu lam, nobs = I (no prior experts are added); the kernel's
+// per-person coefficients P1 = g_mu / lam, P2 = -(g_mu mu + g_lv) / lam come back as d / d (mu, logvar)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void given_pre_kernel(const float* __restrict__ post, float* __restrict__ pre, long long B, int A,
+                                                        int I) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * (A + 1)) return;
+    const long long row = e / (A + 1);
+    const int a = (int)(e % (A + 1));
+    float* st = pre + row * (2 * A + 1);
+    if (a == A) { st[2 * A] = (float)I; return; }
+    const float mu = post[row * 2 * A + a], lam = expf(-post[row * 2 * A + A + a]);
+    st[a] = lam;
+    st[A + a] = mu * lam;
+}
+__global__ __launch_bounds__(256) void given_post_kernel(const float* __restrict__ post, const float* __restrict__ coef, int panels,
+                                                         float* __restrict__ grad, long long B, int A) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * A) return;
+    const long long row = e / A;
+    const int a = (int)(e % A);
+    const float mu = post[row * 2 * A + a], lam = expf(-post[row * 2 * A + A + a]);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float p1 = 0.f, p2 = 0.f;
+        for (int pn = 0; pn < panels; ++pn) {
+            const float* pc = coef + ((size_t)pn * B + row) * 4 * A;
+            p1 += pc[(st * 2 + 0) * A + a];
+            p2 += pc[(st * 2 + 1) * A + a];
+        }
+        const float gmu = p1 * lam;
+        grad[((size_t)st * B + row) * 2 * A + a] = gmu;
+        grad[((size_t)st * B + row) * 2 * A + A + a] = -p2 * lam - gmu * mu;
+    }
+}
+
+// whole-row counts for rows the vector kernel cannot read (unaligned / not chunkable / int64 mask): wave per row
+__global__ __launch_bounds__(256) void row_count_scalar_kernel(const float* __restrict__ response, const void* __restrict__ mask,
+                                                               const int64_t* __restrict__ row_index, int* __restrict__ cnt,
+                                                               long long resp_stride, long long mask_stride, int B, int I,
+                                                               int mask_dtype) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const long long src = row_index ? row_index[row] : row;
+    int packed = 0;
+    for (int i = lane; i < I; i += 64) {
+        bool k = true, one;
+        if (mask_dtype == VIBO_MASK_CODES) {
+            const uint8_t c = static_cast<const uint8_t*>(mask)[src * mask_stride + i];
+            k = c != 2; one = c == 1;
+        } else {
+            if (mask_dtype == VIBO_MASK_U8) k = static_cast<const uint8_t*>(mask)[src * mask_stride + i] != 0;
+            else if (mask_dtype == VIBO_MASK_I64) k = static_cast<const int64_t*>(mask)[src * mask_stride + i] != 0;
+            one = response[src * resp_stride + i] == 1.0f;
+        }
+        if (k) packed += 1 + (one ? (1 << 16) : 0);
+    }
+    const int tot = lane63(wave_sum63(packed));
+    if (lane == 0) cnt[row] = tot;
 }
 
 // ---------------------------------------------------------------------------
@@ -654,6 +731,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     const bool vec = rows_vec_ok(d, response, mask);
     const bool codes = d->mask_dtype == VIBO_MASK_CODES;
     if (codes && !(vec && !pl.general && (pl.panels > 0 || pl.split_ok))) return codes_unsupported();
+    if (pl.given && !vec) return fail(-8, "VIBO_POSTERIOR_GIVEN: rows must be aligned for 4-cell chunks (see vibo_amd.ops.pad_rows)");
 
     if (pl.general || (d->n_flows > 0 && !(pl.split_ok && vec) && pl.panels == 0) || (pl.panels > 0 && !vec)) {
         const size_t n_table = (size_t)(d->posterior == VIBO_POSTERIOR_CONDITIONAL ? 2 * I * 2 * A : 2 * 2 * A);
@@ -719,7 +797,15 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;
         cp.coef_panels = pl.panels; cp.rec_stride = pl.cond_rec; cp.coef_in = coef;
         e = hipSuccess;
-        if (pl.cond) {
+        if (pl.given) {
+            const long long n = (long long)d->num_person * (A + 1);
+            hipLaunchKernelGGL(given_pre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, pre,
+                               (long long)d->num_person, A, I);
+            e = hipGetLastError();
+            p.pre_stats = pre;
+            p.pre_panels = 1;
+            p.table = item_prep;          // the 2-row expert table is not used in this mode: any finite floats
+        } else if (pl.cond) {
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
@@ -742,7 +828,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             p.I = I - p.item0 < 1024 ? I - p.item0 : 1024;
             p.primary = pn == 0 ? 1 : 0;
             p.partial = partial + (size_t)pn * pl.split_nblk * pl.lay.stride;
-            p.post_coef = (pl.cond && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
+            p.post_coef = ((pl.cond || pl.given) && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
             const int nq = (p.I + 255) / 256;
             e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s);
         }
@@ -754,6 +840,12 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 e = launch_cond_post(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.split_nblk, s);
             }
             if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.split_nblk, pl.cond_rec, s);
+        }
+        if (pl.given && grad && e == hipSuccess) {
+            const long long n = (long long)d->num_person * A;
+            hipLaunchKernelGGL(given_post_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, coef, pl.panels,
+                               grad_table, (long long)d->num_person, A);
+            e = hipGetLastError();
         }
         nblk_used = pl.panels * pl.split_nblk;
         panel_items = 1024;
@@ -775,7 +867,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
 
     FinalizeParams f;
     memset(&f, 0, sizeof(f));
-    f.partial = partial; f.out_scalars = out_scalars; f.grad_table = (pl.panels > 0 && pl.cond) ? nullptr : grad_table; f.grad_item = grad_item;
+    f.partial = partial; f.out_scalars = out_scalars; f.grad_table = (pl.panels > 0 && (pl.cond || pl.given)) ? nullptr : grad_table; f.grad_item = grad_item;
     f.grad_flow = grad_flow;
     f.nblk = nblk_used; f.I = I; f.A = A; f.D = pl.D; f.n_flows = d->n_flows; f.reg_mode = d->reg_mode;
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
@@ -796,6 +888,7 @@ static int multi_plan(const vibo_desc* d, vibo_desc* d0, Plan* pl, size_t* prep_
     if (stride < 0) return stride;
     // conditional posterior: the expert table itself depends on the item sample, nothing is shared between samples
     if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) return fail(-8, "multi-sample forward: conditional posterior (one table per sample)");
+    if (d->posterior == VIBO_POSTERIOR_GIVEN) return fail(-8, "multi-sample forward: caller-supplied posterior");
     if (pl->general || !(pl->split_ok || pl->panels > 0)) return fail(-8, "multi-sample forward: shape is not on the row-split path");
     *prep_bytes = ((size_t)((d->num_item + 15) & ~15) * pl->DP * 4 + 255) & ~(size_t)255;
     return 0;
@@ -910,6 +1003,7 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
                 size_t workspace_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
+    if (d->posterior == VIBO_POSTERIOR_GIVEN) return fail(-3, "vibo_encode: the posterior is the caller's own with VIBO_POSTERIOR_GIVEN");
     if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !table || !ability_mu || !ability_logvar) return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
     {
@@ -973,6 +1067,33 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
     hipLaunchKernelGGL(encode_kernel, dim3((d->num_person + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "encode launch");
+    return 0;
+}
+
+int vibo_row_counts(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index, int32_t* counts,
+                    void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !counts) return fail(-5, "null required pointer");
+    if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
+    if (d->num_item > 32767) return fail(-3, "vibo_row_counts: the packed counts hold up to 32767 items");
+    hipStream_t s = (hipStream_t)stream;
+    if (g_num_cu == 0) {
+        int dev = 0, n = 0;
+        g_num_cu = (hipGetDevice(&dev) == hipSuccess &&
+                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    if (d->num_item >= 4 && d->mask_dtype != VIBO_MASK_I64 && rows_vec_ok(d, response, mask)) {
+        int cgrid = g_num_cu * 8;
+        if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
+        hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, counts,
+                           (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, d->num_item, d->mask_dtype);
+    } else {
+        hipLaunchKernelGGL(row_count_scalar_kernel, dim3((d->num_person + 3) / 4), dim3(256), 0, s, response, mask, row_index, counts,
+                           (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, d->num_item, d->mask_dtype);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "row_counts launch");
     return 0;
 }
 

@@ -11,7 +11,7 @@ NUM_SCALARS = 8
 S_LL, S_REG, S_KL, S_LOGQ0, S_LOGP, S_LADJ, S_NOBS = 0, 1, 2, 3, 4, 5, 6
 
 IRT_1PL, IRT_2PL, IRT_3PL = 1, 2, 3
-POSTERIOR_UNCONDITIONAL, POSTERIOR_CONDITIONAL = 0, 1
+POSTERIOR_UNCONDITIONAL, POSTERIOR_CONDITIONAL, POSTERIOR_GIVEN = 0, 1, 2
 MISSING_PRIOR, MISSING_DROP = 0, 1
 MASK_U8, MASK_I64, MASK_NONE, MASK_CODES = 0, 1, 2, 3
 REG_KL, REG_SAMPLED = 0, 1
@@ -45,7 +45,7 @@ class ViboDesc(ctypes.Structure):
 
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
-                    'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes')
+                    'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts')
 
 _lib = None
 
@@ -92,6 +92,8 @@ def load():
     lib.vibo_multi_workspace_bytes.argtypes = [dp, ctypes.c_int]
     lib.vibo_elbo_multi_forward.restype = ctypes.c_int
     lib.vibo_elbo_multi_forward.argtypes = [dp, ctypes.c_int, fp, vp, i64p, fp, fp, fp, fp, fp, vp, ctypes.c_size_t, vp]
+    lib.vibo_row_counts.restype = ctypes.c_int
+    lib.vibo_row_counts.argtypes = [dp, fp, vp, i64p, vp, vp]
     lib.vibo_pack_codes.restype = ctypes.c_int
     lib.vibo_pack_codes.argtypes = [dp, fp, vp, vp, ctypes.c_int64, vp]
     lib.vibo_decode_mean.restype = ctypes.c_int

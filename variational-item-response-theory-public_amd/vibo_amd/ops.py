@@ -31,13 +31,16 @@ class ElboSpec:
     conditional: bool = False
     drop_missing: bool = False       # --drop-missing (vibo.py:52,217)
     n_flows: int = 0
+    given: bool = False              # the caller supplies q(theta_p) per person (--ability-merge mean): VIBO_POSTERIOR_GIVEN
 
     @property
     def item_dim(self):
         return item_feat_dim(self.irt_model, self.ability_dim)
 
-    def table_shape(self, num_item):
+    def table_shape(self, num_item, num_person=None):
         A = self.ability_dim
+        if self.given:
+            return (num_person, 2 * A)
         return (2, num_item, 2 * A) if self.conditional else (2, 2 * A)
 
     def check_supported(self, num_item):
@@ -215,7 +218,8 @@ def _make_desc(spec, B, I, mask_code, reg_mode, want_grad, resp_stride, mask_str
     d.num_item = I
     d.ability_dim = spec.ability_dim
     d.irt_model = spec.irt_model
-    d.posterior = _lib.POSTERIOR_CONDITIONAL if spec.conditional else _lib.POSTERIOR_UNCONDITIONAL
+    d.posterior = (_lib.POSTERIOR_GIVEN if spec.given else
+                   _lib.POSTERIOR_CONDITIONAL if spec.conditional else _lib.POSTERIOR_UNCONDITIONAL)
     d.missing_mode = _lib.MISSING_DROP if spec.drop_missing else _lib.MISSING_PRIOR
     d.mask_dtype = mask_code
     d.reg_mode = reg_mode
@@ -327,6 +331,29 @@ def _hip_decode(spec, ability, item):
     return out
 
 
+def _hip_row_counts(response, mask, mask_code, row_index):
+    """vibo_row_counts: int32 [B], n_correct << 16 | n_observed per person row."""
+    lib = _lib.load()
+    _require_device(response, mask)
+    B = int(row_index.numel()) if row_index is not None else response.shape[0]
+    I = response.shape[1]
+    out = torch.empty(B, dtype=torch.int32, device=response.device)
+    d = _make_desc(ElboSpec(irt_model=1, ability_dim=1), B, I, mask_code, _lib.REG_KL, False, response.stride(0),
+                   mask.stride(0) if mask is not None else 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(response.device).cuda_stream)
+    rc = lib.vibo_row_counts(ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(out), stream)
+    _lib.check(rc, 'vibo_row_counts')
+    return out
+
+
+def row_counts(response, mask, row_index=None):
+    """(n_correct, n_observed) per person as float tensors [B] -- the sufficient statistics of a Bernoulli response row
+    for the unconditional encoders (here: the masked mean of --ability-merge mean, models.py:631-650)."""
+    response, mask, code = prepare_rows(response, mask, keep_int64=True)
+    c = _BACKEND['counts'](response, mask, code, row_index)
+    return (c >> 16).float(), (c & 0xffff).float()
+
+
 def _hip_decode_mean(spec, abilities, items):
     """vibo_decode_mean: abilities [S,B,A], items [S,I,D] -> mean over S of P(response = 1) [B,I]."""
     lib = _lib.load()
@@ -343,7 +370,7 @@ def _hip_decode_mean(spec, abilities, items):
 # The three entry points of the native library.  tests/ swap these for the CPU
 # oracle to exercise the host logic without a GPU (never done by product code).
 _BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward,
-            'decode_mean': _hip_decode_mean}
+            'decode_mean': _hip_decode_mean, 'counts': _hip_row_counts}
 
 
 class FusedELBO(torch.autograd.Function):
@@ -366,8 +393,13 @@ class FusedELBO(torch.autograd.Function):
         flow_c = flow.detach().contiguous() if flow is not None else None
         raw = _BACKEND['elbo'](spec, response, mask, mask_code, row_index, table_c, item_c,
                                eps.contiguous(), flow_c, reg_mode, need_grad, num_person)
-        if reducer is not None:
-            reducer(raw.flat)        # person-sharded data parallelism: ONE all-reduce (RCCL) per step
+        if reducer is not None:      # person-sharded data parallelism: ONE all-reduce (RCCL) per step
+            if spec.given:           # (the per-person posterior gradients in the middle of the buffer stay local)
+                reducer(raw.flat[:_lib.NUM_SCALARS])
+                if raw.n_item + 2 * raw.n_flow:
+                    reducer(raw.flat[_lib.NUM_SCALARS + 2 * raw.n_table:])
+            else:
+                reducer(raw.flat)
         ctx.raw = raw
         ctx.item_shape = tuple(item.shape)
         ctx.has_flow = flow is not None
@@ -405,8 +437,8 @@ def fused_elbo(spec, table, item, flow, response, mask, eps, *, reg_mode=_lib.RE
     I = response.shape[1]
     spec.check_supported(I)
     B = int(row_index.numel()) if row_index is not None else response.shape[0]
-    if tuple(table.shape) != spec.table_shape(I):
-        raise ValueError(f'table shape {tuple(table.shape)} != {spec.table_shape(I)}')
+    if tuple(table.shape) != spec.table_shape(I, B):
+        raise ValueError(f'table shape {tuple(table.shape)} != {spec.table_shape(I, B)}')
     if tuple(item.shape) != (I, spec.item_dim):
         raise ValueError(f'item shape {tuple(item.shape)} != {(I, spec.item_dim)}')
     if tuple(eps.shape) != (B, spec.ability_dim):

@@ -70,6 +70,54 @@ class AbilityEncoder(nn.Module):
         return self.mlp(x.reshape(2 * I, -1)).view(2, I, -1)
 
 
+class _SumGradAcrossRanks(torch.autograd.Function):
+    """Identity whose backward all-reduces (sums) the gradient over the person shards: the mean-merge encoder's
+    parameters see only this rank's persons through autograd."""
+
+    @staticmethod
+    def forward(ctx, x, reducer):
+        ctx.reducer = reducer
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.reducer(g)
+        return g, None
+
+
+class MeanAbilityEncoder(nn.Module):
+    """--ability-merge mean (keys ability_encoder.mlp1.{0,2}.*, mlp2.{0,2}.*; models.py:584-594, 631-650).
+
+    mlp1 -> ELU gives one feature vector per (person, item) term, which for a Bernoulli response takes two values;
+    the mean over a person's OBSERVED items is therefore (n0 h(0) + n1 h(1)) / n_obs with the counts of
+    vibo_row_counts, and mlp2 -- the one dense [B,H] x [H,H] contraction of the path -- maps it to (mu, logvar)."""
+
+    def __init__(self, ability_dim, hidden_dim):
+        super().__init__()
+        self.ability_dim = ability_dim
+        self.conditional = False
+        self.mlp1 = nn.Sequential(nn.Linear(1, hidden_dim), nn.ELU(inplace=True), nn.Linear(hidden_dim, hidden_dim))
+        self.mlp2 = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ELU(inplace=True),
+                                  nn.Linear(hidden_dim, 2 * ability_dim))
+        self.register_buffer('_response_values', torch.tensor([[0.0], [1.0]]), persistent=False)
+
+    def posterior(self, n_correct, n_observed, reducer=None):
+        """[B, 2A] = (mu | logvar) of every person from the row counts (0 observed items -> NaN, as the reference's
+        mean over an empty set, models.py:639-642)."""
+        h = F.elu(self.mlp1(self._response_values.to(self.mlp1[0].weight.dtype)))        # [2, H]
+        if reducer is not None:
+            h = _SumGradAcrossRanks.apply(h, reducer)
+        w1 = (n_correct / n_observed).unsqueeze(1)
+        hid_mean = (1.0 - w1) * h[0] + w1 * h[1]
+        if reducer is None:
+            return self.mlp2(hid_mean)
+        l0, l2 = self.mlp2[0], self.mlp2[2]
+        sync = lambda t: _SumGradAcrossRanks.apply(t, reducer)
+        x = F.elu(F.linear(hid_mean, sync(l0.weight), sync(l0.bias)))
+        return F.linear(x, sync(l2.weight), sync(l2.bias))
+
+
 class ItemEncoder(nn.Module):
     """Per-item Gaussian posterior parameters (models.py:713-726)."""
 
@@ -176,8 +224,9 @@ class VIBO_1PL(nn.Module):
             raise AssertionError('bad response_dist')
         # the fused HIP path covers the 1PL/2PL/3PL logistic link with the product-of-experts
         # encoder on Bernoulli responses (BASELINE.json north_star); nothing else is in scope
-        if ability_merge != 'product':
-            raise NotImplementedError("only --ability-merge product is implemented by the HIP engine")
+        if ability_merge == 'mean' and conditional_posterior:
+            # per-(code, item) feature vectors of width hidden_dim: a [B, 2I] x [2I, H] contraction per step
+            raise NotImplementedError("--ability-merge mean with --conditional-posterior is not implemented by the HIP engine")
         if generative_model != 'irt':
             raise NotImplementedError("only --generative-model irt is implemented by the HIP engine")
         if response_dist != 'bernoulli':
@@ -196,11 +245,15 @@ class VIBO_1PL(nn.Module):
         self.irt_num = self.IRT
         self.item_feat_dim = item_feat_dim(self.IRT, latent_dim)
         self.spec = ElboSpec(irt_model=self.IRT, ability_dim=latent_dim, conditional=conditional_posterior,
-                             drop_missing=not replace_missing_with_prior, n_flows=n_norm_flows)
+                             drop_missing=not replace_missing_with_prior, n_flows=n_norm_flows,
+                             given=ability_merge == 'mean')
         self.spec.check_supported(num_item)
 
         # construction order = the reference's (models.py:281-309) so seeded init matches
-        self.ability_encoder = AbilityEncoder(latent_dim, self.item_feat_dim, hidden_dim, conditional_posterior)
+        if ability_merge == 'mean':
+            self.ability_encoder = MeanAbilityEncoder(latent_dim, hidden_dim)
+        else:
+            self.ability_encoder = AbilityEncoder(latent_dim, self.item_feat_dim, hidden_dim, conditional_posterior)
         self.item_encoder = ItemEncoder(num_item, self.item_feat_dim)
         if n_norm_flows > 0:
             self.ability_norm_flows = FlowStack(latent_dim, n_norm_flows)
@@ -257,7 +310,18 @@ class VIBO_1PL(nn.Module):
             flow_packed = self.ability_norm_flows.packed()
         else:
             item_k, item_ladj, flow_packed = item_feat, None, None
-        table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
+        if self.ability_merge == 'mean':      # per-person posterior from the row counts; the kernel takes it as given
+            if not isinstance(response, ops.CellCodes):
+                response = ops.prepare_response(response)
+                if response.shape[1] % 4 != 0 and response.stride(0) < (response.shape[1] + 3) // 4 * 4:
+                    # compact ragged rows (e.g. 95 items): this path has no fallback kernel, so pad the minibatch
+                    m2 = ops.prepare_mask(mask)[0]
+                    if row_index is not None:
+                        response, m2, row_index = response[row_index], (m2[row_index] if m2 is not None else None), None
+                    response, mask = ops.pad_rows(response, m2)
+            table = self.ability_encoder.posterior(*ops.row_counts(response, mask, row_index), reducer=self._reducer)
+        else:
+            table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
         B = int(row_index.numel()) if row_index is not None else response.shape[0]
         if eps_ability is None:
             eps_ability = self._randn((B, self.ability_dim), item_mu, self._ability_gen)
@@ -287,8 +351,11 @@ class VIBO_1PL(nn.Module):
         (models.py:356-371): forward-only kernel, no gradients through the ability side."""
         item_feat, item_mu, item_lv = self._item_side()
         with torch.no_grad():
-            table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
-            amu, alv = encode_posterior(self.spec, table, response, mask, row_index=row_index)
+            if self.ability_merge == 'mean':
+                amu, alv = torch.chunk(self.ability_encoder.posterior(*ops.row_counts(response, mask, row_index)), 2, dim=1)
+            else:
+                table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
+                amu, alv = encode_posterior(self.spec, table, response, mask, row_index=row_index)
             ability = self.reparameterize_gaussian(
                 amu, alv, self._randn(amu.shape, amu, self._ability_gen))
         return ability, amu, alv, item_feat, item_mu, item_lv
@@ -339,7 +406,7 @@ class VIBO_1PL(nn.Module):
         (vibo_elbo_multi_forward); otherwise one forward launch per sample."""
         with torch.no_grad():
             S = int(num_samples)
-            if not self.conditional_posterior:
+            if not self.conditional_posterior and self.ability_merge == 'product':
                 if not isinstance(response, ops.CellCodes):
                     response = ops.prepare_response(response)
                     if response.shape[1] % 4 != 0 and response.stride(0) < (response.shape[1] + 3) // 4 * 4:

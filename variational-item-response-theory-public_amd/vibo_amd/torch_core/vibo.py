@@ -353,7 +353,8 @@ def main(argv=None):
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
     trainer = None
-    if args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and not args.torch_optimizer:
+    if (args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and args.ability_merge == 'product'
+            and not args.torch_optimizer):
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr)       # same Adam arithmetic, ~7 launches per step
     graphed = None

@@ -19,8 +19,8 @@ from . import _lib, ops
 
 class FusedTrainer:
     def __init__(self, model, lr=5e-3, rng='torch', seed=0):
-        if model.conditional_posterior or model.n_norm_flows > 0:
-            raise NotImplementedError('FusedTrainer covers the unconditional posterior without flows; '
+        if model.conditional_posterior or model.n_norm_flows > 0 or model.ability_merge != 'product':
+            raise NotImplementedError('FusedTrainer covers the unconditional product-of-experts posterior without flows; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
         self.model = model
         mlp = model.ability_encoder.mlp
