@@ -57,6 +57,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=8)
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
+    ap.add_argument('--ability-merge', choices=['product', 'mean'], default='product', help="'mean': the reference's other encoder (models.py:631-650) through VIBO_POSTERIOR_GIVEN + torch autograd / Adam (implies --torch-optimizer --no-graph)")
     ap.add_argument('--no-format-p', action='store_true', help='skip the extra Format P (1-byte cell codes) measurement of the same step')
     ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
     ap.add_argument('--rng', choices=['native', 'torch'], default='native', help='reparameterisation noise: vibo_fill_normal (Philox, in the C ABI) or torch.randn')
@@ -139,6 +140,8 @@ def cpu_baseline(args, irt):
 
 def main():
     args = parse()
+    if args.ability_merge == 'mean':
+        args.torch_optimizer, args.no_graph, args.also_ability_dim = True, True, 0
     irt = int(args.irt_model[0])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -167,7 +170,7 @@ def main():
             resp, mask = ops.pack_cell_codes(resp, mask), None
             torch.cuda.empty_cache()
         torch.manual_seed(args.seed)
-        model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge='product').to(dev)
+        model = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt](A, I, ability_merge=args.ability_merge).to(dev)
         if dist is not None:
             model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
         trainer, opt = None, None
@@ -340,7 +343,7 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU, '
-                                   f'ability_dim={A}, {args.missing:.0%} missing, product-of-experts encoder, '
+                                   f'ability_dim={A}, {args.missing:.0%} missing, {"product-of-experts" if args.ability_merge == "product" else "mean-merge"} encoder, '
                                    f'unconditional posterior, full-shard minibatch',
                        'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': ('hipGraph replay' if (dist is None or args.graph_collective) else 'two hipGraphs around an eager RCCL all-reduce') if m['graph'] else 'eager',
                        'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',

@@ -177,6 +177,22 @@ int vibo_row_counts(const vibo_desc* d, const float* response, const void* mask,
                     void* stream);
 
 /*
+ * The --ability-merge mean encoder per person (models.py:584-594, 631-650).  With Bernoulli responses the mean of the
+ * per-term features over a person's observed items is h0 + w (h1 - h0), w = n_correct / n_observed (counts from
+ * vibo_row_counts), so the first layer of mlp2 is affine in w:  z = u + w v  with the two H-vectors
+ * u = W1 h0 + b1, v = W1 (h1 - h0) the caller forms from mlp1 / mlp2[0] (autograd on 2 x H numbers).  These entry points
+ * do the per-person rest:  posterior[p] = W2 elu(u + w_p v) + b2  = (mu | logvar) [2A]   (W2 = mlp2[2].weight [2A][H]),
+ * and its backward: given d loss / d posterior [B][2A] (what vibo_elbo_fwd_bwd returns in VIBO_POSTERIOR_GIVEN mode,
+ * combined by the caller), `partials` receives n_partials records [ d/du (H) | d/dv (H) | d/dW2 (2A x H) | d/db2 (2A) ]
+ * that the caller sums (fixed order).  n_partials = vibo_mean_encoder_partials(d); hidden <= 256.
+ */
+int vibo_mean_encoder_partials(const vibo_desc* d);
+int vibo_mean_encoder_forward(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v,
+                              const float* w2, const float* b2, float* posterior, void* stream);
+int vibo_mean_encoder_backward(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v,
+                               const float* w2, const float* grad_posterior, float* partials, int n_partials, void* stream);
+
+/*
  * Repack B rows from the reference's layout (fp32 `response`, `mask` per d->mask_dtype U8 / I64 / NONE, strides from d)
  * into 1-byte cell codes for VIBO_MASK_CODES: codes[row * codes_row_stride + i], i < num_item; the cells between
  * num_item and codes_row_stride are written as "missing".  One pass, done once for a device-resident dataset

@@ -80,6 +80,19 @@ def install(ops):
         k = msk != 0
         return (((resp == 1) & k).sum(1).to(torch.int32) << 16) | k.sum(1).to(torch.int32)
 
+    def _mean_w(counts):
+        return ((counts >> 16).float() / (counts & 0xffff).float()).unsqueeze(1)
+
+    def mean_fwd(counts, u, v, w2, b2):
+        return torch.nn.functional.elu(u + _mean_w(counts) * v) @ w2.t() + b2
+
+    def mean_bwd(counts, u, v, w2, gpost):
+        w = _mean_w(counts)
+        z = u + w * v
+        a = torch.nn.functional.elu(z)
+        gz = (gpost @ w2) * torch.where(z > 0, torch.ones_like(z), a + 1.0)
+        return gz.sum(0), (w * gz).sum(0), gpost.t() @ a, gpost.sum(0)
+
     def decode(spec, ability, item):
         from oracle.vibo_oracle import irt_link
         return irt_link(spec.irt_model, ability, item)
@@ -91,7 +104,8 @@ def install(ops):
         from oracle.vibo_oracle import irt_link
         return torch.stack([irt_link(spec.irt_model, abilities[s], items[s]) for s in range(abilities.shape[0])]).mean(0)
 
-    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts)
+    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts, mean_fwd=mean_fwd,
+                        mean_bwd=mean_bwd)
 
     def restore():
         ops._BACKEND.update(saved)

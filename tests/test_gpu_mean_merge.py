@@ -37,7 +37,8 @@ def test_row_counts(I, layout):
         args = ops.pad_rows(resp, mask)
     else:
         args = (resp, mask)
-    n1, nobs = ops.row_counts(*args, row_index=rows)
+    c = ops.row_counts(*args, row_index=rows)
+    n1, nobs = (c >> 16).float(), (c & 0xffff).float()
     sel = rows if rows is not None else slice(None)
     assert torch.equal(nobs, mask[sel].sum(1).float())
     assert torch.equal(n1, ((resp[sel] == 1) & mask[sel]).sum(1).float())
@@ -181,3 +182,28 @@ def test_cli_mean_merge_trains(tmp_path, monkeypatch):
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     ck = torch.load(tmp_path / 'out' / run_dir / 'checkpoint.pth.tar', weights_only=False)
     assert 'ability_encoder.mlp2.2.weight' in ck['model_state_dict'] and 0.0 <= ck['missing_imputation_accuracy'] <= 1.0
+
+
+@pytest.mark.parametrize('B,H,A', [(1, 64, 1), (257, 64, 8), (5000, 16, 3), (70000, 200, 2), (300, 256, 8)])
+def test_mean_encoder_kernels_vs_torch(B, H, A):
+    """vibo_mean_encoder_forward / _backward against autograd through the same expression in fp64."""
+    g = torch.Generator().manual_seed(B + H)
+    nobs = torch.randint(1, 900, (B,), generator=g)
+    n1 = (torch.rand(B, generator=g) * (nobs + 1)).long().clamp(max=nobs)
+    counts = ((n1 << 16) | nobs).to(torch.int32).to(dev)
+    u, v = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    w2, b2 = torch.randn(2 * A, H, generator=g) * 0.3, torch.randn(2 * A, generator=g)
+    gp = torch.randn(B, 2 * A, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (u, v, w2, b2)]
+    w = (n1.double() / nobs.double()).unsqueeze(1)
+    ref = torch.nn.functional.elu(leaves[0] + w * leaves[1]) @ leaves[2].t() + leaves[3]
+    gref = torch.autograd.grad((ref * gp.double()).sum(), leaves)
+    dl = [t.to(dev).requires_grad_(True) for t in (u, v, w2, b2)]
+    post = ops.MeanEncoderFn.apply(*dl, counts)
+    assert (post.detach().cpu() - ref.detach().float()).abs().max() < 2e-5 * max(1.0, float(ref.detach().abs().max()))
+    got = torch.autograd.grad((post * gp.to(dev)).sum(), dl)
+    for a, b in zip(got, gref):
+        assert rel_err(a.cpu(), b) < 2e-5
+    again = torch.autograd.grad((ops.MeanEncoderFn.apply(*dl, counts) * gp.to(dev)).sum(), dl)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)          # fixed-order reduction: bitwise reproducible

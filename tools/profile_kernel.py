@@ -23,6 +23,7 @@ ap.add_argument('--cond', action='store_true')
 ap.add_argument('--flows', type=int, default=0)
 ap.add_argument('--missing', type=float, default=0.1)
 ap.add_argument('--gather', action='store_true', help='rows through a random row_index permutation (shuffled minibatch)')
+ap.add_argument('--given', action='store_true', help='caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN, the --ability-merge mean path)')
 ap.add_argument('--codes', action='store_true', help='rows as 1-byte cell codes (VIBO_MASK_CODES, Format P) instead of fp32 + mask')
 ap.add_argument('--cached-rows', type=int, default=0, help='gather rows from the first N rows only (L2-resident): compute-only timing')
 a = ap.parse_args()
@@ -32,8 +33,8 @@ P, I, A = a.persons, a.items, a.ability_dim
 D = {1: 1, 2: A + 1, 3: A + 2}[a.irt]
 resp = (torch.rand(P, I, device=d, generator=g) < 0.5).float()
 mask = torch.rand(P, I, device=d, generator=g) >= a.missing
-spec = ElboSpec(irt_model=a.irt, ability_dim=A, conditional=a.cond, n_flows=a.flows)
-table = torch.randn(*spec.table_shape(I), device=d, generator=g) * 0.5
+spec = ElboSpec(irt_model=a.irt, ability_dim=A, conditional=a.cond, n_flows=a.flows, given=a.given)
+table = torch.randn(*spec.table_shape(I, P), device=d, generator=g) * 0.5
 flow = torch.randn(a.flows, 2 * A + 1, device=d, generator=g) * 0.5 if a.flows else None
 reg = _lib.REG_SAMPLED if a.flows else _lib.REG_KL
 item = torch.randn(I, D, device=d, generator=g)
@@ -55,5 +56,5 @@ for _ in range(a.iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
-print(f'P={P} I={I} A={A} irt={a.irt} cond={a.cond} flows={a.flows} grad={not a.no_grad} gather={ridx is not None}: {ms:.3f} ms/call, {P*I/ms/1e9:.3f} T terms/s, '
+print(f'P={P} I={I} A={A} irt={a.irt} given={a.given} cond={a.cond} flows={a.flows} grad={not a.no_grad} gather={ridx is not None}: {ms:.3f} ms/call, {P*I/ms/1e9:.3f} T terms/s, '
       f'{((1 if a.codes else 5)+12*A/I)*P*I/ms/1e6:.0f} GB/s algorithmic{" (1 B/cell codes)" if a.codes else ""}, ll={float(raw.scalars[0]):.1f}')

@@ -45,7 +45,8 @@ class ViboDesc(ctypes.Structure):
 
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
-                    'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts')
+                    'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
+                    'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward')
 
 _lib = None
 
@@ -94,6 +95,12 @@ def load():
     lib.vibo_elbo_multi_forward.argtypes = [dp, ctypes.c_int, fp, vp, i64p, fp, fp, fp, fp, fp, vp, ctypes.c_size_t, vp]
     lib.vibo_row_counts.restype = ctypes.c_int
     lib.vibo_row_counts.argtypes = [dp, fp, vp, i64p, vp, vp]
+    lib.vibo_mean_encoder_partials.restype = ctypes.c_int
+    lib.vibo_mean_encoder_partials.argtypes = [dp]
+    lib.vibo_mean_encoder_forward.restype = ctypes.c_int
+    lib.vibo_mean_encoder_forward.argtypes = [dp, ctypes.c_int, vp, fp, fp, fp, fp, fp, vp]
+    lib.vibo_mean_encoder_backward.restype = ctypes.c_int
+    lib.vibo_mean_encoder_backward.argtypes = [dp, ctypes.c_int, vp, fp, fp, fp, fp, fp, ctypes.c_int, vp]
     lib.vibo_pack_codes.restype = ctypes.c_int
     lib.vibo_pack_codes.argtypes = [dp, fp, vp, vp, ctypes.c_int64, vp]
     lib.vibo_decode_mean.restype = ctypes.c_int

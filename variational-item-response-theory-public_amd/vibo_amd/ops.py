@@ -347,11 +347,59 @@ def _hip_row_counts(response, mask, mask_code, row_index):
 
 
 def row_counts(response, mask, row_index=None):
-    """(n_correct, n_observed) per person as float tensors [B] -- the sufficient statistics of a Bernoulli response row
-    for the unconditional encoders (here: the masked mean of --ability-merge mean, models.py:631-650)."""
+    """int32 [B]: n_correct << 16 | n_observed per person -- the sufficient statistics of a Bernoulli response row for
+    the unconditional encoders (here: the masked mean of --ability-merge mean, models.py:631-650)."""
     response, mask, code = prepare_rows(response, mask, keep_int64=True)
-    c = _BACKEND['counts'](response, mask, code, row_index)
-    return (c >> 16).float(), (c & 0xffff).float()
+    return _BACKEND['counts'](response, mask, code, row_index)
+
+
+def _mean_desc(counts, A):
+    return _make_desc(ElboSpec(irt_model=1, ability_dim=A), int(counts.numel()), 1, _lib.MASK_NONE, _lib.REG_KL, False, 1, 0)
+
+
+def _hip_mean_encoder_fwd(counts, u, v, w2, b2):
+    lib = _lib.load()
+    _require_device(counts, u, v, w2, b2)
+    A2, H = w2.shape
+    post = torch.empty(counts.numel(), A2, dtype=torch.float32, device=counts.device)
+    d = _mean_desc(counts, A2 // 2)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(counts.device).cuda_stream)
+    rc = lib.vibo_mean_encoder_forward(ctypes.byref(d), H, _ptr(counts), _ptr(u), _ptr(v), _ptr(w2), _ptr(b2), _ptr(post), stream)
+    _lib.check(rc, 'vibo_mean_encoder_forward')
+    return post
+
+
+def _hip_mean_encoder_bwd(counts, u, v, w2, gpost):
+    """-> (d/du [H], d/dv [H], d/dW2 [2A,H], d/db2 [2A]) summed over the persons."""
+    lib = _lib.load()
+    _require_device(counts, u, v, w2, gpost)
+    A2, H = w2.shape
+    d = _mean_desc(counts, A2 // 2)
+    n_part = lib.vibo_mean_encoder_partials(ctypes.byref(d))
+    part = torch.empty(n_part, 2 * H + A2 * H + A2, dtype=torch.float32, device=counts.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(counts.device).cuda_stream)
+    rc = lib.vibo_mean_encoder_backward(ctypes.byref(d), H, _ptr(counts), _ptr(u), _ptr(v), _ptr(w2), _ptr(gpost), _ptr(part),
+                                        n_part, stream)
+    _lib.check(rc, 'vibo_mean_encoder_backward')
+    tot = part.sum(0)
+    return tot[:H], tot[H:2 * H], tot[2 * H:2 * H + A2 * H].view(A2, H), tot[2 * H + A2 * H:]
+
+
+class MeanEncoderFn(torch.autograd.Function):
+    """(u, v, W2, b2) -> posterior [B, 2A] = W2 elu(u + w_p v) + b2 with w_p from the packed row counts
+    (vibo_mean_encoder_forward / _backward; see include/vibo_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, u, v, w2, b2, counts):
+        u, v, w2, b2 = (t.detach().contiguous().float() for t in (u, v, w2, b2))
+        ctx.save_for_backward(u, v, w2, counts)
+        return _BACKEND['mean_fwd'](counts, u, v, w2, b2)
+
+    @staticmethod
+    def backward(ctx, g):
+        u, v, w2, counts = ctx.saved_tensors
+        gu, gv, gw2, gb2 = _BACKEND['mean_bwd'](counts, u, v, w2, g.contiguous().float())
+        return gu, gv, gw2, gb2, None
 
 
 def _hip_decode_mean(spec, abilities, items):
@@ -370,7 +418,8 @@ def _hip_decode_mean(spec, abilities, items):
 # The three entry points of the native library.  tests/ swap these for the CPU
 # oracle to exercise the host logic without a GPU (never done by product code).
 _BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward,
-            'decode_mean': _hip_decode_mean, 'counts': _hip_row_counts}
+            'decode_mean': _hip_decode_mean, 'counts': _hip_row_counts, 'mean_fwd': _hip_mean_encoder_fwd,
+            'mean_bwd': _hip_mean_encoder_bwd}
 
 
 class FusedELBO(torch.autograd.Function):

@@ -102,20 +102,17 @@ class MeanAbilityEncoder(nn.Module):
                                   nn.Linear(hidden_dim, 2 * ability_dim))
         self.register_buffer('_response_values', torch.tensor([[0.0], [1.0]]), persistent=False)
 
-    def posterior(self, n_correct, n_observed, reducer=None):
-        """[B, 2A] = (mu | logvar) of every person from the row counts (0 observed items -> NaN, as the reference's
-        mean over an empty set, models.py:639-642)."""
-        h = F.elu(self.mlp1(self._response_values.to(self.mlp1[0].weight.dtype)))        # [2, H]
-        if reducer is not None:
-            h = _SumGradAcrossRanks.apply(h, reducer)
-        w1 = (n_correct / n_observed).unsqueeze(1)
-        hid_mean = (1.0 - w1) * h[0] + w1 * h[1]
-        if reducer is None:
-            return self.mlp2(hid_mean)
+    def posterior(self, counts, reducer=None):
+        """[B, 2A] = (mu | logvar) of every person from the packed row counts (0 observed items -> NaN, as the
+        reference's mean over an empty set, models.py:639-642)."""
+        h = F.elu(self.mlp1(self._response_values.to(self.mlp1[0].weight.dtype)))        # [2, H]: the two per-term features
         l0, l2 = self.mlp2[0], self.mlp2[2]
-        sync = lambda t: _SumGradAcrossRanks.apply(t, reducer)
-        x = F.elu(F.linear(hid_mean, sync(l0.weight), sync(l0.bias)))
-        return F.linear(x, sync(l2.weight), sync(l2.bias))
+        u = F.linear(h[0], l0.weight, l0.bias)              # first layer of mlp2 is affine in w = n_correct / n_observed
+        v = F.linear(h[1] - h[0], l0.weight)
+        w2, b2 = l2.weight, l2.bias
+        if reducer is not None:      # person-sharded: these four see only this rank's persons
+            u, v, w2, b2 = (_SumGradAcrossRanks.apply(t, reducer) for t in (u, v, w2, b2))
+        return ops.MeanEncoderFn.apply(u, v, w2, b2, counts)
 
 
 class ItemEncoder(nn.Module):
@@ -319,7 +316,7 @@ class VIBO_1PL(nn.Module):
                     if row_index is not None:
                         response, m2, row_index = response[row_index], (m2[row_index] if m2 is not None else None), None
                     response, mask = ops.pad_rows(response, m2)
-            table = self.ability_encoder.posterior(*ops.row_counts(response, mask, row_index), reducer=self._reducer)
+            table = self.ability_encoder.posterior(ops.row_counts(response, mask, row_index), reducer=self._reducer)
         else:
             table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
         B = int(row_index.numel()) if row_index is not None else response.shape[0]
@@ -352,7 +349,7 @@ class VIBO_1PL(nn.Module):
         item_feat, item_mu, item_lv = self._item_side()
         with torch.no_grad():
             if self.ability_merge == 'mean':
-                amu, alv = torch.chunk(self.ability_encoder.posterior(*ops.row_counts(response, mask, row_index)), 2, dim=1)
+                amu, alv = torch.chunk(self.ability_encoder.posterior(ops.row_counts(response, mask, row_index)), 2, dim=1)
             else:
                 table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
                 amu, alv = encode_posterior(self.spec, table, response, mask, row_index=row_index)
