@@ -328,12 +328,15 @@ def main():
     # MI355X_MICROARCH.md) cannot be collected from inside this process; for the default workload the value
     # recorded in profiles/r01_bench_profile.txt is reported, otherwise null.
     traffic, traffic_note = None, 'not measured for this workload'
-    recorded = {8: (2 * 2461238 + 111894) * 1024.0, 1: (2 * 2453309 + 15751) * 1024.0}     # KiB counters -> bytes
+    recorded = {8: (2 * 2461234 + 111894) * 1024.0, 1: (2 * 2453304 + 15751) * 1024.0}     # KiB counters -> bytes
+    recorded_p = {8: (2 * 508101 + 111894) * 1024.0}                                        # Format P launch (cell codes)
     if (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and A in recorded:
         traffic = recorded[A]
         traffic_note = 'recorded measurement: profiles/r01_bench_profile.txt (2*FETCH_SIZE + WRITE_SIZE of vibo::split_kernel, KiB)'
     if also is not None and (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and args.also_ability_dim in recorded:
         also['traffic'] = recorded[args.also_ability_dim]
+    if format_p is not None and (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and A in recorded_p:
+        format_p['traffic'] = recorded_p[A]
     if rank == 0:
         terms = float(P) * I * args.steps * world
         line = {

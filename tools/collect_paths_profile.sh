@@ -21,5 +21,14 @@ run --persons 100000 --items 10000 --ability-dim 1
 run --persons 100000 --items 10000 --ability-dim 1 --irt 3 --cond --flows 4
 run --persons 535596 --items 96 --ability-dim 1 --missing 0.2
 run --persons 1000000 --items 1000 --ability-dim 8 --no-grad
+# shuffled minibatch (rows through row_index), Format P cell codes, caller-supplied posterior (--ability-merge mean)
+run --persons 1000000 --items 1000 --ability-dim 8 --gather
+run --persons 1000000 --items 1000 --ability-dim 1 --gather
+run --persons 1000000 --items 1000 --ability-dim 1 --codes
+run --persons 1000000 --items 1000 --ability-dim 4 --codes
+run --persons 1000000 --items 1000 --ability-dim 8 --codes --gather
+run --persons 1000000 --items 1000 --ability-dim 1 --cond --codes
+run --persons 100000 --items 10000 --ability-dim 1 --irt 3 --cond --flows 4 --codes
+run --persons 1000000 --items 1000 --ability-dim 8 --given
 rm -rf /tmp/kt
 echo "wrote $S"
