@@ -247,13 +247,17 @@ while time.time() - t0 < a.seconds:
     no_mask = missing == 0.0 and rng.random() < 0.3
     fwd_only = rng.random() < 0.2
     codes = rng.random() < 0.35 and not no_mask and not (cond and A > 4)      # rows as 1-byte cell codes (Format P)
+    given = (not cond) and rng.random() < 0.25      # caller-supplied posterior (VIBO_POSTERIOR_GIVEN, --ability-merge mean)
     if a.replay:
         f = a.replay.split()
         irt, A, B, I, n_flows, dataseed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])
         cond, drop, pad, missing, scale = f[4] == 'True', f[6] == 'True', f[8] == 'True', float(f[7]), float(f[9])
         gather, no_mask, fwd_only = f[11] == 'True', f[12] == 'True', f[13] == 'True'
         codes = len(f) > 14 and f[14] == 'True'
-    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, drop_missing=drop, n_flows=n_flows)
+        given = len(f) > 15 and f[15] == 'True'
+    if given:
+        pad = True                 # this mode exists on the row-split path only: rows padded like the resident data path does
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, drop_missing=drop, n_flows=n_flows, given=given)
     g = torch.Generator().manual_seed(dataseed)
     P = B + rng.choice([3, 50]) if gather else B
     resp_all, mask_all = O.simulate_responses(irt, P, I, A, generator=g, missing_frac=missing)
@@ -265,6 +269,8 @@ while time.time() - t0 < a.seconds:
         resp, mask = (resp_all[rows], mask_all[rows]) if gather else (resp_all, mask_all)
     D = O.item_feat_dim(irt, A)
     table = torch.randn((2, I, 2 * A) if cond else (2, 2 * A), generator=g) * 0.7
+    if given:                      # (mu | logvar) per person
+        table = torch.cat([torch.randn(B, A, generator=g) * 0.8, torch.randn(B, A, generator=g) * 0.6 - 1.5], dim=1)
     item = torch.randn(I, D, generator=g) * scale
     eps = torch.randn(B, A, generator=g)
     flow = None
@@ -278,7 +284,8 @@ while time.time() - t0 < a.seconds:
     flows = [(f[:A].double(), f[A:2 * A].double(), f[2 * A:].double()) for f in flow] if n_flows else None
     mode = 'sampled' if n_flows else 'kl'
     ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt, ability_dim=A,
-                           conditional_posterior=cond, replace_missing_with_prior=not drop, mode=mode, flow_uhat_w_b=flows)
+                           conditional_posterior=cond, replace_missing_with_prior=not drop, mode=mode, flow_uhat_w_b=flows,
+                           given_posterior=given)
     r_, m_ = (ops.pad_rows(resp_all.to(d), mask_all.bool().to(d)) if pad else (resp_all.to(d), mask_all.bool().to(d)))
     if codes:
         r_, m_ = ops.pack_cell_codes(resp_all.to(d), mask_all.bool().to(d)), None
@@ -305,7 +312,7 @@ while time.time() - t0 < a.seconds:
             if float(gref.abs().max()) > 0:
                 errs[f'g_flow{s_}'] = rel(raw.grad_flow(s_).cpu(), gref)
     # model.encode's kernel on the same rows (row-statistics fast path or wave-per-person fallback)
-    emu, elv = ops.encode_posterior(spec, table.to(d), r_, None if no_mask else m_, row_index=rows.to(d) if gather else None)
+    emu, elv = (raw.ability_mu, raw.ability_logvar) if given else ops.encode_posterior(spec, table.to(d), r_, None if no_mask else m_, row_index=rows.to(d) if gather else None)
     errs['enc_mu'] = float((emu.cpu() - ref['ability_mu'].float()).abs().max()) / max(1.0, float(ref['ability_mu'].abs().max()))
     errs['enc_lv'] = float((elv.cpu() - ref['ability_logvar'].float()).abs().max()) / max(1.0, float(ref['ability_logvar'].abs().max()))
     lim = {'ll': 3e-5, 'reg': 3e-5, 'mu': 3e-5, 'theta': 6e-5, 'enc_mu': 3e-5, 'enc_lv': 3e-5}
@@ -316,7 +323,7 @@ while time.time() - t0 < a.seconds:
         print('replayed:', errs)
         sys.exit(1 if bad else 0)
     if bad:
-        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only} codes={codes}: {bad}')
-        print(f'replay: --replay "{irt} {A} {B} {I} {cond} {n_flows} {drop} {missing} {pad} {scale} {dataseed} {gather} {no_mask} {fwd_only} {codes}"')
+        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only} codes={codes} given={given}: {bad}')
+        print(f'replay: --replay "{irt} {A} {B} {I} {cond} {n_flows} {drop} {missing} {pad} {scale} {dataseed} {gather} {no_mask} {fwd_only} {codes} {given}"')
         sys.exit(1)
 print(f'fuzz ok: {n} random configurations, worst relative error {worst:.2e}')

@@ -88,7 +88,8 @@ def main():
             I = rng.choice([1, 3, 4, 12, 64, 95, 100, 256, 260, 512, 1000, 1024, 1028, 2500, 6000, 10000])
             cond = rng.random() < 0.4
             n_flows = rng.choice([0, 0, 2, 4])
-        spec = ElboSpec(irt_model=irt, ability_dim=A, n_flows=n_flows, conditional=cond)
+        given = (not cond) and 4 <= I <= 32767 and rng.random() < 0.25 and n >= len(fixed)      # VIBO_POSTERIOR_GIVEN
+        spec = ElboSpec(irt_model=irt, ability_dim=A, n_flows=n_flows, conditional=cond, given=given)
         try:
             spec.check_supported(I)
         except Exception:
@@ -105,12 +106,12 @@ def main():
         if rows is None:
             r, m = r[:B], m[:B]
         scale = rng.choice([0.5, 0.5, 2.0, 6.0])
-        table = (torch.randn(*spec.table_shape(I), generator=g) * 0.5).to(d)
+        table = (torch.randn(*spec.table_shape(I, B), generator=g) * 0.5).to(d)
         item = (torch.randn(I, spec.item_dim, generator=g) * scale).to(d)
         eps = torch.randn(B, A, generator=g).to(d)
         fl = (torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5).to(d) if n_flows else None
         reg = _lib.REG_SAMPLED if n_flows else rng.choice([_lib.REG_KL, _lib.REG_SAMPLED])
-        cfg = (irt, A, B, I, cond, n_flows, rows is not None, reg, use_codes)
+        cfg = (irt, A, B, I, cond, n_flows, rows is not None, reg, use_codes, given)
         exact = 4 <= I <= 32767 and (not cond or A <= 4)      # row-split paths: partial records + fp64 finalize, no atomics
         for want_grad in (False, True):
             res = []
@@ -125,6 +126,8 @@ def main():
                     hits += 1
         res = []
         for FILL[0] in (0, 0xFF):
+            if given:
+                break
             res.append(ops._hip_encode(spec, r, m, code, rows, table, B))
             hits += not check(('encode',) + cfg)
         for x, y in zip(*res):
@@ -132,7 +135,7 @@ def main():
                 print('INIT-DEPENDENT', ('encode',) + cfg, flush=True)
                 hits += 1
         FILL[0] = 0
-        if not cond:
+        if not cond and not given:
             S = rng.choice([1, 2, 3, 5])
             out = ops._hip_multi_forward(spec, r, m, code, rows, table, torch.stack([item] * S).contiguous(),
                                          torch.stack([eps] * S).contiguous(), fl, _lib.REG_SAMPLED, B)
