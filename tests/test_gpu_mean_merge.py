@@ -207,3 +207,27 @@ def test_mean_encoder_kernels_vs_torch(B, H, A):
     again = torch.autograd.grad((ops.MeanEncoderFn.apply(*dl, counts) * gp.to(dev)).sum(), dl)
     for a, b in zip(got, again):
         assert torch.equal(a, b)          # fixed-order reduction: bitwise reproducible
+
+
+def test_row_counts_are_cached_per_resident_matrix():
+    g = torch.Generator().manual_seed(1)
+    resp, mask = O.simulate_responses(2, 300, 100, 1, generator=g, missing_frac=0.2)
+    resp, mask = resp.to(dev), mask.bool().to(dev)
+    calls = []
+    native = ops._BACKEND['counts']
+    ops._BACKEND['counts'] = lambda *a: (calls.append(1), native(*a))[1]
+    try:
+        rows = torch.tensor([5, 7, 299], device=dev)
+        a = ops.row_counts(resp, mask, rows)
+        b = ops.row_counts(resp, mask)
+        c = ops.row_counts(resp, mask, rows)
+        assert len(calls) == 1 and torch.equal(a, b[rows]) and torch.equal(a, c)
+        mask[5, :] = False                                 # in-place change: counted again
+        d_ = ops.row_counts(resp, mask, rows)
+        assert len(calls) == 2 and int(d_[0]) == 0 and torch.equal(d_[1:], a[1:])
+        codes = ops.pack_cell_codes(resp, mask)
+        e = ops.row_counts(codes, None)
+        f = ops.row_counts(codes, None, rows)
+        assert len(calls) == 3 and torch.equal(e[rows], f) and torch.equal(e, ops.row_counts(resp, mask))
+    finally:
+        ops._BACKEND['counts'] = native

@@ -346,11 +346,26 @@ def _hip_row_counts(response, mask, mask_code, row_index):
     return out
 
 
+_COUNTS_CACHE = []         # [(weakref response, version, weakref mask | None, version, counts)], newest last, at most 4
+
+
 def row_counts(response, mask, row_index=None):
     """int32 [B]: n_correct << 16 | n_observed per person -- the sufficient statistics of a Bernoulli response row for
-    the unconditional encoders (here: the masked mean of --ability-merge mean, models.py:631-650)."""
+    the unconditional encoders (here: the masked mean of --ability-merge mean, models.py:631-650).  The counts of a whole
+    matrix are kept while the same (unmodified) tensors come back -- a resident dataset is counted once, not per step;
+    minibatches gathered through `row_index` index into them."""
+    key_r = response.codes if isinstance(response, CellCodes) else response       # the caller's own tensor objects
+    key_m = mask
+    for rr, rv, mr, mv, cnt in _COUNTS_CACHE:
+        if rr() is key_r and rv == key_r._version and (
+                (mr is None and key_m is None) or (mr is not None and mr() is key_m and mv == key_m._version)):
+            return cnt if row_index is None else cnt[row_index]
     response, mask, code = prepare_rows(response, mask, keep_int64=True)
-    return _BACKEND['counts'](response, mask, code, row_index)
+    cnt = _BACKEND['counts'](response, mask, code, None)
+    _COUNTS_CACHE[:] = [e for e in _COUNTS_CACHE if e[0]() is not None and (e[2] is None or e[2]() is not None)][-3:]
+    _COUNTS_CACHE.append((weakref.ref(key_r), key_r._version, weakref.ref(key_m) if key_m is not None else None,
+                          key_m._version if key_m is not None else 0, cnt))
+    return cnt if row_index is None else cnt[row_index]
 
 
 def _mean_desc(counts, A):
