@@ -201,6 +201,25 @@ def elbo_forward(params, response, mask, eps_item, eps_ability, *, irt_model,
     return out
 
 
+def vi_elbo_forward(params, index, response, mask, eps_item, eps_ability, *, irt_model, ability_dim,
+                    annealing_factor=1.0, use_kl_divergence=True):
+    """Un-amortized VI (models.py:100-243: VI_1PL/2PL/3PL.forward + elbo): per-person Gaussian posteriors looked up by
+    `index` in two embeddings instead of an encoder; same link, log-likelihood and KL / sampled regulariser."""
+    item_mu, item_lv = params['item_mu_lookup.weight'], params['item_logvar_lookup.weight']
+    item_feat = eps_item * torch.exp(0.5 * item_lv) + item_mu                      # models.py:128-131
+    amu, alv = params['ability_mu_lookup.weight'][index], params['ability_logvar_lookup.weight'][index]
+    ability = eps_ability * torch.exp(0.5 * alv) + amu                             # models.py:133-135
+    probs = irt_link(int(irt_model), ability, item_feat)
+    ll = masked_bernoulli_ll(response, mask, probs).sum()
+    if use_kl_divergence:                                                          # models.py:157-160
+        elbo = ll - annealing_factor * kl_std_normal(amu, alv).sum() - annealing_factor * kl_std_normal(item_mu, item_lv).sum()
+    else:                                                                          # models.py:161-170
+        log_p = ll + std_normal_logpdf(ability).sum() + std_normal_logpdf(item_feat).sum()
+        log_q = normal_logpdf(ability, amu, alv).sum() + normal_logpdf(item_feat, item_mu, item_lv).sum()
+        elbo = log_p - log_q
+    return dict(loss=-elbo, ability=ability, ability_mu=amu, ability_logvar=alv, item_feat=item_feat, response_mu=probs)
+
+
 def elbo_loss_and_grads(params, response, mask, eps_item, eps_ability, **cfg):
     """loss + d loss / d every parameter (autograd), as float tensors."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}

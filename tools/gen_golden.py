@@ -188,6 +188,59 @@ def run_case(ref_models, case, out_dir):
     return float(loss.detach())
 
 
+VI_CASES = [
+    # name, irt, A, B, P, I, missing, beta, use_kl   (un-amortized VI: models.py:100-243; persons index an embedding)
+    ('vi_2pl_a2',          2, 2, 16, 40, 20, 0.0, 1.0, True),
+    ('vi_3pl_a1_miss',     3, 1, 37, 60, 95, 0.2, 0.5, True),
+    ('vi_1pl_a3_miss_nokl', 1, 3, 16, 16, 130, 0.2, 1.0, False),
+]
+
+
+def run_vi_case(ref_models, case, out_dir):
+    name, irt, A, B, P, I, missing, beta, use_kl = case
+    seed = 2000 + sum(ord(c) for c in name)
+    resp, mask = make_data(irt, B, I, A, missing, seed)
+    g = torch.Generator().manual_seed(seed)
+    index = torch.randperm(P, generator=g)[:B]
+    cls = {1: ref_models.VI_1PL, 2: ref_models.VI_2PL, 3: ref_models.VI_3PL}[irt]
+    torch.manual_seed(seed)
+    model = cls(A, P, I)
+    with torch.no_grad():
+        # N(0,1)-initialised per-person means AND log-variances put many cells into the Bernoulli probability-clamp band
+        # (|logit| > ~12), where the reference's fp32 result is defined by its own rounding; move to the regime a fitted
+        # model lives in (the parameters used are stored in the fixture, the outputs are still the reference's own)
+        model.ability_mu_lookup.weight.mul_(0.5)
+        model.ability_logvar_lookup.weight.mul_(0.3).sub_(2.0)
+        model.item_mu_lookup.weight.mul_(0.6)
+    D = model.item_feat_dim
+    torch.manual_seed(seed + 1)
+    eps_item = torch.randn(I, D)              # draw order of VI_1PL.encode: item first, then ability
+    eps_ability = torch.randn(B, A)
+    torch.manual_seed(seed + 1)
+    r3, m3 = resp.unsqueeze(2), mask.long().unsqueeze(2)
+    outs = model(index, r3, m3)
+    (_, _, response_mu, ability, ability_mu, ability_logvar, item_feat, item_mu, item_lv) = outs
+    loss = model.elbo(*outs, annealing_factor=beta, use_kl_divergence=use_kl)
+    loss.backward()
+    assert torch.allclose(eps_ability * torch.exp(0.5 * ability_logvar) + ability_mu, ability, atol=1e-6), name
+    assert torch.allclose(eps_item * torch.exp(0.5 * item_lv) + item_mu, item_feat, atol=1e-6), name
+    rec = {
+        'meta': json.dumps(dict(name=name, irt_model=irt, ability_dim=A, num_person=P, batch=B, num_item=I, missing_frac=missing,
+                                annealing_factor=beta, use_kl_divergence=use_kl, torch=torch.__version__)),
+        'response': resp.numpy().astype(np.int8), 'mask': mask.numpy().astype(np.uint8), 'index': index.numpy(),
+        'eps_item': eps_item.numpy(), 'eps_ability': eps_ability.numpy(),
+        'out.loss': loss.detach().numpy(), 'out.ability': ability.detach().numpy(),
+        'out.ability_mu': ability_mu.detach().numpy(), 'out.ability_logvar': ability_logvar.detach().numpy(),
+        'out.item_feat': item_feat.detach().numpy(), 'out.response_mu': response_mu.detach().squeeze(2).numpy(),
+    }
+    for k, v in model.state_dict().items():
+        rec['sd.' + k] = v.detach().numpy().copy()
+    for k, p in model.named_parameters():
+        rec['grad.' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, f'{name}.npz'), **rec)
+    return float(loss.detach())
+
+
 def saturation_case(ref_utils, out_dir):
     """masked_bernoulli_log_pdf(sigmoid(l)) and its gradient for l in [-30, 30]
     plus dense sweeps around the clamp thresholds (utils.py:46-49)."""
@@ -270,6 +323,10 @@ def main():
             continue
         loss = run_case(ref_models, case, out_dir)
         print(f'{case[0]:34s} loss={loss:.6f}')
+    for case in VI_CASES:
+        if args.only and args.only not in case[0]:
+            continue
+        print(f'{case[0]:34s} loss={run_vi_case(ref_models, case, out_dir):.6f}')
     if not args.only:
         saturation_case(ref_utils, out_dir)
         log_marginal_case(ref_models, out_dir)

@@ -477,6 +477,122 @@ class VIBO_3PL(VIBO_2PL):
     IRT = 3
 
 
+# ---------------------------------------------------------------------------
+# un-amortized VI (reference models.py:100-243; training script vi.py): per-person posteriors in two embeddings
+# ---------------------------------------------------------------------------
+
+class VI_1PL(nn.Module):
+    """Drop-in for the reference's VI_1PL/2PL/3PL: forward(index, response, mask) -> the 9-tuple, elbo(*outputs).
+    The per-person (mu, logvar) rows looked up by `index` go to the fused kernel as a caller-supplied posterior
+    (VIBO_POSTERIOR_GIVEN); its per-person gradients flow back into the embeddings through autograd."""
+    IRT = 1
+
+    def __init__(self, latent_dim, num_person, num_item):
+        super().__init__()
+        self.latent_dim = self.ability_dim = latent_dim
+        self.response_dim = 1
+        self.num_person, self.num_item = num_person, num_item
+        self.item_feat_dim = item_feat_dim(self.IRT, latent_dim)
+        self.spec = ElboSpec(irt_model=self.IRT, ability_dim=latent_dim, given=True)
+        self.spec.check_supported(num_item)
+        # construction order = the reference's (models.py:113-117): N(0,1) embeddings drawn in this order
+        self.ability_mu_lookup = nn.Embedding(num_person, latent_dim)
+        self.ability_logvar_lookup = nn.Embedding(num_person, latent_dim)
+        self.item_mu_lookup = nn.Embedding(num_item, self.item_feat_dim)
+        self.item_logvar_lookup = nn.Embedding(num_item, self.item_feat_dim)
+
+    @staticmethod
+    def reparameterize_gaussian(mean, logvar, eps=None):
+        std = torch.exp(0.5 * logvar)
+        return (torch.randn_like(std) if eps is None else eps) * std + mean
+
+    def _posterior_rows(self, index):
+        idx = index.reshape(-1).long()
+        return self.ability_mu_lookup(idx), self.ability_logvar_lookup(idx)
+
+    def _run(self, index, response, mask, eps_item=None, eps_ability=None, reg_mode=_lib.REG_KL, row_index=None):
+        item_mu, item_lv = self.item_mu_lookup.weight, self.item_logvar_lookup.weight
+        item_feat = self.reparameterize_gaussian(item_mu, item_lv, eps_item)          # item eps first (models.py:128-135)
+        amu, alv = self._posterior_rows(index)
+        B = amu.shape[0]
+        if eps_ability is None:
+            eps_ability = torch.randn(B, self.ability_dim, dtype=amu.dtype, device=amu.device)
+        if not isinstance(response, ops.CellCodes):
+            response = ops.prepare_response(response)
+            if response.shape[1] % 4 != 0 and response.stride(0) < (response.shape[1] + 3) // 4 * 4:
+                m2 = ops.prepare_mask(mask)[0]           # compact ragged rows: this mode has no fallback kernel
+                if row_index is not None:
+                    response, m2, row_index = response[row_index], (m2[row_index] if m2 is not None else None), None
+                response, mask = ops.pad_rows(response, m2)
+        table = torch.cat([amu, alv], dim=1)
+        heads = fused_elbo(self.spec, table, item_feat, None, response, mask, eps_ability, reg_mode=reg_mode,
+                           row_index=row_index)
+        ctx = FusedContext(self, response, mask, eps_ability, table, item_feat, None, reg_mode, heads)
+        ctx.item_feat, ctx.item_mu, ctx.item_lv, ctx.eps_item = item_feat, item_mu, item_lv, eps_item
+        ctx.index, ctx.row_index, ctx.amu, ctx.alv = index, row_index, amu, alv
+        return ctx
+
+    def forward(self, index, response, mask, eps_item=None, eps_ability=None, row_index=None):
+        """(response, mask, response_mu, ability, ability_mu, ability_logvar, item_feat, item_feat_mu,
+        item_feat_logvar) (models.py:120-126).  `row_index` gathers the rows from a resident matrix in-kernel."""
+        ctx = self._run(index, response, mask, eps_item, eps_ability, row_index=row_index)
+        return (response, mask, DeferredResponseMu(ctx, ctx.ability, ctx.item_feat), ctx.ability, ctx.amu, ctx.alv,
+                ctx.item_feat, ctx.item_mu, ctx.item_lv)
+
+    def encode(self, index, response=None, mask=None):
+        """models.py:127-139 (plain lookups + reparameterisation; no pass over the responses)."""
+        item_mu, item_lv = self.item_mu_lookup.weight, self.item_logvar_lookup.weight
+        item_feat = self.reparameterize_gaussian(item_mu, item_lv)
+        amu, alv = self._posterior_rows(index)
+        return self.reparameterize_gaussian(amu, alv), amu, alv, item_feat, item_mu, item_lv
+
+    def decode(self, ability, item_feat):
+        return decode_probs(self.spec, ability, item_feat).unsqueeze(2)
+
+    def elbo(self, response, mask, response_mu, ability, ability_mu, ability_logvar, item_feat, item_feat_mu,
+             item_feat_logvar, annealing_factor=1, use_kl_divergence=True):
+        """-ELBO summed over the minibatch (models.py:144-172)."""
+        if not isinstance(response_mu, DeferredResponseMu):
+            raise TypeError('elbo() expects the outputs of this model\'s forward()')
+        ctx = response_mu.ctx
+        want_mode = _lib.REG_KL if use_kl_divergence else _lib.REG_SAMPLED
+        if want_mode != ctx.reg_mode:
+            if torch.is_grad_enabled() and ctx.ll.requires_grad:
+                ctx = self._run(ctx.index, ctx.response, ctx.mask, ctx.eps_item, ctx.eps_ability, reg_mode=want_mode,
+                                row_index=ctx.row_index)
+                item_feat, item_feat_mu, item_feat_logvar = ctx.item_feat, ctx.item_mu, ctx.item_lv
+                reg = ctx.reg
+            else:
+                sc = ctx.scalars
+                reg = (sc[_lib.S_LOGQ0] - sc[_lib.S_LOGP]) if want_mode == _lib.REG_SAMPLED else sc[_lib.S_KL]
+        else:
+            reg = ctx.reg
+        if use_kl_divergence:
+            kl_d = (-0.5 * (1.0 + item_feat_logvar - item_feat_mu.pow(2) - item_feat_logvar.exp())).sum()
+            return -(ctx.ll - annealing_factor * reg - annealing_factor * kl_d)
+        log_q_d = _normal_logpdf(item_feat, item_feat_mu, item_feat_logvar).sum()
+        log_p_d = _std_normal_logpdf(item_feat).sum()
+        return -(ctx.ll + log_p_d - reg - log_q_d)
+
+    def log_marginal(self, index, response, mask, num_samples=100):
+        """Batch-level importance-weighted bound (models.py:174-207; the reference's own loop there omits `index` in its
+        forward call and cannot run -- this is the same estimator with the index passed)."""
+        with torch.no_grad():
+            log_w = []
+            for _ in range(int(num_samples)):
+                outs = self.forward(index, response, mask)
+                log_w.append(-self.elbo(*outs, annealing_factor=1, use_kl_divergence=False))
+            return torch.logsumexp(torch.stack(log_w), 0) - math.log(int(num_samples))
+
+
+class VI_2PL(VI_1PL):
+    IRT = 2
+
+
+class VI_3PL(VI_2PL):
+    IRT = 3
+
+
 def _normal_logpdf(x, mu, logvar):
     return -0.5 * LOG_2PI - 0.5 * logvar - 0.5 * (x - mu) ** 2 / logvar.exp()
 
