@@ -106,3 +106,29 @@ def test_cli_end_to_end_checkpoint_layout(cpu_ops, tmp_dirs, extra):
     times = np.load(tmp_dirs / 'out' / run_dir / 'train_times.npy')
     assert losses.shape == (4,) and np.isfinite(losses).all() and (times <= 0).all()
     assert losses[-1] < losses[0]                         # it learns
+
+
+@pytest.mark.parametrize('extra', [[], ['--artificial-missing-perc', '0.2', '--irt-model', '3pl', '--dataset', '3pl_simulation',
+                                        '--ability-dim', '2']])
+def test_vi_cli_end_to_end_checkpoint_layout(cpu_ops, tmp_dirs, extra):
+    """Drop-in for src/torch_core/vi.py (flags vi.py:20-78, out-dir name :87-96, checkpoint keys :318-368)."""
+    from vibo_amd.torch_core import vi
+    argv = ['--irt-model', '2pl', '--dataset', '2pl_simulation', '--num-person', '300', '--num-item', '12',
+            '--epochs', '5', '--batch-size', '16', '--num-posterior-samples', '3', '--lr', '0.02',
+            '--out-dir', str(tmp_dirs / 'out')] + extra
+    out_dir = vi.main(argv)
+    (run_dir,) = os.listdir(tmp_dirs / 'out')
+    irt = '3pl' if extra else '2pl'
+    assert run_dir == f'vi_{irt}_{irt}_simulation_300person_12item_{0.2 if extra else 0.0}maskperc_{2 if extra else 1}ability'
+    assert out_dir.endswith(run_dir)
+    files = set(os.listdir(tmp_dirs / 'out' / run_dir))
+    assert {'checkpoint.pth.tar', 'model_best.pth.tar', 'train_losses.npy', 'train_times.npy'} <= files
+    ck = torch.load(tmp_dirs / 'out' / run_dir / 'checkpoint.pth.tar', weights_only=False)
+    assert {'model_state_dict', 'epoch', 'args', 'train_logp', 'infer_dict', 'posterior_predict_samples'} <= set(ck)
+    assert set(ck['model_state_dict']) == {'ability_mu_lookup.weight', 'ability_logvar_lookup.weight', 'item_mu_lookup.weight',
+                                           'item_logvar_lookup.weight'}
+    assert ck['infer_dict']['ability_mu'].shape == (240, 2 if extra else 1)           # the train split: first 80 % of the persons
+    losses = np.load(tmp_dirs / 'out' / run_dir / 'train_losses.npy')
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    if extra:
+        assert 0.0 <= ck['missing_imputation_accuracy'] <= 1.0

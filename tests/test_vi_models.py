@@ -111,3 +111,19 @@ def test_module_matches_reference_on_the_gpu(vi_golden):
     a = model.elbo(*model(idx, resp, mask, **kw))
     b = model.elbo(*model(idx, codes, None, row_index=idx, **kw))
     assert rel_err(b.detach().cpu(), a.detach().cpu()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_vi_cli_on_the_gpu(tmp_path, monkeypatch):
+    from vibo_amd import config
+    from vibo_amd.torch_core import vi
+    monkeypatch.setattr(config, 'DATA_DIR', str(tmp_path / 'data'))
+    monkeypatch.setattr(config, 'OUT_DIR', str(tmp_path / 'out'))
+    out_dir = vi.main(['--irt-model', '2pl', '--dataset', '2pl_simulation', '--num-person', '800', '--num-item', '30',
+                       '--artificial-missing-perc', '0.2', '--epochs', '6', '--batch-size', '32', '--lr', '0.02',
+                       '--num-posterior-samples', '4', '--cuda', '--out-dir', str(tmp_path / 'out')])
+    losses = np.load(os.path.join(out_dir, 'train_losses.npy'))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    ck = torch.load(os.path.join(out_dir, 'checkpoint.pth.tar'), weights_only=False)
+    assert ck['infer_dict']['ability_mu'].shape == (640, 1) and 0.0 <= ck['missing_imputation_accuracy'] <= 1.0
+    assert np.isfinite(ck['train_logp'])
