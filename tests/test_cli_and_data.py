@@ -132,3 +132,25 @@ def test_vi_cli_end_to_end_checkpoint_layout(cpu_ops, tmp_dirs, extra):
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     if extra:
         assert 0.0 <= ck['missing_imputation_accuracy'] <= 1.0
+
+
+def test_posthoc_scripts_enrich_a_checkpoint(cpu_ops, tmp_dirs):
+    """infer.py / marginal.py / predictives.py drop-ins: rebuild everything from the checkpoint's own args and write the
+    result back into the file."""
+    from vibo_amd.torch_core import infer, marginal, predictives
+    cli.main(['--irt-model', '2pl', '--dataset', '2pl_simulation', '--num-person', '300', '--num-item', '12', '--epochs', '2',
+              '--batch-size', '16', '--num-posterior-samples', '3', '--artificial-missing-perc', '0.2', '--no-infer-dict',
+              '--no-marginal', '--no-test', '--out-dir', str(tmp_dirs / 'out')])
+    (run_dir,) = os.listdir(tmp_dirs / 'out')
+    path = str(tmp_dirs / 'out' / run_dir / 'checkpoint.pth.tar')
+    before = torch.load(path, weights_only=False)
+    assert 'infer_dict' not in before and 'train_logp' not in before
+    ck = infer.main([path])
+    assert ck['infer_dict']['ability_mu'].shape == (240, 1)
+    ck = marginal.main([path])
+    assert np.isfinite(ck['train_logp']) and np.isfinite(ck['test_logp'])
+    ck = predictives.main([path, '--num-posterior-samples', '5'])
+    assert ck['posterior_predict_samples']['response'].shape[1:3] == (240, 12) and 0.0 <= ck['missing_imputation_accuracy'] <= 1.0
+    after = torch.load(path, weights_only=False)
+    assert {'infer_dict', 'train_logp', 'test_logp', 'posterior_predict_samples', 'missing_imputation_accuracy'} <= set(after)
+    assert after['args'].num_posterior_samples == 5
