@@ -218,16 +218,17 @@ def test_row_counts_are_cached_per_resident_matrix():
     ops._BACKEND['counts'] = lambda *a: (calls.append(1), native(*a))[1]
     try:
         rows = torch.tensor([5, 7, 299], device=dev)
-        a = ops.row_counts(resp, mask, rows)
+        a = ops.row_counts(resp, mask, rows)               # first gathered minibatch of this matrix: those rows only
+        a2 = ops.row_counts(resp, mask, rows)              # the matrix came back: counted as a whole, once
         b = ops.row_counts(resp, mask)
         c = ops.row_counts(resp, mask, rows)
-        assert len(calls) == 1 and torch.equal(a, b[rows]) and torch.equal(a, c)
+        assert len(calls) == 2 and torch.equal(a, b[rows]) and torch.equal(a, c) and torch.equal(a, a2)
         mask[5, :] = False                                 # in-place change: counted again
         d_ = ops.row_counts(resp, mask, rows)
-        assert len(calls) == 2 and int(d_[0]) == 0 and torch.equal(d_[1:], a[1:])
+        assert len(calls) == 3 and int(d_[0]) == 0 and torch.equal(d_[1:], a[1:])
         codes = ops.pack_cell_codes(resp, mask)
         e = ops.row_counts(codes, None)
         f = ops.row_counts(codes, None, rows)
-        assert len(calls) == 3 and torch.equal(e[rows], f) and torch.equal(e, ops.row_counts(resp, mask))
+        assert len(calls) == 4 and torch.equal(e[rows], f) and torch.equal(e, ops.row_counts(resp, mask))
     finally:
         ops._BACKEND['counts'] = native

@@ -347,6 +347,7 @@ def _hip_row_counts(response, mask, mask_code, row_index):
 
 
 _COUNTS_CACHE = []         # [(weakref response, version, weakref mask | None, version, counts)], newest last, at most 4
+_COUNTS_SEEN = []          # [weakref to the last response tensor a gathered minibatch came from]
 
 
 def row_counts(response, mask, row_index=None):
@@ -361,6 +362,11 @@ def row_counts(response, mask, row_index=None):
                 (mr is None and key_m is None) or (mr is not None and mr() is key_m and mv == key_m._version)):
             return cnt if row_index is None else cnt[row_index]
     response, mask, code = prepare_rows(response, mask, keep_int64=True)
+    if row_index is not None and not (_COUNTS_SEEN and _COUNTS_SEEN[0]() is key_r):
+        # a gathered minibatch of a matrix seen for the first time: count those rows only; the whole matrix is counted
+        # (once) when the same tensor comes back
+        _COUNTS_SEEN[:] = [weakref.ref(key_r)]
+        return _BACKEND['counts'](response, mask, code, row_index)
     cnt = _BACKEND['counts'](response, mask, code, None)
     _COUNTS_CACHE[:] = [e for e in _COUNTS_CACHE if e[0]() is not None and (e[2] is None or e[2]() is not None)][-3:]
     _COUNTS_CACHE.append((weakref.ref(key_r), key_r._version, weakref.ref(key_m) if key_m is not None else None,
