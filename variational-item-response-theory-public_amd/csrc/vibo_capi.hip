@@ -419,6 +419,31 @@ __global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict
     }
 }
 
+// the same for 4-cell chunks of aligned rows (thread = one chunk: float4 + mask word in, one code word out)
+__global__ __launch_bounds__(256) void pack_codes4_kernel(const float* __restrict__ response, const void* __restrict__ mask,
+                                                          uint32_t* __restrict__ codes, long long resp_stride, long long mask_stride,
+                                                          long long chunks_per_row, long long B, int I, int mask_dtype) {
+    const long long n = B * chunks_per_row;
+    const int n4 = (I + 3) >> 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long row = e / chunks_per_row;
+        const int c = (int)(e - row * chunks_per_row);
+        uint32_t w = kAllMissing4;
+        if (c < n4) {
+            const float4 x = reinterpret_cast<const float4*>(response + row * resp_stride)[c];
+            uint32_t m = mask_dtype == VIBO_MASK_U8
+                             ? reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(mask) + row * mask_stride)[c]
+                             : 0x01010101u;
+            m = ((m | (m >> 1) | (m >> 2) | (m >> 3) | (m >> 4) | (m >> 5) | (m >> 6) | (m >> 7)) & 0x01010101u);   // any bit -> 1
+            if ((I & 3) && c == (I >> 2)) m &= (1u << (8 * (I & 3))) - 1u;
+            const uint32_t one = (x.x == 1.0f ? 1u : 0u) | (x.y == 1.0f ? 1u << 8 : 0u) | (x.z == 1.0f ? 1u << 16 : 0u) |
+                                 (x.w == 1.0f ? 1u << 24 : 0u);
+            w = (one & m) | ((m ^ 0x01010101u) << 1);          // observed: 0 / 1; not observed (or padding): 2
+        }
+        codes[e] = w;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // finalize: fixed-order sum of the per-block partial records (fp64 accumulate)
 // ---------------------------------------------------------------------------
@@ -1099,6 +1124,20 @@ int vibo_row_counts(const vibo_desc* d, const float* response, const void* mask,
 
 int vibo_pack_codes(const vibo_desc* d, const float* response, const void* mask, uint8_t* codes, int64_t codes_row_stride,
                     void* stream) {
+    // fast path: aligned rows, 4 cells per thread (16 B of responses + 4 B of mask -> one code word)
+    if (check_desc(d) == 0 && response && codes && d->mask_dtype != VIBO_MASK_CODES && d->mask_dtype != VIBO_MASK_I64 &&
+        (d->mask_dtype == VIBO_MASK_NONE) == (mask == nullptr) && codes_row_stride % 4 == 0 &&
+        codes_row_stride >= ((d->num_item + 3) & ~3) && (((uintptr_t)codes & 3) == 0) && rows_vec_ok(d, response, mask)) {
+        const long long n = (long long)d->num_person * (codes_row_stride / 4);
+        long long grid = (n + 255) / 256;
+        if (grid > 262144) grid = 262144;
+        hipLaunchKernelGGL(pack_codes4_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, response, mask,
+                           reinterpret_cast<uint32_t*>(codes), (long long)d->response_row_stride, (long long)d->mask_row_stride,
+                           (long long)(codes_row_stride / 4), (long long)d->num_person, d->num_item, d->mask_dtype);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "pack_codes launch");
+        return 0;
+    }
     int rc = check_desc(d);
     if (rc) return rc;
     if (d->mask_dtype == VIBO_MASK_CODES) return fail(-3, "vibo_pack_codes: the source rows are already cell codes");
