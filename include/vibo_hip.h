@@ -240,13 +240,23 @@ int vibo_decode_mean(const vibo_desc* d, int num_samples, const float* ability, 
  *  mlp_params / adam_m / adam_v: one flat fp32 buffer each laid out  W0[H] | b0[H] | W1[H][H] | b1[H] | W2[2A][H] | b2[2A]
  *  item_mu, item_logvar, item_m/v (mu then logvar): [I][D] each
  *  beta, lr: device scalars (fp32) so that an annealing schedule stays hipGraph-capturable
- *  step_count: device int32, incremented by the prologue
+ *  step_count: device int32[2].  [0] = Adam's step number t, incremented by the prologue and read by the epilogue;
+ *              [1] = number of COMPLETED steps, incremented by the epilogue: the step component of the noise counters
+ *              (vibo_train_prologue_noise below, or vibo_fill_normal called with step_count + 1)
+ * vibo_train_prologue_noise = vibo_train_prologue that draws its own reparameterisation noise in the same launch:
+ *     eps_item [I][D]  <- stream 0, eps_ability [B][A] <- stream `ability_stream_id`, both exactly the values
+ *     vibo_fill_normal(out, n, seed, step_count + 1, stream_id) produces (torch.randn_like in models.py:506-510);
+ *     two launches fewer per step, which is a quarter of a step at the reference's default batch size of 16.
  *  kl_parts: workspace of at least ceil(I*D/256) floats;  hidden_dim H <= 256
  */
 int vibo_train_prologue(const vibo_desc* d, int hidden_dim, const float* mlp_params, const float* item_mu,
                         const float* item_logvar, const float* eps_item, float* item_feat, float* table,
                         float* saved_h, float* kl_parts, int32_t* step_count, void* stream);
 
+int vibo_train_prologue_noise(const vibo_desc* d, int hidden_dim, const float* mlp_params, const float* item_mu,
+                              const float* item_logvar, float* eps_item, float* item_feat, float* table,
+                              float* saved_h, float* kl_parts, int32_t* step_count, uint64_t seed, float* eps_ability,
+                              uint32_t ability_stream_id, void* stream);
 int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, const float* saved_h,
                         const float* kl_parts, const float* eps_item, const float* beta, const float* lr,
                         const int32_t* step_count, float* mlp_params, float* mlp_m, float* mlp_v,

@@ -86,7 +86,7 @@ def test_fused_trainer_native_rng_trains():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('extra', [[], ['--no-graph'], ['--artificial-missing-perc', '0.2', '--conditional-posterior'],
+@pytest.mark.parametrize('extra', [[], ['--no-graph'], ['--rng', 'native'], ['--artificial-missing-perc', '0.2', '--conditional-posterior'],
                                    ['--n-norm-flows', '2', '--irt-model', '3pl', '--dataset', '3pl_simulation'],
                                    ['--num-item', '95', '--ability-dim', '3']])
 def test_cli_end_to_end_on_the_gpu(tmp_path, monkeypatch, extra):
@@ -109,3 +109,38 @@ def test_cli_end_to_end_on_the_gpu(tmp_path, monkeypatch, extra):
     assert losses.shape == (4,) and np.isfinite(losses).all() and losses[-1] < losses[0]
     if '--artificial-missing-perc' in extra:
         assert 0.0 <= ck['missing_imputation_accuracy'] <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('A,I,B', [(1, 100, 16), (8, 1000, 4099), (3, 95, 77)])
+def test_noise_drawn_in_the_prologue_equals_separate_fills(A, I, B):
+    """vibo_train_prologue_noise draws exactly the streams vibo_fill_normal gives (item: stream 0, ability: stream
+    1 + rank, step = completed steps): the two trainers stay bitwise identical, eagerly and replayed from a hipGraph."""
+    import copy
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(A + I)
+    resp, mask = O.simulate_responses(2, B, I, A, generator=g, missing_frac=0.1)
+    from vibo_amd import ops
+    resp, mask = ops.pad_rows(resp.to(dev), mask.bool().to(dev))
+    torch.manual_seed(5)
+    m1 = VIBO_2PL(A, I, ability_merge='product').to(dev)
+    m2 = copy.deepcopy(m1)
+    t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=11, fused_noise=True)
+    t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=11, fused_noise=False)
+    for step in range(3):
+        l1, l2 = t1.step(resp, mask), t2.step(resp, mask)
+        assert torch.equal(l1, l2), step
+        assert torch.equal(t1._eps_item, t2._eps_item) and torch.equal(t1._eps_ab, t2._eps_ab)
+    assert int(t1.step_count) == 3 and t1._steps.tolist() == [3, 3]
+    first = t1._eps_ab.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lg = t1.step(resp, mask)                 # capture only: nothing runs
+    for step in range(3):
+        graph.replay()
+        l2 = t2.step(resp, mask)
+        assert torch.equal(lg, l2), step
+    assert not torch.equal(first, t1._eps_ab)    # fresh noise on every replay (the step counters live on the device)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -21,11 +21,55 @@ __host__ __device__ inline MlpOffsets mlp_offsets(int H, int O) {
 
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
 
+// ---------------------------------------------------------------------------
+// N(0,1) fill: Philox4x32-10 (Salmon et al. 2011) + Box-Muller, 4 normals per counter
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t k0, const uint32_t k1) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+}
+
+// the 4 normals of counter group g (outputs 4g .. 4g+3 of the stream)
+__device__ __forceinline__ float4 philox_normal4(const long long g, const uint32_t step, const uint32_t stream_id, const uint32_t seed_lo,
+                                                 const uint32_t seed_hi) {
+    uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), step, stream_id};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    // uniforms in (0, 1]; v_sin / v_cos take their argument in revolutions
+    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * kLn2 * fast_log2(u0)), r1 = sqrtf(-2.0f * kLn2 * fast_log2(u2));
+    return float4{r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
+                  r1 * __builtin_amdgcn_sinf(u3)};
+}
+__device__ __forceinline__ void store_normal4(float* __restrict__ out, const long long n, const long long g, const float4 z) {
+    if (4 * g + 3 < n && (((uintptr_t)out & 15) == 0)) {
+        reinterpret_cast<float4*>(out)[g] = z;
+    } else {
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+        for (int k = 0; k < 4; ++k)
+            if (4 * g + k < n) out[4 * g + k] = zz[k];
+    }
+}
+
+
 __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n_item_entries, const float* __restrict__ P,
                                                              const float* __restrict__ mu, const float* __restrict__ lv,
                                                              const float* __restrict__ eps, float* __restrict__ item_feat,
                                                              float* __restrict__ table, float* __restrict__ saved_h,
-                                                             float* __restrict__ kl_parts, int32_t* step_count) {
+                                                             float* __restrict__ kl_parts, int32_t* step_count,
+                                                             // noise (gen != 0): eps is written here instead of read, and the
+                                                             // blocks past the item blocks fill eps_ab [n_ab]; both draws are
+                                                             // the streams vibo_fill_normal gives for step_count[1]
+                                                             int gen, uint32_t seed_lo, uint32_t seed_hi, float* __restrict__ eps_w,
+                                                             float* __restrict__ eps_ab, long long n_ab, uint32_t ab_stream,
+                                                             int n_item_blocks) {
     __shared__ float h1[2][kMaxHidden], h2[2][kMaxHidden];
     __shared__ float red[4];
     const int tid = threadIdx.x;
@@ -58,12 +102,25 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
         }
         return;
     }
+    if ((int)blockIdx.x > n_item_blocks) {          // ability noise (stream ab_stream), 4 normals per thread
+        const long long g = (long long)(blockIdx.x - 1 - n_item_blocks) * 256 + tid;
+        if (4 * g < n_ab) store_normal4(eps_ab, n_ab, g, philox_normal4(g, (uint32_t)step_count[1], ab_stream, seed_lo, seed_hi));
+        return;
+    }
     // item side: 256 entries of [I][D] per workgroup
     const int idx = (blockIdx.x - 1) * 256 + tid;
     float kl = 0.f;
     if (idx < n_item_entries) {
         const float m = mu[idx], l = lv[idx];
-        item_feat[idx] = fmaf(expf(0.5f * l), eps[idx], m);
+        float e;
+        if (gen) {                                   // entry idx of stream 0 (its group of 4 is recomputed by 4 threads: O(I) work)
+            const float4 z = philox_normal4(idx >> 2, (uint32_t)step_count[1], 0u, seed_lo, seed_hi);
+            e = (idx & 3) == 0 ? z.x : (idx & 3) == 1 ? z.y : (idx & 3) == 2 ? z.z : z.w;
+            eps_w[idx] = e;
+        } else {
+            e = eps[idx];
+        }
+        item_feat[idx] = fmaf(expf(0.5f * l), e, m);
         kl = -0.5f * (1.0f + l - m * m - expf(l));
     }
     kl = wave_total(kl);
@@ -93,6 +150,7 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
     const float bc1 = 1.0f - powf(0.9f, t), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t));
     const int n_table = 2 * O;
     if (blockIdx.x == 0) {
+        if (tid == 0) const_cast<int32_t*>(step_count)[1] += 1;      // completed steps: the noise counter of the NEXT step
         const MlpOffsets o = mlp_offsets(H, O);
         for (int k = tid; k < 2 * H; k += 256) {
             h1[k / H][k % H] = saved_h[k];
@@ -183,40 +241,11 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
     }
 }
 
-// ---------------------------------------------------------------------------
-// N(0,1) fill: Philox4x32-10 (Salmon et al. 2011) + Box-Muller, 4 normals per counter
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t k0, const uint32_t k1) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
-}
-
 __global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ out, long long n, uint32_t seed_lo, uint32_t seed_hi,
                                                           const int32_t* __restrict__ step_count, uint32_t stream_id) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;        // group of 4 outputs
     if (4 * g >= n) return;
-    uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(*step_count), stream_id};
-    uint32_t k0 = seed_lo, k1 = seed_hi;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    // uniforms in (0, 1]; v_sin / v_cos take their argument in revolutions
-    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
-    const float r0 = sqrtf(-2.0f * kLn2 * fast_log2(u0)), r1 = sqrtf(-2.0f * kLn2 * fast_log2(u2));
-    const float4 z = float4{r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
-                            r1 * __builtin_amdgcn_sinf(u3)};
-    if (4 * g + 3 < n && (((uintptr_t)out & 15) == 0)) {
-        reinterpret_cast<float4*>(out)[g] = z;
-    } else {
-        const float zz[4] = {z.x, z.y, z.z, z.w};
-        for (int k = 0; k < 4; ++k)
-            if (4 * g + k < n) out[4 * g + k] = zz[k];
-    }
+    store_normal4(out, n, g, philox_normal4(g, (uint32_t)(*step_count), stream_id, seed_lo, seed_hi));
 }
 
 }  // namespace vibo
@@ -241,7 +270,25 @@ extern "C" int vibo_train_prologue(const vibo_desc* d, int hidden_dim, const flo
     const int n = d->num_item * item_dim_of(d);
     const int blocks = 1 + (n + 255) / 256;
     hipLaunchKernelGGL(train_prologue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hidden_dim, 2 * d->ability_dim, n,
-                       mlp_params, item_mu, item_logvar, eps_item, item_feat, table, saved_h, kl_parts, step_count);
+                       mlp_params, item_mu, item_logvar, eps_item, item_feat, table, saved_h, kl_parts, step_count, 0, 0u, 0u,
+                       (float*)nullptr, (float*)nullptr, 0LL, 0u, (n + 255) / 256);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vibo_train_prologue_noise(const vibo_desc* d, int hidden_dim, const float* mlp_params, const float* item_mu,
+                                         const float* item_logvar, float* eps_item, float* item_feat, float* table,
+                                         float* saved_h, float* kl_parts, int32_t* step_count, uint64_t seed, float* eps_ability,
+                                         uint32_t ability_stream_id, void* stream) {
+    if (!d || hidden_dim < 1 || hidden_dim > kMaxHidden || d->posterior != VIBO_POSTERIOR_UNCONDITIONAL || d->n_flows != 0) return -6;
+    if (!eps_item || !eps_ability || !step_count) return -5;
+    const int n = d->num_item * item_dim_of(d);
+    const int item_blocks = (n + 255) / 256;
+    const long long n_ab = (long long)d->num_person * d->ability_dim;
+    const long long ab_blocks = ((n_ab + 3) / 4 + 255) / 256;
+    hipLaunchKernelGGL(train_prologue_kernel, dim3((unsigned)(1 + item_blocks + ab_blocks)), dim3(256), 0, (hipStream_t)stream,
+                       hidden_dim, 2 * d->ability_dim, n, mlp_params, item_mu, item_logvar, (const float*)eps_item, item_feat, table,
+                       saved_h, kl_parts, step_count, 1, (uint32_t)seed, (uint32_t)(seed >> 32), eps_item, eps_ability, n_ab,
+                       ability_stream_id, item_blocks);
     return (int)hipGetLastError();
 }
 

@@ -46,7 +46,7 @@ class ViboDesc(ctypes.Structure):
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
-                    'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward')
+                    'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise')
 
 _lib = None
 
@@ -85,6 +85,8 @@ def load():
     lib.vibo_decode.argtypes = [dp, fp, fp, fp, vp]
     lib.vibo_train_prologue.restype = ctypes.c_int
     lib.vibo_train_prologue.argtypes = [dp, ctypes.c_int] + [fp] * 8 + [vp, vp]
+    lib.vibo_train_prologue_noise.restype = ctypes.c_int
+    lib.vibo_train_prologue_noise.argtypes = [dp, ctypes.c_int] + [fp] * 8 + [vp, ctypes.c_uint64, fp, ctypes.c_uint32, vp]
     lib.vibo_train_epilogue.restype = ctypes.c_int
     lib.vibo_train_epilogue.argtypes = [dp, ctypes.c_int] + [fp] * 6 + [vp] + [fp] * 8 + [vp]
     lib.vibo_fill_normal.restype = ctypes.c_int

@@ -75,6 +75,9 @@ def build_parser():
                         "one byte per cell (same results, a fifth of the memory and HBM traffic); 'auto' = codes "
                         "whenever the fused kernels support them (--cuda, 4..32767 items, ability dim <= 4 with "
                         "--conditional-posterior)")
+    p.add_argument('--rng', choices=['torch', 'native'], default='torch',
+                   help="reparameterisation noise of the fused trainer: torch.randn (the stream torch.manual_seed(--seed) governs) or "
+                        "the library's Philox generator drawn inside the prologue kernel (two launches fewer per step)")
     p.add_argument('--no-graph', action='store_true', default=False,
                    help='launch every fused train step eagerly instead of replaying a hipGraph (single-GPU runs)')
     p.add_argument('--store-predictive-samples', action='store_true', default=False,
@@ -356,7 +359,7 @@ def main(argv=None):
     if (args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and args.ability_merge == 'product'
             and not args.torch_optimizer):
         from ..trainer import FusedTrainer
-        trainer = FusedTrainer(model, lr=args.lr)       # same Adam arithmetic, ~7 launches per step
+        trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)       # same Adam arithmetic, 5-7 launches per step
     graphed = None
     if trainer is not None and world == 1 and not args.no_graph:
         graphed = GraphedTrainStep(trainer, train, local_bs)      # (multi-GPU: eager steps around the all-reduce)

@@ -18,7 +18,7 @@ from . import _lib, ops
 
 
 class FusedTrainer:
-    def __init__(self, model, lr=5e-3, rng='torch', seed=0):
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True):
         if model.conditional_posterior or model.n_norm_flows > 0 or model.ability_merge != 'product':
             raise NotImplementedError('FusedTrainer covers the unconditional product-of-experts posterior without flows; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
@@ -44,7 +44,7 @@ class FusedTrainer:
         n_item = self.item_mu.numel()
         self.item_m = torch.zeros(2 * n_item, device=dev)
         self.item_v = torch.zeros(2 * n_item, device=dev)
-        self.step_count = torch.zeros((), dtype=torch.int32, device=dev)
+        self._steps = torch.zeros(2, dtype=torch.int32, device=dev)      # [Adam step t, completed steps (noise counter)]
         self.lr = torch.tensor(float(lr), device=dev)
         self.beta = torch.tensor(1.0, device=dev)
         self._beta_host = 1.0
@@ -62,6 +62,7 @@ class FusedTrainer:
         if rng not in ('torch', 'native'):
             raise ValueError("rng must be 'torch' or 'native'")
         self.rng, self.seed = rng, int(seed)
+        self.fused_noise = bool(fused_noise)      # rng='native': draw the noise inside the prologue launch (2 launches fewer)
         self._eps_item = torch.empty_like(self.item_mu) if rng == 'native' else None
         self._eps_ab = None
 
@@ -95,27 +96,40 @@ class FusedTrainer:
         d = ops._make_desc(spec, B, I, code, _lib.REG_KL, True, response.stride(0), mask.stride(0) if mask is not None else 0)
         p = ops._ptr
         # reference draw order: item eps, then ability eps (models.py:361,368)
+        ab_stream = 1 + getattr(model, '_shard_rank', 0)      # item noise: the same on every rank; ability noise: per rank
         if self.rng == 'native':
             eps_item = self._eps_item
-            _lib.check(lib.vibo_fill_normal(p(eps_item), eps_item.numel(), self.seed, p(self.step_count), 0, stream), 'vibo_fill_normal')
-        else:
-            eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
-        rc = lib.vibo_train_prologue(ctypes.byref(d), self.hidden, p(self.mlp_flat), p(self.item_mu), p(self.item_lv),
-                                     p(eps_item), p(self.item_feat), p(self.table), p(self.saved_h), p(self.kl_parts),
-                                     p(self.step_count), stream)
-        _lib.check(rc, 'vibo_train_prologue')
-        if self.rng == 'native':
             if self._eps_ab is None or self._eps_ab.shape[0] != B:
                 self._eps_ab = torch.empty(B, model.ability_dim, device=dev)
             eps_ab = self._eps_ab
-            _lib.check(lib.vibo_fill_normal(p(eps_ab), eps_ab.numel(), self.seed, p(self.step_count), 1 + getattr(model, '_shard_rank', 0), stream), 'vibo_fill_normal')
         else:
-            eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
+            eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
+        if self.rng == 'native' and self.fused_noise:       # noise drawn inside the prologue launch
+            rc = lib.vibo_train_prologue_noise(ctypes.byref(d), self.hidden, p(self.mlp_flat), p(self.item_mu), p(self.item_lv),
+                                               p(eps_item), p(self.item_feat), p(self.table), p(self.saved_h), p(self.kl_parts),
+                                               p(self._steps), self.seed, p(eps_ab), ab_stream, stream)
+            _lib.check(rc, 'vibo_train_prologue_noise')
+        else:
+            noise_step = ctypes.c_void_p(self._steps.data_ptr() + 4)          # completed steps (step_count[1])
+            if self.rng == 'native':
+                _lib.check(lib.vibo_fill_normal(p(eps_item), eps_item.numel(), self.seed, noise_step, 0, stream), 'vibo_fill_normal')
+                _lib.check(lib.vibo_fill_normal(p(eps_ab), eps_ab.numel(), self.seed, noise_step, ab_stream, stream), 'vibo_fill_normal')
+            rc = lib.vibo_train_prologue(ctypes.byref(d), self.hidden, p(self.mlp_flat), p(self.item_mu), p(self.item_lv),
+                                         p(eps_item), p(self.item_feat), p(self.table), p(self.saved_h), p(self.kl_parts),
+                                         p(self._steps), stream)
+            _lib.check(rc, 'vibo_train_prologue')
+            if self.rng != 'native':
+                eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
         raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None,
                                    _lib.REG_KL, True, B)
         self._pending = (d, eps_item, raw)
         self.last = raw
         return raw
+
+    @property
+    def step_count(self):
+        """Adam's step number (device int32 scalar)."""
+        return self._steps[0]
 
     @torch.no_grad()
     def update(self):
@@ -124,7 +138,7 @@ class FusedTrainer:
         lib, p = _lib.load(), ops._ptr
         stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
         rc = lib.vibo_train_epilogue(ctypes.byref(d), self.hidden, p(raw.flat), p(self.saved_h), p(self.kl_parts),
-                                     p(eps_item), p(self.beta), p(self.lr), p(self.step_count), p(self.mlp_flat),
+                                     p(eps_item), p(self.beta), p(self.lr), p(self._steps), p(self.mlp_flat),
                                      p(self.mlp_m), p(self.mlp_v), p(self.item_mu), p(self.item_lv), p(self.item_m),
                                      p(self.item_v), p(self.loss), stream)
         _lib.check(rc, 'vibo_train_epilogue')
