@@ -350,7 +350,7 @@ def main():
                                    f'unconditional posterior, full-shard minibatch',
                        'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': ('hipGraph replay' if (dist is None or args.graph_collective) else 'two hipGraphs around an eager RCCL all-reduce') if m['graph'] else 'eager',
                        'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',
-                       'noise': 'torch.randn' if (args.torch_optimizer or args.eval_only or args.rng == 'torch') else 'vibo_fill_normal (Philox4x32-10)',
+                       'noise': 'torch.randn' if (args.torch_optimizer or args.eval_only or args.rng == 'torch') else 'Philox4x32-10 drawn in the prologue kernel (vibo_train_prologue_noise = the vibo_fill_normal streams)',
                        'final_loss_per_term': final_loss / (P * I * world)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
