@@ -467,14 +467,22 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeParams f) 
             src = e;   // same offsets in the partial record (off_table = 8, off_flow = 8 + 8A)
         } else {
             const int k = e - (8 + n_tab + n_flow);
-            const int i = k / f.D, dd = k % f.D;
+            const int dd = k / f.I, i = k % f.I;          // consecutive lanes = consecutive items: coalesced record reads
             const int panel = i / f.panel_items;          // panel mode: only this panel's blocks hold item i
             src = f.lay.off_item + dd * f.lay.i_pad + (i - panel * f.panel_items);
             b0 = panel * f.bpp;
             b1 = b0 + f.bpp;
         }
         // fixed order: slice s sums blocks s, s+SLICES, ... in fp64, then the slices are summed in order
-        for (int b = b0 + slice; b < b1; b += SLICES) acc += (double)f.partial[(size_t)b * f.lay.stride + src];
+        // (four independent chains keep four record loads in flight)
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = b0 + slice;
+        for (; b + 3 * SLICES < b1; b += 4 * SLICES) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += (double)f.partial[(size_t)(b + u * SLICES) * f.lay.stride + src];
+        }
+        for (int u = 0; b < b1; b += SLICES, ++u) a4[u] += (double)f.partial[(size_t)b * f.lay.stride + src];
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     part[slice][lane] = acc;
     __syncthreads();
@@ -490,7 +498,8 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeParams f) 
         } else if (e < 8 + n_tab + n_flow) {
             f.grad_flow[e - 8 - n_tab] = (float)t;
         } else {
-            f.grad_item[e - 8 - n_tab - n_flow] = (float)t;
+            const int k = e - 8 - n_tab - n_flow;
+            f.grad_item[(size_t)(k % f.I) * f.D + k / f.I] = (float)t;
         }
     }
     if (blockIdx.x == 0) {
