@@ -907,7 +907,8 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
     f.panel_items = panel_items; f.bpp = bpp ? bpp : nblk_used;
     const int n_out = 8 + (grad ? 8 * A + 2 * d->n_flows * (2 * A + 1) + I * pl.D : 0);
-    if (f.bpp >= 1024) hipLaunchKernelGGL(finalize_kernel<16>, dim3((n_out + 15) / 16), dim3(1024), 0, s, f);
+    if (f.bpp >= 1024 || n_out <= 64)      // many small records, or the 8 scalars of a forward-only call: more slices per output
+        hipLaunchKernelGGL(finalize_kernel<16>, dim3((n_out + 15) / 16), dim3(1024), 0, s, f);
     else hipLaunchKernelGGL(finalize_kernel<64>, dim3((n_out + 63) / 64), dim3(1024), 0, s, f);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "finalize launch");
