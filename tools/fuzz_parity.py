@@ -273,7 +273,9 @@ while time.time() - t0 < a.seconds:
     D = O.item_feat_dim(irt, A)
     table = torch.randn((2, I, 2 * A) if cond else (2, 2 * A), generator=g) * 0.7
     if given:                      # (mu | logvar) per person
-        table = torch.cat([torch.randn(B, A, generator=g) * 0.8, torch.randn(B, A, generator=g) * 0.6 - 1.5], dim=1)
+        # (3PL: narrower, so that flows on wide samples do not push logits into the probability-clamp band, see above)
+        table = torch.cat([torch.randn(B, A, generator=g) * (0.3 if irt == 3 else 0.8),
+                           torch.randn(B, A, generator=g) * 0.6 - (3.0 if irt == 3 else 1.5)], dim=1)
     item = torch.randn(I, D, generator=g) * scale
     eps = torch.randn(B, A, generator=g)
     flow = None
@@ -323,7 +325,7 @@ while time.time() - t0 < a.seconds:
     worst = max(worst, max(errs.values()))
     n += 1
     if a.replay:
-        print('replayed:', errs)
+        print('replayed:', errs, '| max |logit| of the case:', float(ref['logit'].abs().max()))
         sys.exit(1 if bad else 0)
     if bad:
         print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only} codes={codes} given={given}: {bad}')
