@@ -241,6 +241,46 @@ def run_vi_case(ref_models, case, out_dir):
     return float(loss.detach())
 
 
+MLE_CASES = [
+    # name, irt, A, B, P, I, missing   (maximum-likelihood point estimates: models.py:22-97, loss of mle.py:192-197)
+    ('mle_2pl_a2', 2, 2, 16, 40, 20, 0.0),
+    ('mle_3pl_a1_miss', 3, 1, 37, 60, 95, 0.2),
+    ('mle_1pl_a3_miss', 1, 3, 16, 16, 130, 0.2),
+]
+
+
+def run_mle_case(ref_models, case, out_dir):
+    import torch.nn.functional as F
+    name, irt, A, B, P, I, missing = case
+    seed = 3000 + sum(ord(c) for c in name)
+    resp, mask = make_data(irt, B, I, A, missing, seed)
+    g = torch.Generator().manual_seed(seed)
+    index = torch.randperm(P, generator=g)[:B]
+    cls = {1: ref_models.MLE_1PL, 2: ref_models.MLE_2PL, 3: ref_models.MLE_3PL}[irt]
+    torch.manual_seed(seed)
+    model = cls(A, P, I)
+    with torch.no_grad():                       # a regime without saturated logits (see run_vi_case)
+        model.ability.weight.mul_(0.5)
+        model.item_feat.weight.mul_(0.6)
+    r3, m3 = resp.unsqueeze(2), mask.long().unsqueeze(2)
+    response_mu = model(index, r3, m3)
+    # mle.py:194-196 with the missing cells' target (-1 in the loaders) set to 0: those terms are multiplied by mask = 0
+    loss = (F.binary_cross_entropy(response_mu, r3.clamp(min=0).float(), reduction='none') * m3).mean()
+    loss.backward()
+    rec = {
+        'meta': json.dumps(dict(name=name, irt_model=irt, ability_dim=A, num_person=P, batch=B, num_item=I, missing_frac=missing,
+                                torch=torch.__version__)),
+        'response': resp.numpy().astype(np.int8), 'mask': mask.numpy().astype(np.uint8), 'index': index.numpy(),
+        'out.loss': loss.detach().numpy(), 'out.response_mu': response_mu.detach().squeeze(2).numpy(),
+    }
+    for k, v in model.state_dict().items():
+        rec['sd.' + k] = v.detach().numpy().copy()
+    for k, p in model.named_parameters():
+        rec['grad.' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, f'{name}.npz'), **rec)
+    return float(loss.detach())
+
+
 def saturation_case(ref_utils, out_dir):
     """masked_bernoulli_log_pdf(sigmoid(l)) and its gradient for l in [-30, 30]
     plus dense sweeps around the clamp thresholds (utils.py:46-49)."""
@@ -327,6 +367,10 @@ def main():
         if args.only and args.only not in case[0]:
             continue
         print(f'{case[0]:34s} loss={run_vi_case(ref_models, case, out_dir):.6f}')
+    for case in MLE_CASES:
+        if args.only and args.only not in case[0]:
+            continue
+        print(f'{case[0]:34s} loss={run_mle_case(ref_models, case, out_dir):.6f}')
     if not args.only:
         saturation_case(ref_utils, out_dir)
         log_marginal_case(ref_models, out_dir)

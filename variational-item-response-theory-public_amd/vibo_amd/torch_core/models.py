@@ -593,6 +593,75 @@ class VI_3PL(VI_2PL):
     IRT = 3
 
 
+# ---------------------------------------------------------------------------
+# maximum-likelihood point estimates (reference models.py:22-97; training script mle.py)
+# ---------------------------------------------------------------------------
+
+class MLE_1PL(nn.Module):
+    """Drop-in for the reference's MLE_1PL/2PL/3PL (keys ability.weight [P,A], item_feat.weight [I,D]).
+
+    forward(index, response, mask) returns the materialised response_mu [B,I,1] with autograd, as the reference's
+    training loop needs it (mle.py:193-197 computes the masked BCE itself) -- that is an O(B I) PyTorch tensor by
+    contract.  `nll_step` is the same loss (mean over ALL B x I cells of mask x BCE) through the fused kernel: the persons'
+    rows are a caller-supplied posterior with zero noise, so the sample is the point estimate and the kernel's d LL/d mu,
+    d LL/d item are the gradients; one pass over the response rows, nothing of size B x I is stored."""
+    IRT = 1
+
+    def __init__(self, latent_dim, num_person, num_item):
+        super().__init__()
+        self.latent_dim = self.ability_dim = latent_dim
+        self.response_dim = 1
+        self.num_person, self.num_item = num_person, num_item
+        self.item_feat_dim = item_feat_dim(self.IRT, latent_dim)
+        self.spec = ElboSpec(irt_model=self.IRT, ability_dim=latent_dim, given=True)
+        self.spec.check_supported(num_item)
+        self.ability = nn.Embedding(num_person, latent_dim)                 # models.py:41-42, N(0,1) init
+        self.item_feat = nn.Embedding(num_item, self.item_feat_dim)
+
+    def encode(self, index, response=None, mask=None):
+        return self.ability(index.reshape(-1).long()), self.item_feat.weight       # models.py:49-53
+
+    def decode(self, ability, item_feat):
+        return decode_probs(self.spec, ability, item_feat).unsqueeze(2)
+
+    def forward(self, index, response=None, mask=None):
+        ability, item = self.encode(index)
+        A = self.ability_dim
+        if self.IRT == 1:                                                       # models.py:729-735
+            logit = ability.sum(1, keepdim=True) + item[:, 0].unsqueeze(0)
+        else:                                                                    # models.py:738-766
+            logit = -(ability @ item[:, :A].t()) + item[:, A].unsqueeze(0)
+        p = torch.sigmoid(logit)
+        if self.IRT == 3:
+            guess = torch.sigmoid(item[:, A + 1]).unsqueeze(0)
+            p = guess + (1.0 - guess) * p
+        return p.unsqueeze(2)
+
+    def nll_step(self, index, response, mask, row_index=None):
+        """mean_{B x I}(mask * BCE(response_mu, response)) (mle.py:193-196) without materialising response_mu."""
+        ability, item = self.encode(index)
+        B = ability.shape[0]
+        if not isinstance(response, ops.CellCodes):
+            response = ops.prepare_response(response)
+            if response.shape[1] % 4 != 0 and response.stride(0) < (response.shape[1] + 3) // 4 * 4:
+                m2 = ops.prepare_mask(mask)[0]
+                if row_index is not None:
+                    response, m2, row_index = response[row_index], (m2[row_index] if m2 is not None else None), None
+                response, mask = ops.pad_rows(response, m2)
+        table = torch.cat([ability, torch.zeros_like(ability)], dim=1)          # (mu | logvar = 0), eps = 0: theta = mu
+        heads = fused_elbo(self.spec, table, item, None, response, mask, torch.zeros_like(ability), reg_mode=_lib.REG_KL,
+                           row_index=row_index)
+        return -heads[0] / float(B * self.num_item)
+
+
+class MLE_2PL(MLE_1PL):
+    IRT = 2
+
+
+class MLE_3PL(MLE_2PL):
+    IRT = 3
+
+
 def _normal_logpdf(x, mu, logvar):
     return -0.5 * LOG_2PI - 0.5 * logvar - 0.5 * (x - mu) ** 2 / logvar.exp()
 
