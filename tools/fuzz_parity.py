@@ -84,22 +84,26 @@ def fuzz_module():
         if irt == 3:          # 3PL: clamp-band chaos grows with the logit spread (see above): narrow abilities, no flows
             A, n_flows = min(A, 2), 0
         use_kl = n_flows == 0 and rng.random() < 0.7
+        merge = 'mean' if (not cond and rng.random() < 0.3) else 'product'      # --ability-merge mean: unconditional only
         seed = rng.randrange(1 << 30)
-        if a.replay:      # "irt A B I cond flows drop missing beta use_kl seed"
+        if a.replay:      # "irt A B I cond flows drop missing beta use_kl seed [merge]"
             f = a.replay.split()
             irt, A, B, I, n_flows, seed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])
             cond, drop, use_kl, missing, beta = f[4] == 'True', f[6] == 'True', f[9] == 'True', float(f[7]), float(f[8])
+            merge = f[11] if len(f) > 11 else 'product'
         torch.manual_seed(seed)
         cls = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[irt]
-        model = cls(A, I, hidden_dim=16, ability_merge='product', conditional_posterior=cond,
+        model = cls(A, I, hidden_dim=16, ability_merge=merge, conditional_posterior=cond,
                     replace_missing_with_prior=not drop, n_norm_flows=n_flows)
         with torch.no_grad():      # keep the logits out of the Bernoulli clamp band (fp32 decisions there are chaotic,
             # in the reference as well: the saturation golden pins the exact 1PL/2PL semantics separately)
             model.item_encoder.mu_lookup.weight.mul_(0.3)
             model.item_encoder.logvar_lookup.weight.mul_(0.3).sub_(2.0)
             for name, prm in model.named_parameters():       # small posterior means, well-conditioned flows: |logit| < ~8
-                if name.endswith('mlp.4.weight'):
+                if name.endswith('mlp.4.weight') or name.endswith('mlp2.2.weight'):
                     prm.mul_(0.2)
+                elif name.endswith('mlp2.2.bias'):           # mean merge: log-variances around -2 (the product of experts gets
+                    prm[A:] = -2.0                           # its narrow posteriors from the number of experts)
                 elif '_norm_flows' in name and name.endswith('.w'):      # uhat ~ w / |w|^2: keep |w| away from 0
                     prm.copy_(torch.sign(prm) * (0.5 + prm.abs()) / prm.numel() ** 0.5)
                 elif '_norm_flows' in name and name.endswith('.u'):
@@ -148,7 +152,7 @@ def fuzz_module():
             sys.exit(0)
         if bad:
             print(f'FAIL module irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} beta={beta} '
-                  f'use_kl={use_kl} seed={seed}: {bad}')
+                  f'use_kl={use_kl} seed={seed} merge={merge}: {bad}')
             sys.exit(1)
     print(f'fuzz module ok: {n} random configurations, worst relative error {worst:.2e}')
 
