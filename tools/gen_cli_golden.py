@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Trained-model golden: run the REAL reference CLI (src/torch_core/vibo.py, CPU) end to end on a seeded simulation
+and keep what SURVEY.md §8c asks a trained GPU model to be compared with (final losses, imputation accuracy, inferred
+posterior means).  Build container only; only the resulting numbers are committed (tests/golden/cli_trained_2pl.npz).
+
+Shims: stub `nltk`; Distribution validate_args off; torch.load(weights_only=False); DATA_DIR / OUT_DIR
+patched before `src.datasets` is imported; nothing is written under /root/reference.  The simulation file is written
+by this repo's generator in the reference's own format (simulate.py:54-58 needs pyro, which is not installed).
+"""
+import json
+import os
+import runpy
+import sys
+import tempfile
+import types
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+REF = '/root/reference'
+ARGS = dict(irt='2pl', num_person=2000, num_item=50, ability_dim=1, perc=0.2, epochs=30, batch=16, samples=20, seed=42)
+
+
+def main():
+    sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
+    from vibo_amd import simulate
+    tmp = tempfile.mkdtemp(prefix='vibo_cli_golden_')
+    data_dir, out_dir = os.path.join(tmp, 'data'), os.path.join(tmp, 'out')
+    d = os.path.join(data_dir, f"{ARGS['irt']}_simulation_{ARGS['num_person']}person_{ARGS['num_item']}item_{ARGS['ability_dim']}ability")
+    os.makedirs(d)
+    os.makedirs(out_dir)
+    torch.save(simulate.generate(ARGS['irt'], ARGS['num_person'], ARGS['num_item'], ARGS['ability_dim'], seed=ARGS['seed']),
+               os.path.join(d, 'simulation.pth'))
+
+    sys.modules.setdefault('nltk', types.SimpleNamespace(word_tokenize=None))
+    sys.path.insert(0, REF)
+    torch.distributions.Distribution.set_default_validate_args(False)
+    _load = torch.load
+    torch.load = lambda *a, **k: _load(*a, **{**k, 'weights_only': False})
+    import src.config as cfg
+    cfg.DATA_DIR, cfg.OUT_DIR = data_dir, out_dir
+    cfg.IS_REAL_WORLD.setdefault('3pl_simulation', False)
+    sys.argv = ['vibo.py', '--irt-model', ARGS['irt'], '--dataset', f"{ARGS['irt']}_simulation", '--num-person', str(ARGS['num_person']),
+                '--num-item', str(ARGS['num_item']), '--ability-dim', str(ARGS['ability_dim']), '--artificial-missing-perc',
+                str(ARGS['perc']), '--epochs', str(ARGS['epochs']), '--batch-size', str(ARGS['batch']), '--num-posterior-samples',
+                str(ARGS['samples']), '--no-marginal', '--seed', str(ARGS['seed']), '--out-dir', out_dir]
+    runpy.run_path(os.path.join(REF, 'src', 'torch_core', 'vibo.py'), run_name='__main__')
+    (run,) = os.listdir(out_dir)
+    ck = _load(os.path.join(out_dir, run, 'checkpoint.pth.tar'), weights_only=False)
+    rec = {
+        'meta': json.dumps(dict(ARGS, run_dir=run, torch=torch.__version__)),
+        'train_losses': np.load(os.path.join(out_dir, run, 'train_losses.npy')),
+        'test_losses': np.load(os.path.join(out_dir, run, 'test_losses.npy')),
+        'missing_imputation_accuracy': np.float64(ck['missing_imputation_accuracy']),
+        'ability_mu': ck['infer_dict']['ability_mu'].numpy(), 'ability_logvar': ck['infer_dict']['ability_logvar'].numpy(),
+        'item_feat_mu': ck['infer_dict']['item_feat_mu'].cpu().numpy(),
+    }
+    out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz')
+    np.savez_compressed(out, **rec)
+    print('wrote', out, 'train loss', rec['train_losses'][-1], 'test loss', rec['test_losses'][-1], 'imputation acc',
+          float(rec['missing_imputation_accuracy']))
+
+
+if __name__ == '__main__':
+    main()
