@@ -24,7 +24,7 @@ REF = '/root/reference'
 ARGS = dict(irt='2pl', num_person=2000, num_item=50, ability_dim=1, perc=0.2, epochs=30, batch=16, samples=20, seed=42)
 
 
-def main():
+def main(script='vibo'):
     sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
     from vibo_amd import simulate
     tmp = tempfile.mkdtemp(prefix='vibo_cli_golden_')
@@ -47,22 +47,24 @@ def main():
                 '--num-item', str(ARGS['num_item']), '--ability-dim', str(ARGS['ability_dim']), '--artificial-missing-perc',
                 str(ARGS['perc']), '--epochs', str(ARGS['epochs']), '--batch-size', str(ARGS['batch']), '--num-posterior-samples',
                 str(ARGS['samples']), '--no-marginal', '--seed', str(ARGS['seed']), '--out-dir', out_dir]
-    runpy.run_path(os.path.join(REF, 'src', 'torch_core', 'vibo.py'), run_name='__main__')
+    if script == 'vi':                       # the un-amortized VI script: same data, its own (larger) step size
+        sys.argv[0] = 'vi.py'
+        sys.argv += ['--lr', '0.02']
+    runpy.run_path(os.path.join(REF, 'src', 'torch_core', f'{script}.py'), run_name='__main__')
     (run,) = os.listdir(out_dir)
     ck = _load(os.path.join(out_dir, run, 'checkpoint.pth.tar'), weights_only=False)
     rec = {
-        'meta': json.dumps(dict(ARGS, run_dir=run, torch=torch.__version__)),
+        'meta': json.dumps(dict(ARGS, run_dir=run, script=script, lr=0.02 if script == 'vi' else 5e-3, torch=torch.__version__)),
         'train_losses': np.load(os.path.join(out_dir, run, 'train_losses.npy')),
-        'test_losses': np.load(os.path.join(out_dir, run, 'test_losses.npy')),
+        'test_losses': np.load(os.path.join(out_dir, run, 'test_losses.npy')) if script == 'vibo' else np.zeros(0),
         'missing_imputation_accuracy': np.float64(ck['missing_imputation_accuracy']),
         'ability_mu': ck['infer_dict']['ability_mu'].numpy(), 'ability_logvar': ck['infer_dict']['ability_logvar'].numpy(),
         'item_feat_mu': ck['infer_dict']['item_feat_mu'].cpu().numpy(),
     }
-    out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz')
+    out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz' if script == 'vibo' else f'cli_trained_{script}_2pl.npz')
     np.savez_compressed(out, **rec)
-    print('wrote', out, 'train loss', rec['train_losses'][-1], 'test loss', rec['test_losses'][-1], 'imputation acc',
-          float(rec['missing_imputation_accuracy']))
+    print('wrote', out, 'train loss', rec['train_losses'][-1], 'imputation acc', float(rec['missing_imputation_accuracy']))
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else 'vibo')

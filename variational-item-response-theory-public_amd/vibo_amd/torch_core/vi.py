@@ -153,6 +153,8 @@ def main(argv=None):
         ckpt = torch.load(path, weights_only=False)
         model.load_state_dict(ckpt['model_state_dict'])
         infer = _cli.infer_dict(face, train, args.batch_size)
+        for k in ('item_feat_mu', 'item_feat_logvar'):      # vi.py:289-290 stacks the (identical) per-batch item tensors:
+            infer[k] = infer[k].cpu().unsqueeze(0).expand(n_batches, -1, -1)      # [n_batches, I, D] (stride 0: stored once)
         if not args.no_predictive:
             samples = _cli.posterior_predictive(face, train, args, args.batch_size, args.store_predictive_samples)
             ckpt['posterior_predict_samples'] = samples
