@@ -108,3 +108,33 @@ def test_mle_cli_on_the_cpu_stand_in(tmp_path, monkeypatch):
 @pytest.mark.gpu
 def test_mle_cli_on_the_gpu(tmp_path, monkeypatch):
     _run_cli(tmp_path, monkeypatch, cuda=True)
+
+
+@pytest.mark.gpu
+def test_trained_mle_model_matches_the_reference_mle_run(tmp_path, monkeypatch):
+    """The reference's mle.py run end to end on CPU (tools/gen_cli_golden.py mle -> tests/golden/cli_trained_mle_2pl.npz; complete
+    data: its BCE call rejects the -1 targets of hidden cells on current PyTorch) against this mle.py on the GPU on the same seeded
+    data.  No sampling noise here, only the minibatch order differs."""
+    from vibo_amd import simulate
+    from vibo_amd.torch_core import mle
+    z = np.load(os.path.join(GOLDEN_DIR, 'cli_trained_mle_2pl.npz'))
+    a = json.loads(str(z['meta']))
+    monkeypatch.setattr(config, 'DATA_DIR', str(tmp_path / 'data'))
+    monkeypatch.setattr(config, 'OUT_DIR', str(tmp_path / 'out'))
+    d = simulate.simulation_dir(a['irt'], a['num_person'], a['num_item'], a['ability_dim'], data_dir=str(tmp_path / 'data'))
+    os.makedirs(d, exist_ok=True)
+    torch.save(simulate.generate(a['irt'], a['num_person'], a['num_item'], a['ability_dim'], seed=a['seed']),
+               os.path.join(d, 'simulation.pth'))
+    out_dir = mle.main(['--irt-model', a['irt'], '--dataset', f"{a['irt']}_simulation", '--num-person', str(a['num_person']),
+                        '--num-item', str(a['num_item']), '--ability-dim', str(a['ability_dim']), '--epochs', str(a['epochs']),
+                        '--batch-size', str(a['batch']), '--seed', str(a['seed']), '--lr', str(a['lr']), '--cuda',
+                        '--out-dir', str(tmp_path / 'out')])
+    assert os.path.basename(out_dir) == a['run_dir']
+    tr, te = np.load(os.path.join(out_dir, 'train_losses.npy')), np.load(os.path.join(out_dir, 'test_losses.npy'))
+    assert np.abs(tr - z['train_losses']).max() < 0.01 * z['train_losses'].max(), (tr, z['train_losses'])
+    assert np.abs(te - z['test_losses']).max() < 0.03 * z['test_losses'].max(), (te, z['test_losses'])
+    ck = torch.load(os.path.join(out_dir, 'checkpoint.pth.tar'), weights_only=False)
+    assert len(ck['infer_dict']['item_feat']) == int(z['n_item_feat_copies'])
+    r = np.corrcoef(ck['infer_dict']['ability'].numpy().ravel(), z['ability'].ravel())[0, 1]
+    ri = np.corrcoef(ck['infer_dict']['item_feat'][0].numpy().ravel(), z['item_feat'].ravel())[0, 1]
+    assert r > 0.98 and ri > 0.98, (r, ri)

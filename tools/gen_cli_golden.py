@@ -25,6 +25,8 @@ ARGS = dict(irt='2pl', num_person=2000, num_item=50, ability_dim=1, perc=0.2, ep
 
 
 def main(script='vibo'):
+    if script == 'mle':          # the reference's mle.py feeds the -1 of hidden cells to F.binary_cross_entropy as a target, which
+        ARGS['perc'] = 0.0       # current PyTorch rejects ("all elements of target should be between 0 and 1"): complete data only
     sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
     from vibo_amd import simulate
     tmp = tempfile.mkdtemp(prefix='vibo_cli_golden_')
@@ -50,17 +52,29 @@ def main(script='vibo'):
     if script == 'vi':                       # the un-amortized VI script: same data, its own (larger) step size
         sys.argv[0] = 'vi.py'
         sys.argv += ['--lr', '0.02']
+    if script == 'mle':                      # mle.py has neither posterior samples nor a marginal
+        i = sys.argv.index('--num-posterior-samples')
+        del sys.argv[i:i + 2]
+        sys.argv.remove('--no-marginal')
+        sys.argv[0] = 'mle.py'
+        sys.argv += ['--lr', '0.02']
     runpy.run_path(os.path.join(REF, 'src', 'torch_core', f'{script}.py'), run_name='__main__')
     (run,) = os.listdir(out_dir)
     ck = _load(os.path.join(out_dir, run, 'checkpoint.pth.tar'), weights_only=False)
     rec = {
-        'meta': json.dumps(dict(ARGS, run_dir=run, script=script, lr=0.02 if script == 'vi' else 5e-3, torch=torch.__version__)),
+        'meta': json.dumps(dict(ARGS, run_dir=run, script=script, lr=0.02 if script in ('vi', 'mle') else 5e-3, torch=torch.__version__)),
         'train_losses': np.load(os.path.join(out_dir, run, 'train_losses.npy')),
         'test_losses': np.load(os.path.join(out_dir, run, 'test_losses.npy')) if script == 'vibo' else np.zeros(0),
-        'missing_imputation_accuracy': np.float64(ck['missing_imputation_accuracy']),
-        'ability_mu': ck['infer_dict']['ability_mu'].numpy(), 'ability_logvar': ck['infer_dict']['ability_logvar'].numpy(),
-        'item_feat_mu': ck['infer_dict']['item_feat_mu'].cpu().numpy(),
+        'missing_imputation_accuracy': np.float64(ck.get('missing_imputation_accuracy', float('nan'))),
     }
+    if script == 'mle':
+        rec['test_losses'] = np.load(os.path.join(out_dir, run, 'test_losses.npy'))
+        rec['ability'] = ck['infer_dict']['ability'].numpy()
+        rec['item_feat'] = ck['infer_dict']['item_feat'][0].numpy()
+        rec['n_item_feat_copies'] = np.int64(len(ck['infer_dict']['item_feat']))
+    else:
+        rec.update(ability_mu=ck['infer_dict']['ability_mu'].numpy(), ability_logvar=ck['infer_dict']['ability_logvar'].numpy(),
+                   item_feat_mu=ck['infer_dict']['item_feat_mu'].cpu().numpy())
     out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz' if script == 'vibo' else f'cli_trained_{script}_2pl.npz')
     np.savez_compressed(out, **rec)
     print('wrote', out, 'train loss', rec['train_losses'][-1], 'imputation acc', float(rec['missing_imputation_accuracy']))

@@ -142,7 +142,7 @@ def main(argv=None):
         if not args.no_infer_dict:
             with torch.no_grad():
                 ability, item_feat = model.ability.weight.detach().cpu(), model.item_feat.weight.detach().cpu()
-                ckpt['infer_dict'] = {'ability': ability, 'item_feat': [item_feat]}          # mle.py:235-259 (item_feat: one per batch)
+                ckpt['infer_dict'] = {'ability': ability, 'item_feat': [item_feat] * n_batches}      # mle.py:235-259: one (identical) entry per batch
                 if args.artificial_missing_perc > 0:
                     inferred = model.decode(model.ability.weight, model.item_feat.weight).squeeze(2).cpu()
                     ckpt['missing_imputation_accuracy'] = _cli.imputation_accuracy(
