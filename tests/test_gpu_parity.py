@@ -542,3 +542,31 @@ def test_encode_and_decode_on_a_flow_model():
     assert (pr - O.irt_link(irt, ref['ability'].float(), item)).abs().max() < 2e-6
     prm = ops.decode_probs_mean(spec, ref['ability'].float().to(d)[None], item.to(d)[None]).cpu()
     assert (prm - pr).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize('I,A', [(50, 2), (95, 1), (1030, 3)])
+def test_conditional_posterior_does_not_touch_memory_behind_the_table(I, A):
+    """Regression (found by the trained-model parity run: NaN in epoch 12 of a conditional-posterior training with 50 items):
+    the last 4-item chunk of a row whose item count is not a multiple of 4 reaches past the per-item expert table; whatever
+    lies there (here: NaN) must not enter the sums, not even multiplied by a zero weight."""
+    d = dev()
+    B = 16
+    spec = ElboSpec(irt_model=2, ability_dim=A, conditional=True)
+    resp, mask, table, item, eps = random_problem(2, A, B, I, 0.2, seed=I + A, cond=True)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=2, ability_dim=A,
+                           conditional_posterior=True, mode='kl')
+    n = table.numel()
+    buf = torch.full((n + 256,), float('nan'), device=d)
+    buf[:n] = table.to(d).reshape(-1)
+    tab = buf[:n].view(2, I, 2 * A)
+    ibuf = torch.full((item.numel() + 256,), float('nan'), device=d)
+    ibuf[:item.numel()] = item.to(d).reshape(-1)
+    it = ibuf[:item.numel()].view(I, spec.item_dim)
+    r_, m_ = ops.pad_rows(resp.to(d), mask.bool().to(d))
+    for rows in ((r_, m_), (ops.pack_cell_codes(r_, m_), None)):
+        r, m, code = ops.prepare_rows(*rows)
+        raw = ops._hip_launch_elbo(spec, r, m, code, None, tab, it, eps.to(d), None, _lib.REG_KL, True, B)
+        assert torch.isfinite(raw.flat).all() and torch.isfinite(raw.ability_mu).all()
+        compare_raw(raw, ref, (I, spec.item_dim))
+        mu, lv = ops._hip_encode(spec, r, m, code, None, tab, B)
+        assert torch.isfinite(mu).all() and (mu.cpu() - ref['ability_mu'].float()).abs().max() < 2e-5

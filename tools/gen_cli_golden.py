@@ -24,7 +24,26 @@ REF = '/root/reference'
 ARGS = dict(irt='2pl', num_person=2000, num_item=50, ability_dim=1, perc=0.2, epochs=30, batch=16, samples=20, seed=42)
 
 
+def out_path(variant):
+    return os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz' if variant == 'vibo' else f'cli_trained_{variant}_2pl.npz')
+
+
+VARIANTS = {      # extra reference-CLI flags of the additional VIBO runs
+    'vibo_cond': ['--conditional-posterior', '--ability-dim', '2'],
+    'vibo_mean': ['--ability-merge', 'mean'],
+    'vibo_3pl_flows': ['--n-norm-flows', '2'],
+}
+
+
 def main(script='vibo'):
+    variant, extra = script, []
+    if script in VARIANTS:
+        extra, script = VARIANTS[script], 'vibo'
+        ARGS['epochs'] = 15
+        if variant == 'vibo_cond':
+            ARGS['ability_dim'] = 2
+        if variant == 'vibo_3pl_flows':
+            ARGS['irt'] = '3pl'
     if script == 'mle':          # the reference's mle.py feeds the -1 of hidden cells to F.binary_cross_entropy as a target, which
         ARGS['perc'] = 0.0       # current PyTorch rejects ("all elements of target should be between 0 and 1"): complete data only
     sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
@@ -49,6 +68,11 @@ def main(script='vibo'):
                 '--num-item', str(ARGS['num_item']), '--ability-dim', str(ARGS['ability_dim']), '--artificial-missing-perc',
                 str(ARGS['perc']), '--epochs', str(ARGS['epochs']), '--batch-size', str(ARGS['batch']), '--num-posterior-samples',
                 str(ARGS['samples']), '--no-marginal', '--seed', str(ARGS['seed']), '--out-dir', out_dir]
+    for i in range(0, len(extra)):
+        if extra[i] == '--ability-dim':          # already in argv: replace
+            j = sys.argv.index('--ability-dim')
+            sys.argv[j + 1] = extra[i + 1]
+    sys.argv += [e for k, e in enumerate(extra) if e != '--ability-dim' and (k == 0 or extra[k - 1] != '--ability-dim')]
     if script == 'vi':                       # the un-amortized VI script: same data, its own (larger) step size
         sys.argv[0] = 'vi.py'
         sys.argv += ['--lr', '0.02']
@@ -62,11 +86,15 @@ def main(script='vibo'):
     (run,) = os.listdir(out_dir)
     ck = _load(os.path.join(out_dir, run, 'checkpoint.pth.tar'), weights_only=False)
     rec = {
-        'meta': json.dumps(dict(ARGS, run_dir=run, script=script, lr=0.02 if script in ('vi', 'mle') else 5e-3, torch=torch.__version__)),
+        'meta': json.dumps(dict(ARGS, run_dir=run, script=script, extra=extra, lr=0.02 if script in ('vi', 'mle') else 5e-3, torch=torch.__version__)),
         'train_losses': np.load(os.path.join(out_dir, run, 'train_losses.npy')),
         'test_losses': np.load(os.path.join(out_dir, run, 'test_losses.npy')) if script == 'vibo' else np.zeros(0),
         'missing_imputation_accuracy': np.float64(ck.get('missing_imputation_accuracy', float('nan'))),
     }
+    if 'infer_dict' not in ck:            # flows: vibo.py:102-104 switches the inference dictionary off
+        np.savez_compressed(out_path(variant), **rec)
+        print('wrote', out_path(variant), 'train loss', rec['train_losses'][-1])
+        return
     if script == 'mle':
         rec['test_losses'] = np.load(os.path.join(out_dir, run, 'test_losses.npy'))
         rec['ability'] = ck['infer_dict']['ability'].numpy()
@@ -75,7 +103,7 @@ def main(script='vibo'):
     else:
         rec.update(ability_mu=ck['infer_dict']['ability_mu'].numpy(), ability_logvar=ck['infer_dict']['ability_logvar'].numpy(),
                    item_feat_mu=ck['infer_dict']['item_feat_mu'].cpu().numpy())
-    out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz' if script == 'vibo' else f'cli_trained_{script}_2pl.npz')
+    out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz' if variant == 'vibo' else f'cli_trained_{variant}_2pl.npz')
     np.savez_compressed(out, **rec)
     print('wrote', out, 'train loss', rec['train_losses'][-1], 'imputation acc', float(rec['missing_imputation_accuracy']))
 

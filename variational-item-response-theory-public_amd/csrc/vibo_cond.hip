@@ -102,11 +102,15 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float* te = p.table + ((size_t)c * p.I_total + (p.item0 + 4 * chunk + j)) * 2 * A;
+            // (the last chunk of a row whose item count is not a multiple of 4 covers items past the table's end: those
+            // cells carry code 0, but 0 x (whatever lies behind the table) must not be formed -- it may be Inf / NaN)
+            const int item = p.item0 + 4 * chunk + j;
+            const bool item_ok = chunk_ok && item < p.I_total;
+            const float* te = p.table + ((size_t)c * p.I_total + (item_ok ? item : 0)) * 2 * A;
 #pragma unroll
             for (int a = 0; a < AT; ++a) {
                 float t = 0.f, mm = 0.f;
-                if (chunk_ok && a < A) {
+                if (item_ok && a < A) {
                     t = 1.0f / (expf(te[A + a]) + kPoeEps);       // utils.py:105-113
                     mm = te[a] * t;
                 }
@@ -237,7 +241,8 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
                 float tauv[4], muv[4], esv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float* te = p.table + ((size_t)c * p.I_total + (p.item0 + 4 * chunk + j)) * 2 * A;
+                    const int item = p.item0 + 4 * chunk + j;          // (past the row's end: read item 0, the result is never used)
+                    const float* te = p.table + ((size_t)c * p.I_total + (item < p.I_total ? item : 0)) * 2 * A;
                     esv[j] = expf(te[A + a]);
                     tauv[j] = 1.0f / (esv[j] + kPoeEps);
                     muv[j] = te[a];
