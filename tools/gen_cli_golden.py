@@ -32,6 +32,7 @@ VARIANTS = {      # extra reference-CLI flags of the additional VIBO runs
     'vibo_cond': ['--conditional-posterior', '--ability-dim', '2'],
     'vibo_mean': ['--ability-merge', 'mean'],
     'vibo_3pl_flows': ['--n-norm-flows', '2'],
+    'vibo_1pl_drop95': ['--drop-missing'],          # 95 items (CritLangAcq's count: not a multiple of 4), dropped experts
 }
 
 
@@ -44,6 +45,8 @@ def main(script='vibo'):
             ARGS['ability_dim'] = 2
         if variant == 'vibo_3pl_flows':
             ARGS['irt'] = '3pl'
+        if variant == 'vibo_1pl_drop95':
+            ARGS['irt'], ARGS['num_item'] = '1pl', 95
     if script == 'mle':          # the reference's mle.py feeds the -1 of hidden cells to F.binary_cross_entropy as a target, which
         ARGS['perc'] = 0.0       # current PyTorch rejects ("all elements of target should be between 0 and 1"): complete data only
     sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
