@@ -148,7 +148,8 @@ def test_noise_drawn_in_the_prologue_equals_separate_fills(A, I, B):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('golden_name', ['cli_trained_2pl', 'cli_trained_vibo_cond_2pl', 'cli_trained_vibo_mean_2pl',
-                                         'cli_trained_vibo_3pl_flows_2pl', 'cli_trained_vibo_1pl_drop95_2pl'])
+                                         'cli_trained_vibo_3pl_flows_2pl', 'cli_trained_vibo_1pl_drop95_2pl',
+                                         'cli_trained_vibo_a8_1100_2pl', 'cli_trained_vibo_cond_1030_2pl'])
 def test_trained_model_matches_the_reference_cli_run(tmp_path, monkeypatch, golden_name):
     """SURVEY §8c trained-model parity: the same seeded dataset and flags through this CLI on the GPU (different noise
     stream) against what the REAL reference CLI produced on CPU (tools/gen_cli_golden.py -> tests/golden/cli_trained_2pl.npz):

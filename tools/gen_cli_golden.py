@@ -32,7 +32,9 @@ VARIANTS = {      # extra reference-CLI flags of the additional VIBO runs
     'vibo_cond': ['--conditional-posterior', '--ability-dim', '2'],
     'vibo_mean': ['--ability-merge', 'mean'],
     'vibo_3pl_flows': ['--n-norm-flows', '2'],
-    'vibo_1pl_drop95': ['--drop-missing'],          # 95 items (CritLangAcq's count: not a multiple of 4), dropped experts
+    'vibo_1pl_drop95': ['--drop-missing'],
+    'vibo_a8_1100': [],                            # more than 1024 items: panel mode of the row-split kernel, 8 ability dims
+    'vibo_cond_1030': ['--conditional-posterior'],   # conditional posterior over two panels, item count not a multiple of 4          # 95 items (CritLangAcq's count: not a multiple of 4), dropped experts
 }
 
 
@@ -47,6 +49,10 @@ def main(script='vibo'):
             ARGS['irt'] = '3pl'
         if variant == 'vibo_1pl_drop95':
             ARGS['irt'], ARGS['num_item'] = '1pl', 95
+        if variant == 'vibo_a8_1100':
+            ARGS.update(num_person=400, num_item=1100, ability_dim=8, epochs=10)
+        if variant == 'vibo_cond_1030':
+            ARGS.update(num_person=400, num_item=1030, epochs=10)
     if script == 'mle':          # the reference's mle.py feeds the -1 of hidden cells to F.binary_cross_entropy as a target, which
         ARGS['perc'] = 0.0       # current PyTorch rejects ("all elements of target should be between 0 and 1"): complete data only
     sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
