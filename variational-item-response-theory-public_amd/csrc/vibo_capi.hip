@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/vibo_hip.h"
@@ -59,6 +60,8 @@ struct Plan {
     int row_nblk;
     bool split_ok;            // row-split register kernel (ability_dim 3..8) is applicable (subject to alignment)
     int split_nq, split_nblk;
+    bool msplit;              // the row-split launches go to the matrix-pipe kernel (vibo_msplit_kernel.hpp): split_nq = waves of
+                              // 128 items per workgroup, batches of 32 rows
     int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
     size_t off_cnt;           // panel mode: per-person packed counts of the whole row
     bool cond;                // panel mode with the conditional posterior: cond_pre / split / cond_post per panel
@@ -73,7 +76,14 @@ struct Plan {
 
 static int g_num_cu = 0;
 
-static hipError_t launch_split(const ElboParams& p, int AT, bool codes, int irt, bool grad, int nq, int grid, hipStream_t s) {
+static hipError_t launch_split(const ElboParams& p, int AT, bool codes, int irt, bool grad, int nq, int grid, hipStream_t s,
+                               bool msplit = false) {
+    if (msplit) {
+        const int nw = (p.I + 127) / 128;
+        if (codes) return launch_elbo_msplit_c(p, irt, grad, nw, grid, s);
+        if (p.row_index) return launch_elbo_msplit_g(p, irt, grad, nw, grid, s);
+        return launch_elbo_msplit_a(p, irt, grad, nw, grid, s);
+    }
     if (codes)
         return AT <= 2   ? launch_elbo_split_c2(p, irt, grad, nq, grid, s)
                : AT == 4 ? launch_elbo_split_c4(p, irt, grad, nq, grid, s)
@@ -117,8 +127,25 @@ static bool codes_three_waves(const vibo_desc* d, int AT) {
     return d->mask_dtype == VIBO_MASK_CODES && (AT <= 2 || (AT == 4 && d->irt_model <= 2));
 }
 
-static int make_plan(const vibo_desc* d, Plan* pl) {
+// Which row-split kernel: the matrix-pipe kernel (contractions as f16 hi/lo MFMAs) or the VALU kernel.  VIBO_MSPLIT=0/1 in the
+// environment forces one of them (A/B measurements, tests of both paths); planar flows stay on the VALU kernel.
+static bool want_msplit(const vibo_desc* d) {
+    if (d->n_flows > 0) return false;
+    const char* e = getenv("VIBO_MSPLIT");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    return true;
+}
+static int msplit_blocks(int num_cu, int items, long long persons) {
+    const int nw = (items + 127) / 128;
+    long long nblk = (long long)num_cu * (nw >= 8 ? 1 : nw >= 4 ? 2 : nw >= 2 ? 4 : 8);
+    const long long nb = (persons + 31) / 32;
+    return (int)(nblk < nb ? nblk : nb);
+}
+
+static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
     const int I = d->num_item, A = d->ability_dim;
+    pl->msplit = false;
     pl->AT = padded_ability_dim(A);
     pl->D = item_feat_dim(d->irt_model, A);
     pl->DP = prepped_item_width(d->irt_model, pl->AT);
@@ -159,6 +186,12 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
         pl->split_nq = 4;
         pl->split_nblk = g_num_cu * ((d->want_grad && !codes_three_waves(d, pl->AT)) ? 2 : 3);
         if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
+        if (allow_msplit && want_msplit(d)) {
+            pl->msplit = true;
+            pl->AT = 8;
+            pl->DP = prepped_item_width(d->irt_model, 8);
+            pl->split_nblk = msplit_blocks(g_num_cu, I < 1024 ? I : 1024, d->num_person);
+        }
         pl->nblk = 0;
         pl->lds_main = 0;
         pl->lay = partial_layout(A, pl->D, 1024, d->n_flows);
@@ -245,6 +278,12 @@ static int make_plan(const vibo_desc* d, Plan* pl) {
     }
     pl->split_nblk = g_num_cu * (((d->want_grad && !codes_three_waves(d, pl->AT)) ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
     if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
+    if (pl->split_ok && allow_msplit && want_msplit(d)) {
+        pl->msplit = true;
+        pl->AT = 8;
+        pl->DP = prepped_item_width(d->irt_model, 8);
+        pl->split_nblk = msplit_blocks(g_num_cu, I, d->num_person);
+    }
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
     pl->geom.grid = nblk;
@@ -864,7 +903,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             p.partial = partial + (size_t)pn * pl.split_nblk * pl.lay.stride;
             p.post_coef = ((pl.cond || pl.given) && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
             const int nq = (p.I + 255) / 256;
-            e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s);
+            e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s, pl.msplit);
         }
         if (pl.cond && grad) {
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
@@ -886,7 +925,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         bpp = pl.split_nblk;
     } else if (pl.split_ok && vec) {
         nblk_used = pl.split_nblk;
-        e = launch_split(p, pl.AT, codes, d->irt_model, grad, pl.split_nq, pl.split_nblk, s);
+        e = launch_split(p, pl.AT, codes, d->irt_model, grad, pl.split_nq, pl.split_nblk, s, pl.msplit);
     } else if (pl.row_ok && vec && I % 4 == 0 && pl.AT == A) {
         nblk_used = pl.row_nblk;
         e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);
@@ -919,7 +958,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
 static int multi_plan(const vibo_desc* d, vibo_desc* d0, Plan* pl, size_t* prep_bytes) {
     *d0 = *d;
     d0->want_grad = 0;
-    const int stride = make_plan(d0, pl);
+    const int stride = make_plan(d0, pl, false);
     if (stride < 0) return stride;
     // conditional posterior: the expert table itself depends on the item sample, nothing is shared between samples
     if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) return fail(-8, "multi-sample forward: conditional posterior (one table per sample)");
