@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Phase timing of the matrix row-split kernel (development build: make -C .../csrc TIMING=1).
+   python tools/ms_timing.py [profile_kernel.py args]  -> mean shader-clock cycles per batch and phase, per wave"""
+import ctypes, os, subprocess, sys
+import numpy as np
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.argv = ['profile_kernel.py'] + sys.argv[1:]
+exec(open(os.path.join(ROOT, 'tools', 'profile_kernel.py')).read())
+from vibo_amd import _lib
+lib = _lib.load() if hasattr(_lib, 'load') else ctypes.CDLL(os.path.join(ROOT, 'variational-item-response-theory-public_amd', 'vibo_amd', 'libvibo_hip.so'))
+n = 1024 * 8 * 16
+buf = (ctypes.c_longlong * n)()
+lib.vibo_debug_ms_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = lib.vibo_debug_ms_timing(buf, n)
+t = np.frombuffer(buf, dtype=np.int64).reshape(1024, 8, 16)[:256, :, :12].astype(np.float64)
+nb = (P + 31) // 32 / 256
+names = ['tiles u0', 'pack0', 'tiles u1', 'pack1', 'counts+gth', 'barrier A', 'forward', 'barrier B', 'read ops', 'backward', 'wait loads x2', 'issue loads x2']
+print('rc', rc, 'batches per workgroup %.1f' % nb)
+print('phase           ' + ''.join(f' wave{w:1d}  ' for w in range(8)) + '   (cycles per batch, mean over workgroups)')
+for k, nm in enumerate(names):
+    print(f'{nm:14s}' + ''.join(f'{t[:, w, k].mean() / nb:8.0f}' for w in range(8)))
+print(f'{"total":14s}' + ''.join(f'{t[:, w, :].sum(axis=1).mean() / nb:8.0f}' for w in range(8)))

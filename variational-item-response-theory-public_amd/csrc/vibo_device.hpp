@@ -72,23 +72,27 @@ __device__ __forceinline__ float code_to_f32(uint32_t word) {
 }
 
 // 4 responses (fp32 0.0/1.0) + 4 mask bytes (0/1) -> 4 fp8 codes; counts packed n1<<16 | nobs.
+// NEG: the sign of the codes is flipped (0x38 = +1 for a wrong answer, 0xB8 = -1 for a right one): the matrix row-split
+// kernel multiplies the logit by -w
+template <bool NEG = false>
 __device__ __forceinline__ uint32_t pack_codes4(const float4 x, const uint32_t m, int& packed) {
     const uint32_t x0 = __builtin_bit_cast(uint32_t, x.x), x1 = __builtin_bit_cast(uint32_t, x.y);
     const uint32_t x2 = __builtin_bit_cast(uint32_t, x.z), x3 = __builtin_bit_cast(uint32_t, x.w);
     // byte 3 of 1.0f is 0x3F, of 0.0f is 0x00: bit 24 tells "correct"
     const uint32_t hi = __builtin_amdgcn_perm(x1, x0, 0x0c0c0703u) | __builtin_amdgcn_perm(x3, x2, 0x07030c0cu);
     const uint32_t xb = hi & 0x01010101u;
-    const uint32_t code = (0xB8B8B8B8u ^ (xb << 7)) & ((m << 8) - m);   // m * 0xFF without the slow v_mul_lo_u32
+    const uint32_t code = ((NEG ? 0x38383838u : 0xB8B8B8B8u) ^ (xb << 7)) & ((m << 8) - m);   // m * 0xFF without the slow v_mul_lo_u32
     packed += __builtin_popcount(m) + (__builtin_popcount(xb & m) << 16);
     return code;
 }
 
 // Format P: 4 one-byte cell codes (0 = answered wrong, 1 = answered right, 2 = missing; VIBO_MASK_CODES) -> the same
 // fp8 codes / packed counts.  `keep` = 0xFF for the bytes that belong to the row (padding past the row's end is dropped).
+template <bool NEG = false>
 __device__ __forceinline__ uint32_t pack_cell_codes4(const uint32_t w, const uint32_t keep, int& packed) {
     const uint32_t xb = w & 0x01010101u;
     const uint32_t m = (((w >> 1) & 0x01010101u) ^ 0x01010101u) & keep;
-    const uint32_t code = (0xB8B8B8B8u ^ (xb << 7)) & ((m << 8) - m);
+    const uint32_t code = ((NEG ? 0x38383838u : 0xB8B8B8B8u) ^ (xb << 7)) & ((m << 8) - m);
     packed += __builtin_popcount(m) + (__builtin_popcount(xb & m) << 16);
     return code;
 }

@@ -33,6 +33,17 @@
 #include "vibo_device.hpp"
 #include "vibo_params.hpp"
 
+#ifdef VIBO_MS_TIMING
+// development build (make TIMING=1): shader-clock time per phase of the batch loop, summed per wave
+__device__ long long g_ms_timing[1024 * 8 * 16];
+#define MS_T(i) { __builtin_amdgcn_sched_barrier(0); long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+                  __builtin_amdgcn_sched_barrier(0); tacc[i] += now_ - tlast; tlast = now_; }
+#define MS_WAITV() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define MS_T(i)
+#define MS_WAITV()
+#endif
+
 namespace vibo {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -47,7 +58,7 @@ constexpr int kMsSpan = 128;      // items per wave
 constexpr int kMsItemRow = 24;    // halfs per item of the operand image: na_hi[8] | na_lo[8] | nb pieces[3] | 0...
 constexpr int kMsItemLane = 4 * kMsItemRow + 8;   // halfs per float4 chunk (4 items) + 16 B of padding (208 B: conflict-free b128 reads)
 struct alignas(16) MsWaveLds {
-    _Float16 tr[2][2][64 * 16];   // [hi | lo][M-tile][row = 16 t + i16][16 persons]: g pieces of a u-step
+    _Float16 tr[2][2][32 * 16];   // [hi | lo][M-tile][row = 16 (t & 1) + i16][16 persons]: g pieces of one 32-item K-tile
     _Float16 img[2][16 * kMsItemLane];   // [u-step][chunk i16][item t][24]: MFMA operands of this wave's 128 items
     float gth[2][kMsRows][8];     // [batch parity] this wave's share of d LL/d theta of the batch (log2 units)
     int cnt[kMsRows];             // packed counts (n1 << 16 | nobs) of this wave's items
@@ -58,7 +69,8 @@ struct alignas(16) MsCommonLds {
     _Float16 thT[16][kMsRows];    // [dim (hi) | 8 + dim (lo)][slot]: B operand of the d LL/d a MFMA
     float st[2][5][256];          // [batch parity] forward state of the (person, dim) pairs, kept for the backward
     float ctab[4 * 2 * 8];
-    float tred[8][8][8];          // [wave][k][dim] table-gradient sums of the wave's (person, dim) lanes
+    float tacc[2][12][256];       // [batch parity][k][(person, dim) pair]: running sums of the pair's table-gradient terms
+                                  // (k < 8) and of its kl | logq0 | logp | nobs terms: one LDS add per value and batch
 };
 inline size_t msplit_lds_bytes(int nw) { return sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds); }
 
@@ -76,6 +88,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ms_rsrc(const void* base, long
     const unsigned n = bytes <= 0 ? 0u : bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)n, 0x00020000);
 }
+// running sum in LDS, one owner lane per address: plain read-modify-write (measured: 12 ds_add_f32 per batch and owner
+// lane instead cost the whole kernel 0.29 ms of 1.46 -- the LDS serialises its float atomics)
+__device__ __forceinline__ void lds_add(float* p, float v) { *p += v; }
 __device__ __forceinline__ f32x4 mfma16(const half8 a, const half8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -175,11 +190,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
     f32x4 acc_gt[2];                    // d LL/d theta of the batch: [16 persons of M-tile][a_hi cols | a_lo cols]
     acc_gt[0] = acc_gt[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (lane < 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cl.tred[q][k][lane] = 0.f;
-    }
-    float s_log = 0.f, s_kl = 0.f, s_logq0 = 0.f, s_logp = 0.f, s_nobs = 0.f;
+    for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
+    float s_log = 0.f;
     int unobs = 0;
     __syncthreads();
     const int ed = lane & 7;
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int rofs = 64 * g + 16 * (i16 >> 2) + 4 * ((i16 & 3) ^ g);
 
     const long long n_batches = ((long long)p.B + R - 1) / R;
-    float4 x[CODES ? 1 : 8];
+    float4 x[CODES ? 1 : 8];                        // [2 j + u]: person j of the half, chunk u
     uint32_t m[8];
     int ridx[8];
     auto fetch_idx = [&](const long long bt) {
@@ -204,82 +216,107 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
     };
+    // Row loads.  The unit is a "half": the lane's 4 persons of one M-tile x BOTH chunks of the wave's item span, so
+    // that a wave asks for 512 contiguous bytes of a response row (128 of its mask row) back to back and neighbouring
+    // waves touch a row at the same time: segment-edge cache lines are fetched once (units of 32 rows x 64 items left them
+    // to be re-fetched half a batch later: 1.34x the algorithmic HBM traffic).
     // In-order rows go through buffer loads: one resource per batch (scalar registers) whose record limit ends at the last
-    // row of the matrix (rows past the end read as zeros), ONE per-lane offset shared by the 8 rows of a lane and the row
-    // step as a scalar offset -- no per-row address registers.  Gathered rows compute their addresses at the load.  Chunks
+    // row of the matrix (rows past the end read as zeros), per-lane offsets shared by all rows of the lane and the row step
+    // as a scalar offset -- no per-row address registers.  Gathered rows compute their addresses at the load.  Chunks
     // past the row's end read its last chunk; both cases are masked when the cells are packed.
-    auto load_ustep = [&](const long long bt, const int u) {
+    const int cc0 = min(32 * q + i16, n4 - 1), cc1 = min(32 * q + 16 + i16, n4 - 1);
+    const unsigned mvo0 = (unsigned)(4 * g * (int)p.mask_stride + 4 * cc0), mvo1 = (unsigned)(4 * g * (int)p.mask_stride + 4 * cc1);
+    const unsigned rvo0 = (unsigned)(16 * g * (int)p.resp_stride + 16 * cc0), rvo1 = (unsigned)(16 * g * (int)p.resp_stride + 16 * cc1);
+    // per-batch source of the in-order rows (scalar registers): past the last batch the record count is 0 and every load
+    // returns zeros, so no load sits behind a branch
+    struct RowSrc { __amdgpu_buffer_rsrc_t r, m; };
+    const long long full_r = (31ll * p.resp_stride + 4 * n4) * 4, full_m = 31ll * p.mask_stride + 4 * n4;
+    auto row_src = [&](const long long bt) {
         const long long row0 = bt * R;
         const long long left = (long long)p.B - row0;
-        if (left <= 0) return;
-        const int c = min(32 * q + 16 * u + i16, n4 - 1);
-        const long long nrow = left < R ? left : R;
+        long long br = full_r, bm = full_m;
+        if (left < R) {                      // (wave-uniform; the last batch of the matrix, or past it)
+            br = left > 0 ? ((left - 1) * p.resp_stride + 4 * n4) * 4 : 0;
+            bm = left > 0 ? (left - 1) * p.mask_stride + 4 * n4 : 0;
+        }
+        RowSrc rs;
+        rs.m = ms_rsrc(static_cast<const uint8_t*>(p.mask) + row0 * p.mask_stride + p.item0, p.mask ? bm : 0);
+        if constexpr (!CODES) rs.r = ms_rsrc(p.response + row0 * p.resp_stride + p.item0, br);
+        else rs.r = rs.m;
+        return rs;
+    };
+    // quarter (h, j) = person 4 h + j of the lane (row 4 g + j + 16 h of the batch), both chunks: 2 x 16 B + 2 x 4 B
+    auto load_quarter = [&](const long long bt, const RowSrc& rs, const int h, const int j) {
+#ifdef VIBO_MS_NOLOAD
+        if (bt >= 2 * (long long)gridDim.x) return;
+#endif
         bool linear = RM == 0;
         if constexpr (RM == 2) linear = p.row_index == nullptr;
         if (linear) {
-            const unsigned mvo = (unsigned)(4 * g * (int)p.mask_stride + 4 * c);
-            const __amdgpu_buffer_rsrc_t mrs = ms_rsrc(static_cast<const uint8_t*>(p.mask) + row0 * p.mask_stride + p.item0,
-                                                       (nrow - 1) * p.mask_stride + 4 * n4);
+            const int mso = (j + 16 * h) * (int)p.mask_stride;
             if constexpr (CODES) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    m[k] = __builtin_amdgcn_raw_buffer_load_b32(mrs, mvo, ((k & 3) + 16 * (k >> 2)) * (int)p.mask_stride, 0);
+                m[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo0, mso, 0);
+                m[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo1, mso, 0);
             } else {
-                const unsigned rvo = (unsigned)(16 * g * (int)p.resp_stride + 16 * c);
-                const __amdgpu_buffer_rsrc_t rrs = ms_rsrc(p.response + row0 * p.resp_stride + p.item0,
-                                                           ((nrow - 1) * p.resp_stride + 4 * n4) * 4);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rrs, rvo, ((k & 3) + 16 * (k >> 2)) * 4 * (int)p.resp_stride, 0);
-                    x[k] = __builtin_bit_cast(float4, v);
-                    if (p.mask_dtype == 0)
-                        m[k] = __builtin_amdgcn_raw_buffer_load_b32(mrs, mvo, ((k & 3) + 16 * (k >> 2)) * (int)p.mask_stride, 0);
-                    else
-                        m[k] = 0x01010101u;
+                const int so = (j + 16 * h) * 4 * (int)p.resp_stride;
+                x[2 * j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo0, so, 0));
+                x[2 * j + 1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo1, so, 0));
+                if (p.mask_dtype == 0) {
+                    m[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo0, mso, 0);
+                    m[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo1, mso, 0);
+                } else {
+                    m[2 * j] = m[2 * j + 1] = 0x01010101u;
                 }
             }
         } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const long long src = (long long)ridx[k];
-                if constexpr (CODES) {
-                    m[k] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[c];
+            if (bt >= n_batches) return;
+            const long long src = (long long)ridx[4 * h + j];
+            if constexpr (CODES) {
+                const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
+                m[2 * j] = mp[cc0];
+                m[2 * j + 1] = mp[cc1];
+            } else {
+                const float4* rp = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0);
+                x[2 * j] = rp[cc0];
+                x[2 * j + 1] = rp[cc1];
+                if (p.mask_dtype == 0) {
+                    const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
+                    m[2 * j] = mp[cc0];
+                    m[2 * j + 1] = mp[cc1];
                 } else {
-                    x[k] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[c];
-                    if (p.mask_dtype == 0)
-                        m[k] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[c];
-                    else
-                        m[k] = 0x01010101u;
+                    m[2 * j] = m[2 * j + 1] = 0x01010101u;
                 }
             }
         }
     };
-    auto pack_ustep = [&](const long long bt, const int u, uint32_t (&cw)[8], int (&pk)[8]) {
-        const int c = 32 * q + 16 * u + i16;
-        const uint32_t tail_mask = c >= n4 ? 0u : ((I & 3) && c == (I >> 2)) ? ((1u << (8 * (I & 3))) - 1u) : 0xFFFFFFFFu;
+    // pack a quarter: the code words of person 4 h + j for both u-steps and its counts
+    const uint32_t tm_tail = (I & 3) ? ((1u << (8 * (I & 3))) - 1u) : 0xFFFFFFFFu;
+    const uint32_t tm0 = (32 * q + i16) >= n4 ? 0u : ((I & 3) && (32 * q + i16) == (I >> 2)) ? tm_tail : 0xFFFFFFFFu;
+    const uint32_t tm1 = (32 * q + 16 + i16) >= n4 ? 0u : ((I & 3) && (32 * q + 16 + i16) == (I >> 2)) ? tm_tail : 0xFFFFFFFFu;
+    // pk[j]: 8-bit fields nobs | nobs of M-tile 1 | n1 | n1 of M-tile 1 of persons j and 4 + j (each <= 8 per lane)
+    auto pack_quarter = [&](const long long bt, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4]) {
+        int pc = 0;
         const long long left = (long long)p.B - bt * R;          // (wave-uniform) only the last batch has rows past the end
-        if (left >= R) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if constexpr (CODES) cw[k] = pack_cell_codes4(m[k], tail_mask, pk[k]);
-                else cw[k] = pack_codes4(x[k], m[k] & tail_mask, pk[k]);
-            }
+        const bool in = left >= R || 4 * g + j + 16 * h < (int)left;
+        const uint32_t k0 = in ? tm0 : 0u, k1 = in ? tm1 : 0u;
+        // 1PL/2PL carry -w in the codes (the exponent is -w x logit: one VOP2 multiply)
+        if constexpr (CODES) {
+            cw0[4 * h + j] = pack_cell_codes4<IRT != 3>(m[2 * j], k0, pc);
+            cw1[4 * h + j] = pack_cell_codes4<IRT != 3>(m[2 * j + 1], k1, pc);
         } else {
-            const int nleft = (int)left;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t keep = (4 * g + (k & 3) + 16 * (k >> 2) < nleft) ? tail_mask : 0u;
-                if constexpr (CODES) cw[k] = pack_cell_codes4(m[k], keep, pk[k]);
-                else cw[k] = pack_codes4(x[k], m[k] & keep, pk[k]);
-            }
+            cw0[4 * h + j] = pack_codes4<IRT != 3>(x[2 * j], m[2 * j] & k0, pc);
+            cw1[4 * h + j] = pack_codes4<IRT != 3>(x[2 * j + 1], m[2 * j + 1] & k1, pc);
         }
+        pk[j] += h ? (pc << 8) : pc;
+        // (pinned here: hipcc otherwise sinks the whole pack to the end of the batch, and the next loads take new registers)
+        asm volatile("" : "+v"(cw0[4 * h + j]), "+v"(cw1[4 * h + j]), "+v"(pk[j]));
     };
     // packed counts of the lane's 8 persons (both u-steps) -> 16-lane sums -> wl.cnt
-    auto put_counts = [&](const int (&pk)[8], const bool real) {
+    auto put_counts = [&](const int (&pk)[4], const bool real) {
         int v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            int t = pk[k] + (pk[k + 4] << 8);       // fields of 8 bits: nobs_k | nobs_k+4 | n1_k | n1_k+4  (each <= 128)
+            int t = pk[k];
             t += dpp_i<0xb1>(t);                    // quad_perm [1,0,3,2]
             t += dpp_i<0x4e>(t);                    // quad_perm [2,3,0,1]
             t += dpp_i<0x141>(t);                   // row_half_mirror
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if constexpr (IRT != 3) {
             int obs = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) obs += pk[k] & 0xffff;
+            for (int k = 0; k < 4; ++k) obs += (pk[k] & 0xff) + ((pk[k] >> 8) & 0xff);
             if (real) unobs += 64 - obs;        // (a batch past the end is packed but never evaluated)
         }
         const int sel = i16 & 3;
@@ -301,16 +338,30 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // ---- (person, dim) lanes.  Slot s = 64 of the batch's 256 (person, dim) pairs; with 8 waves the slots of even batches
     //      belong to waves 0-3 and those of odd batches to waves 4-7, else to wave s mod nw.
     // product of experts + reparameterised sample of one slot (models.py:596-629)
-    auto forward_slot = [&](const long long bt, const int par, const int s, const float eps_c) {
+    // EXT: the variant that reads global memory in the sync phase (whole-row counts of the panel mode, the conditional /
+    // given posterior's statistics).  The plain variant issues no load at all: a load destination shared with it would make
+    // hipcc guard the register with an s_waitcnt vmcnt(0) -- behind the row loads that are in flight across the sync phase.
+    auto forward_slot = [&](auto extc, const long long bt, const int par, const int s, const float eps_c) {
+        constexpr bool EXT = decltype(extc)::value;
         const long long row0 = bt * R;
         const int e = 64 * s + lane, pp = e >> 3;
         const bool live = ed < A && (row0 + pp) < p.B;
         int cnt = 0;
-        if (p.row_cnt) {
-            cnt = live ? p.row_cnt[row0 + pp] : 0;
-        } else {
+        bool have_cnt = false;
+        if constexpr (EXT) {
+            if (p.row_cnt) {
+                cnt = live ? p.row_cnt[row0 + pp] : 0;
+                have_cnt = true;
+            }
+        }
+        if (!have_cnt) {
+            if (nw == 8) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) cnt += wls[w].cnt[pp];
+            } else {
 #pragma unroll 1
-            for (int w = 0; w < nw; ++w) cnt += wls[w].cnt[pp];
+                for (int w = 0; w < nw; ++w) cnt += wls[w].cnt[pp];
+            }
         }
         const float n1 = (float)(cnt >> 16);
         float nobs = (float)(cnt & 0xffff);
@@ -318,12 +369,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const float tau0 = cl.ctab[(0 * 2 + 0) * 8 + ed], tau1 = cl.ctab[(0 * 2 + 1) * 8 + ed];
         const float mt0 = cl.ctab[(1 * 2 + 0) * 8 + ed], mt1 = cl.ctab[(1 * 2 + 1) * 8 + ed];
         float lam = n0 * tau0 + n1 * tau1, smu = n0 * mt0 + n1 * mt1;
-        if (p.pre_stats) {
-            lam = 0.f; smu = 0.f; nobs = 0.f;
-            if (live) {
-                for (int pn = 0; pn < p.pre_panels; ++pn) {
-                    const float* st = p.pre_stats + ((size_t)pn * p.B + (row0 + pp)) * (2 * A + 1);
-                    lam += st[ed]; smu += st[A + ed]; nobs += st[2 * A];
+        if constexpr (EXT) {
+            if (p.pre_stats) {
+                lam = 0.f; smu = 0.f; nobs = 0.f;
+                if (live) {
+                    for (int pn = 0; pn < p.pre_panels; ++pn) {
+                        const float* st = p.pre_stats + ((size_t)pn * p.B + (row0 + pp)) * (2 * A + 1);
+                        lam += st[ed]; smu += st[A + ed]; nobs += st[2 * A];
+                    }
                 }
             }
         }
@@ -341,10 +394,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             p.ability_mu[o] = amu;
             p.ability_logvar[o] = alv;
             p.ability[o] = th0;
-            s_kl += -0.5f * (1.0f + alv - amu * amu - inv_lam);
-            s_logq0 += -0.5f * kLog2Pi - 0.5f * alv - 0.5f * eps_c * eps_c;
-            s_logp += -0.5f * kLog2Pi - 0.5f * thv * thv;
-            if (ed == 0) s_nobs += nobs;
+            lds_add(&cl.tacc[par][8][e], -0.5f * (1.0f + alv - amu * amu - inv_lam));
+            lds_add(&cl.tacc[par][9][e], -0.5f * kLog2Pi - 0.5f * alv - 0.5f * eps_c * eps_c);
+            lds_add(&cl.tacc[par][10][e], -0.5f * kLog2Pi - 0.5f * thv * thv);
+            if (ed == 0) lds_add(&cl.tacc[par][11][e], nobs);
         }
         if constexpr (GRAD) {
             cl.st[par][0][e] = amu; cl.st[par][1][e] = sig; cl.st[par][2][e] = inv_lam; cl.st[par][3][e] = eps_c;
@@ -365,8 +418,13 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int e = 64 * s + lane, pp = e >> 3;
         const bool live = ed < A && (row0 + pp) < p.B;
         float g0 = 0.f;
+        if (nw == 8) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) g0 += wls[w].gth[par][pp][ed];
+        } else {
 #pragma unroll 1
-        for (int w = 0; w < nw; ++w) g0 += wls[w].gth[par][pp][ed];
+            for (int w = 0; w < nw; ++w) g0 += wls[w].gth[par][pp][ed];
+        }
         const float gz0 = live ? g0 * kLn2 : 0.f;
         const float amu = cl.st[par][0][e], sig = cl.st[par][1][e], inv_lam = cl.st[par][2][e], eps_c = cl.st[par][3][e];
         const int cnt = __builtin_bit_cast(int, cl.st[par][4][e]);
@@ -411,17 +469,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float v = dt[k];
-            v += dpp_f<0x128>(v);                     // row_ror 8: lanes d and d + 8 of a row
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            dt[k] = v;
-        }
-        if (lane < 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cl.tred[q][k][lane] += dt[k];
-        }
+        for (int k = 0; k < 8; ++k) lds_add(&cl.tacc[par][k][e], dt[k]);      // (one lane per address: order is program order)
     };
     // slots of this wave for a batch: [s0, s1) in steps of `step` (one slot at most with 4 or more waves)
     auto my_slots = [&](const int par, int& s0, int& s1, int& step) {
@@ -445,14 +493,18 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     auto person_forward = [&](const long long bt, const int par) {
         int s0, s1, step;
         my_slots(par, s0, s1, step);
+        if (nw < 4 || p.row_cnt || p.pre_stats) {          // (wave-uniform)
 #pragma unroll 1
-        for (int s = s0; s < s1; s += step) {
-            float eps_c = epn;
-            if (nw < 4) {
-                const long long row = bt * R + ((64 * s + lane) >> 3);
-                eps_c = (ed < A && row < p.B) ? p.eps[row * A + ed] : 0.f;
+            for (int s = s0; s < s1; s += step) {
+                float eps_c = epn;
+                if (nw < 4) {
+                    const long long row = bt * R + ((64 * s + lane) >> 3);
+                    eps_c = (ed < A && row < p.B) ? p.eps[row * A + ed] : 0.f;
+                }
+                forward_slot(std::true_type{}, bt, par, s, eps_c);
             }
-            forward_slot(bt, par, s, eps_c);
+        } else if (s0 < s1) {
+            forward_slot(std::false_type{}, bt, par, s0, epn);
         }
     };
     auto person_backward = [&](const long long bt, const int par) {
@@ -462,106 +514,166 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         for (int s = s0; s < s1; s += step) backward_slot(bt, par, s);
     };
 
-    // ---- one u-step of math: 4 item tiles x 2 M-tiles ----
+    // ---- the batch's math: 8 item tiles (2 u-steps x 4) x 2 M-tiles, software-pipelined by hand:
+    //      tile n issues the logit MFMAs of tile n + 1 first (their latency and the LDS read of the item operand hide
+    //      under tile n's element-wise stream), and the d LL/d theta MFMAs of a 32-item K-tile run one tile after its
+    //      pieces were written to the LDS image (the transposed reads are issued at the start of that tile)
     half8 A1[2], B2;
+    float wev[8], wod[8];                // code values of the even tile / of the odd tile that follows it
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto math_ustep = [&](auto uc, const uint32_t (&cw)[8]) {
-        constexpr int u = decltype(uc)::value;
-        auto tile = [&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const half8 b1 = *reinterpret_cast<const half8*>(&wl.img[u][0] + b1ofs + t * kMsItemRow);
-            const f32x4 d0 = mfma16(A1[0], b1, zero4), d1 = mfma16(A1[1], b1, zero4);
-            const float lg[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-            float gl[8];
-            float pr0 = 1.0f, pr1 = 1.0f, lmax = 0.f;
+    auto logits = [&](auto uc, auto tc, f32x4& d0, f32x4& d1) {
+        constexpr int u = decltype(uc)::value, t = decltype(tc)::value;
+        const half8 b1 = *reinterpret_cast<const half8*>(&wl.img[u][0] + b1ofs + t * kMsItemRow);
+        d0 = mfma16(A1[0], b1, zero4);
+        d1 = mfma16(A1[1], b1, zero4);
+    };
+    struct KTileOps { half8 a3[2][2], b3; };
+    auto ktile_read = [&](auto uc, auto ktc, KTileOps& ko) {
+        constexpr int u = decltype(uc)::value, kt = decltype(ktc)::value;
+        const _Float16* rp = &wl.tr[0][0][0] + rofs;
+        const _Float16* ip = &wl.img[u][0] + b3ofs + 2 * kt * kMsItemRow;
+        ko.b3 = cat8(lds_tr16(ip), lds_tr16(ip + kMsItemRow));
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const _Float16* r0 = rp + 512 * (2 * hl + mt);
+                ko.a3[hl][mt] = cat8(lds_tr16(r0), lds_tr16(r0 + 256));
+            }
+    };
+    auto ktile_mfma = [&](const KTileOps& ko) {
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc_gt[mt] = mfma16(ko.a3[hl][mt], ko.b3, acc_gt[mt]);
+    };
+    // tile (u, t) on the logits d0 | d1; n0 | n1 receive the next tile's logits
+    auto tile = [&](auto uc, auto tc, const f32x4 d0, const f32x4 d1, f32x4& n0, f32x4& n1, const uint32_t (&cw)[8]) {
+        constexpr int u = decltype(uc)::value, t = decltype(tc)::value;
+        constexpr bool last = u == 1 && t == 3;
+        if constexpr (!last) logits(std::integral_constant<int, (t < 3 ? u : 1)>{}, std::integral_constant<int, (t < 3 ? t + 1 : 0)>{}, n0, n1);
+        // K-tile whose pieces were completed by the previous tile: (u, 0) at t = 2, (0, 1) at (1, 0)
+        constexpr bool pend = GRAD && (t == 2 || (u == 1 && t == 0));
+        const float lg[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        float gl[8];
+        float pr0 = 1.0f, pr1 = 1.0f;
+        // the codes of tiles t and t + 1 are converted together at the even tile (one instruction per person and pair)
+        if constexpr ((t & 1) == 0) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float w = code_to_f32<t>(cw[k]);
+                const float2v w2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw[k], t == 2);
+                wev[k] = w2[0];
+                wod[k] = w2[1];
+            }
+        }
+        const float (&wc)[8] = (t & 1) ? wod : wev;
+        if constexpr (IRT != 3) {
+            // wc = -w.  exponent e = -w l; ll = -log2(1 + 2^e); d ll/d l = w 2^e / (1 + 2^e) = wc / (1 + 2^e) - wc.
+            // The reference's probability clamp (utils.py:46-49 -> torch) only matters for |logit| > 15.94: value capped at
+            // +-kLogitLo, gradient exactly zero outside [-kLogitLo, kLogitHi] -- a wave-uniform slow path; everywhere else the
+            // plain formula is the reference's.
+            float tt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tt[k] = 1.0f + fast_exp2(wc[k] * lg[k]);
+            float lmax = fmaxf(fmaxf(fabsf(lg[0]), fabsf(lg[1])), fabsf(lg[2]));
+            lmax = fmaxf(fmaxf(lmax, fabsf(lg[3])), fabsf(lg[4]));
+            lmax = fmaxf(fmaxf(lmax, fabsf(lg[5])), fabsf(lg[6]));
+            lmax = fmaxf(lmax, fabsf(lg[7]));
+            const bool rare = __any(!(lmax <= kLoS));                   // (NaN-safe)
+            if (rare) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tt[k] = 1.0f + fast_exp2(wc[k] * med3(lg[k], -kLoS, kLoS));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float& pr = (k & 1) ? pr1 : pr0;
+                pr *= tt[k];                                          // <= (1 + 2^23)^4: one log2 per 4 terms
+                if constexpr (GRAD) gl[k] = fmaf(wc[k], fast_rcp(tt[k]), -wc[k]);
+            }
+            if constexpr (GRAD) {
+                if (rare) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gl[k] = (lg[k] < -kLoS || lg[k] > kHiS) ? 0.f : gl[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float w = wc[k];
                 float& pr = (k & 1) ? pr1 : pr0;
                 gl[k] = 0.f;
-                if constexpr (IRT != 3) {
-                    const float lc = med3(lg[k], -kLoS, kLoS);
-                    const float eu = fast_exp2(-w * lc);                  // exactly 1 for a missing cell (w = 0)
-                    const float tt = 1.0f + eu;
-                    pr *= tt;                                             // <= (1 + 2^23)^4: one log2 per 4 terms
-                    if constexpr (GRAD) gl[k] = fmaf(-w, fast_rcp(tt), w);   // w e / (1 + e) = d ll / d logit
-                    if constexpr (GRAD) lmax = fmaxf(lmax, fabsf(lg[k]));
-                } else {
-                    // 3PL: p = guess + (1 - guess) sigmoid(l)  (models.py:758-765), probability clamp on p itself
-                    const float l = lg[k];
-                    const float ee = fast_exp2(-fabsf(l));
-                    const float rr_ = fast_rcp(1.0f + ee);
-                    const float er_ = ee * rr_;
-                    const float sp = (l >= 0.f) ? rr_ : er_;
-                    const float sn = (l >= 0.f) ? er_ : rr_;
-                    const float prb = fmaf(om[u][t], sp, gs[u][t]);
-                    const float qr = om[u][t] * sn;
-                    const float pc = med3(prb, kEps32, 1.0f - kEps32);
-                    const float arg = (w > 0.f) ? pc : med3(qr, kEps32, 1.0f - kEps32);
-                    pr *= (w != 0.f) ? arg : 1.0f;
-                    if constexpr (GRAD) {
-                        const float wlv = (prb == pc) ? w : 0.f;
-                        const float common = wlv * fast_rcp(arg) * om[u][t] * sn;
-                        gl[k] = common * sp;
-                        acc_g[u][t] = fmaf(common, gs[u][t], acc_g[u][t]);
-                    }
+                // 3PL: p = guess + (1 - guess) sigmoid(l)  (models.py:758-765), probability clamp on p itself
+                const float l = lg[k];
+                const float ee = fast_exp2(-fabsf(l));
+                const float rr_ = fast_rcp(1.0f + ee);
+                const float er_ = ee * rr_;
+                const float sp = (l >= 0.f) ? rr_ : er_;
+                const float sn = (l >= 0.f) ? er_ : rr_;
+                const float prb = fmaf(om[u][t], sp, gs[u][t]);
+                const float qr = om[u][t] * sn;
+                const float pc = med3(prb, kEps32, 1.0f - kEps32);
+                const float arg = (w > 0.f) ? pc : med3(qr, kEps32, 1.0f - kEps32);
+                pr *= (w != 0.f) ? arg : 1.0f;
+                if constexpr (GRAD) {
+                    const float wlv = (prb == pc) ? w : 0.f;
+                    const float common = wlv * fast_rcp(arg) * om[u][t] * sn;
+                    gl[k] = common * sp;
+                    acc_g[u][t] = fmaf(common, gs[u][t], acc_g[u][t]);
                 }
             }
-            s_log += fast_log2(pr0) + fast_log2(pr1);
-            asm volatile("" : "+v"(s_log));          // (keeps hipcc from sinking the whole batch's products to the loop end)
-            if constexpr (GRAD) {
-                if constexpr (IRT != 3) {
-                    if (__any(lmax > kLoS)) {
-                        // rare: the reference's gradient is exactly zero outside [-kLogitLo, kLogitHi]
+        }
+        s_log += fast_log2(pr0) + fast_log2(pr1);
+        asm volatile("" : "+v"(s_log));          // (keeps hipcc from sinking the whole batch's products to the loop end)
+        if constexpr (GRAD) {
+            acc_b[u][t] += ((gl[0] + gl[1]) + (gl[2] + gl[3])) + ((gl[4] + gl[5]) + (gl[6] + gl[7]));
+            asm volatile("" : "+v"(acc_b[u][t]));
+            if constexpr (IRT == 3) asm volatile("" : "+v"(acc_g[u][t]));
+            KTileOps ko;              // (the transposed reads fly under the split below)
+#ifndef VIBO_X_NOGT
+            if constexpr (pend) ktile_read(std::integral_constant<int, (t == 2 ? u : 0)>{}, std::integral_constant<int, (t == 2 ? 0 : 1)>{}, ko);
+#endif
+            // f16 hi/lo pieces of g: hi = rtz(g), lo = f16(g - hi) by two mixed-precision fmas writing the two halves
+            half2v hh[4], ll[4];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) gl[k] = (lg[k] < -kLoS || lg[k] > kHiS) ? 0.f : gl[k];
-                    }
-                }
-                acc_b[u][t] += ((gl[0] + gl[1]) + (gl[2] + gl[3])) + ((gl[4] + gl[5]) + (gl[6] + gl[7]));
-                asm volatile("" : "+v"(acc_b[u][t]));
-                if constexpr (IRT == 3) asm volatile("" : "+v"(acc_g[u][t]));
-                half2v hh[4], ll[4];
-#pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2) {
-                    hh[k2] = pkrtz(gl[2 * k2], gl[2 * k2 + 1]);
-                    ll[k2] = pkrtz(gl[2 * k2] - (float)hh[k2][0], gl[2 * k2 + 1] - (float)hh[k2][1]);
-                }
-                const half8 a2h = cat8(hh[0], hh[1], hh[2], hh[3]), a2l = cat8(ll[0], ll[1], ll[2], ll[3]);
-                if constexpr (IRT != 1) {
-                    acc_ga[u][t] = mfma16(a2h, B2, acc_ga[u][t]);
-                    acc_ga[u][t] = mfma16(a2l, B2, acc_ga[u][t]);
-                }
-                // LDS image for the transposed read: persons of M-tile 0 = registers 0-1, M-tile 1 = registers 2-3
-                _Float16* wp = &wl.tr[0][0][0] + wofs + 256 * t;
-                *reinterpret_cast<uint2*>(wp) = uint2{__builtin_bit_cast(uint32_t, hh[0]), __builtin_bit_cast(uint32_t, hh[1])};
-                *reinterpret_cast<uint2*>(wp + 1024) = uint2{__builtin_bit_cast(uint32_t, hh[2]), __builtin_bit_cast(uint32_t, hh[3])};
-                *reinterpret_cast<uint2*>(wp + 2048) = uint2{__builtin_bit_cast(uint32_t, ll[0]), __builtin_bit_cast(uint32_t, ll[1])};
-                *reinterpret_cast<uint2*>(wp + 3072) = uint2{__builtin_bit_cast(uint32_t, ll[2]), __builtin_bit_cast(uint32_t, ll[3])};
-                if constexpr (t & 1) {
-                    constexpr int kt = t >> 1;
-                    const _Float16* rp = &wl.tr[0][0][0] + rofs + 512 * kt;
-                    const _Float16* ip = &wl.img[u][0] + b3ofs + 2 * kt * kMsItemRow;
-                    const half8 b3 = cat8(lds_tr16(ip), lds_tr16(ip + kMsItemRow));
-#pragma unroll
-                    for (int hl = 0; hl < 2; ++hl)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            const _Float16* r0 = rp + 1024 * (2 * hl + mt);
-                            const half8 a3 = cat8(lds_tr16(r0), lds_tr16(r0 + 256));
-                            acc_gt[mt] = mfma16(a3, b3, acc_gt[mt]);
-                        }
-                }
+            for (int k2 = 0; k2 < 4; ++k2) {
+                hh[k2] = pkrtz(gl[2 * k2], gl[2 * k2 + 1]);
+                uint32_t lw;
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hh[k2]), "v"(gl[2 * k2]));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hh[k2]), "v"(gl[2 * k2 + 1]));
+                ll[k2] = __builtin_bit_cast(half2v, lw);
             }
-        };
-        tile(std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        tile(std::integral_constant<int, 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        tile(std::integral_constant<int, 2>{});
-        __builtin_amdgcn_sched_barrier(0);
-        tile(std::integral_constant<int, 3>{});
+            const half8 a2h = cat8(hh[0], hh[1], hh[2], hh[3]), a2l = cat8(ll[0], ll[1], ll[2], ll[3]);
+#ifndef VIBO_X_NOGT
+            if constexpr (pend) ktile_mfma(ko);
+#endif
+#ifndef VIBO_X_NOGA
+            if constexpr (IRT != 1) {
+                acc_ga[u][t] = mfma16(a2h, B2, acc_ga[u][t]);
+                acc_ga[u][t] = mfma16(a2l, B2, acc_ga[u][t]);
+            }
+#else
+            asm volatile("" :: "v"(a2h), "v"(a2l));
+#endif
+#ifndef VIBO_X_NOGT
+            // LDS image for the transposed read: persons of M-tile 0 = registers 0-1, M-tile 1 = registers 2-3
+            _Float16* wp = &wl.tr[0][0][0] + wofs + 256 * (t & 1);
+            *reinterpret_cast<uint2*>(wp) = uint2{__builtin_bit_cast(uint32_t, hh[0]), __builtin_bit_cast(uint32_t, hh[1])};
+            *reinterpret_cast<uint2*>(wp + 512) = uint2{__builtin_bit_cast(uint32_t, hh[2]), __builtin_bit_cast(uint32_t, hh[3])};
+            *reinterpret_cast<uint2*>(wp + 1024) = uint2{__builtin_bit_cast(uint32_t, ll[0]), __builtin_bit_cast(uint32_t, ll[1])};
+            *reinterpret_cast<uint2*>(wp + 1536) = uint2{__builtin_bit_cast(uint32_t, ll[2]), __builtin_bit_cast(uint32_t, ll[3])};
+            if constexpr (last) {                 // the batch's last K-tile: nothing left to hide it under
+                KTileOps kl;
+                ktile_read(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, kl);
+                ktile_mfma(kl);
+            }
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
+    using IC0 = std::integral_constant<int, 0>;
+    using IC1 = std::integral_constant<int, 1>;
+    using IC2 = std::integral_constant<int, 2>;
+    using IC3 = std::integral_constant<int, 3>;
     auto put_gtheta = [&](const int par) {
         float v[8];
 #pragma unroll
@@ -586,73 +698,137 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // ================= prologue: first batch =================
     long long bt = blockIdx.x;
     uint32_t cwA0[8], cwA1[8], cwB0[8], cwB1[8];
-    int pk[8];
+    int pk[4];
     const long long G = gridDim.x;
     if (bt < n_batches) {
         fetch_idx(bt);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pk[k] = 0;
-        load_ustep(bt, 0);
-        pack_ustep(bt, 0, cwA0, pk);
-        load_ustep(bt, 1);
-        pack_ustep(bt, 1, cwA1, pk);
+        for (int k = 0; k < 4; ++k) pk[k] = 0;
+        {
+            const RowSrc s0 = row_src(bt);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) load_quarter(bt, s0, h, j);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pack_quarter(bt, h, j, cwA0, cwA1, pk);
+            }
+        }
         put_counts(pk, true);
-        fetch_idx(bt + G);
-        load_ustep(bt + G, 0);
         fetch_eps(bt, 0);
-        __syncthreads();
-        person_forward(bt, 0);
-        __syncthreads();
-        read_theta_ops();
-        fetch_eps(bt + G, 1);
+        asm volatile("" : "+v"(epn));                 // (in before the loop: no wait on it behind the loop's own loads)
     }
     int par = 0;                                      // parity of the workgroup's batch counter: LDS double buffers, slot owners
+#ifdef VIBO_MS_TIMING
+    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = (long long)__builtin_readcyclecounter();
+#endif
+    // One iteration = [request the first half of the next batch's rows] [sync phase of this batch: counts -> theta]
+    // [backward of the previous batch] [math of this batch, with the next batch's rows packed / requested under it].
+    // The rows travel in two halves (M-tile 0, M-tile 1), each requested at least four tiles before it is packed; the first
+    // goes out right before the sync phase (the texture pipeline digests the workgroup's 128 load instructions while the
+    // waves sit in the barriers; issued after them, with all 8 waves in step, every wave stalled ~5000 cycles on it).
+    // Nothing loaded is in flight across the loop's back edge: hipcc otherwise parks such registers in a second set and
+    // copies them at the back edge behind an s_waitcnt vmcnt(0), which serialises the prefetch.  The sched_barriers keep
+    // the loads behind the pack that frees their registers.
     for (; bt < n_batches; bt += G, par ^= 1) {
         const long long nxt = bt + G;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pk[k] = 0;
-        math_ustep(std::integral_constant<int, 0>{}, cwA0);
-        pack_ustep(nxt, 0, cwB0, pk);                 // rows (nxt, u-step 0) have landed under the math
-        load_ustep(nxt, 1);
-        fetch_idx(nxt + G);                      // (the row indices of the batch after that, consumed one u-step later)
-        math_ustep(std::integral_constant<int, 1>{}, cwA1);
-        pack_ustep(nxt, 1, cwB1, pk);
-        load_ustep(nxt + G, 0);
+        for (int k = 0; k < 4; ++k) pk[k] = 0;
+        fetch_idx(nxt);
+        {
+            const RowSrc sn = row_src(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 0, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        MS_T(4)
+        __syncthreads();                              // counts of bt and d LL/d theta shares of bt - G are out
+        MS_T(5)
+        person_forward(bt, par);                      // short: counts -> theta operands (eps came a batch ahead)
+        MS_T(6)
+        __syncthreads();
+        MS_T(7)
+        read_theta_ops();
+        MS_T(8)
+#ifndef VIBO_X_NOBW
+        if constexpr (GRAD) {
+            if (bt >= G + (long long)blockIdx.x) person_backward(bt - G, par ^ 1);   // nobody waits for this
+        }
+#endif
+        MS_T(9)
+        f32x4 da0, da1, db0, db1;
+        logits(IC0{}, IC0{}, da0, da1);
+        tile(IC0{}, IC0{}, da0, da1, db0, db1, cwA0);
+        tile(IC0{}, IC1{}, db0, db1, da0, da1, cwA0);
+        tile(IC0{}, IC2{}, da0, da1, db0, db1, cwA0);
+        tile(IC0{}, IC3{}, db0, db1, da0, da1, cwA0);
+        MS_T(0)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pack_quarter(nxt, 0, j, cwB0, cwB1, pk);
+            fetch_eps(nxt, par ^ 1);                  // (complete by the second pack: free to carry across the back edge)
+            const RowSrc sn = row_src(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 1, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        MS_T(1)
+        tile(IC1{}, IC0{}, da0, da1, db0, db1, cwA1);
+        tile(IC1{}, IC1{}, db0, db1, da0, da1, cwA1);
+        tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1);
+        tile(IC1{}, IC3{}, db0, db1, da0, da1, cwA1);
+        MS_T(2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pack_quarter(nxt, 1, j, cwB0, cwB1, pk);
+        asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
+        MS_T(3)
         put_counts(pk, nxt < n_batches);
         if constexpr (GRAD) put_gtheta(par);
-        __syncthreads();
-        if (nxt < n_batches) person_forward(nxt, par ^ 1);   // short: counts -> theta operands (eps came a batch ahead)
-        __syncthreads();
-        read_theta_ops();
-        fetch_eps(nxt + G, par);
-        if constexpr (GRAD) person_backward(bt, par);     // nobody waits for this: it overlaps the other waves' math
 #pragma unroll
         for (int k = 0; k < 8; ++k) { cwA0[k] = cwB0[k]; cwA1[k] = cwB1[k]; }
     }
+    if constexpr (GRAD) {
+        // backward of the workgroup's last batch
+        __syncthreads();
+        if (bt >= G + (long long)blockIdx.x) person_backward(bt - G, par ^ 1);
+    }
 
+#ifdef VIBO_MS_TIMING
+    if (lane == 0 && blockIdx.x < 1024) {
+        for (int k = 0; k < 12; ++k) g_ms_timing[((size_t)blockIdx.x * 8 + q) * 16 + k] = tacc[k];
+    }
+#endif
     // ================= workgroup reduction -> partial record =================
     float* out = p.partial + (size_t)blockIdx.x * p.lay.stride;
     {
         // 1PL/2PL: every cell without an observation contributed exactly log2(1 + 2^0) = 1 to s_log
         const float ll = (IRT == 3 ? kLn2 : -kLn2) * wave_total(s_log - (float)unobs);
-        const float t_kl = wave_total(s_kl), t_q0 = wave_total(s_logq0), t_lp = wave_total(s_logp);
-        const float t_no = wave_total(s_nobs);
-        if (lane == 0) {
-            wl.red[0] = ll; wl.red[1] = t_kl; wl.red[2] = t_q0; wl.red[3] = t_lp; wl.red[4] = 0.f; wl.red[5] = t_no;
-            wl.red[6] = 0.f; wl.red[7] = 0.f;
-        }
+        if (lane == 0) wl.red[0] = ll;
     }
     __syncthreads();
-    if (tid < 8) {
+    // scalars: 0 ll | 1 kl | 2 logq0 | 3 logp | 4 ladj | 5 nobs
+    if (tid == 0) {
         float t = 0.f;
-        for (int w = 0; w < nw; ++w) t += wls[w].red[tid];
-        out[tid] = (tid < 6) ? t : 0.f;
+        for (int w = 0; w < nw; ++w) t += wls[w].red[0];
+        out[0] = t;
+        out[4] = 0.f; out[6] = 0.f; out[7] = 0.f;
+    }
+    if (tid < 4) {                            // sums of the (person, dim) pairs' running terms, fixed order
+        const int k = 8 + tid;
+        float t = 0.f;
+        for (int par2 = 0; par2 < 2; ++par2)
+            for (int e = 0; e < 256; ++e) t += cl.tacc[par2][k][e];
+        out[k == 8 ? 1 : k == 9 ? 2 : k == 10 ? 3 : 5] = t;
     }
     if constexpr (GRAD) {
         if (tid < 8 * A) {
             const int a = tid >> 3, k = tid & 7;
             float t = 0.f;
-            for (int w = 0; w < nw; ++w) t += cl.tred[w][k][a];
+            for (int par2 = 0; par2 < 2; ++par2)
+                for (int e = a; e < 256; e += 8) t += cl.tacc[par2][k][e];
             const int st = k >> 2, c = (k >> 1) & 1, ms = k & 1;
             out[p.lay.off_table + (st * 2 + c) * 2 * A + ms * A + a] = t;
         }
