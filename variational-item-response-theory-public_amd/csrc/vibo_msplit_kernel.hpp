@@ -247,9 +247,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     };
     // quarter (h, j) = person 4 h + j of the lane (row 4 g + j + 16 h of the batch), both chunks: 2 x 16 B + 2 x 4 B
     auto load_quarter = [&](const long long bt, const RowSrc& rs, const int h, const int j) {
-#ifdef VIBO_MS_NOLOAD
-        if (bt >= 2 * (long long)gridDim.x) return;
-#endif
         bool linear = RM == 0;
         if constexpr (RM == 2) linear = p.row_index == nullptr;
         if (linear) {
@@ -629,9 +626,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             asm volatile("" : "+v"(acc_b[u][t]));
             if constexpr (IRT == 3) asm volatile("" : "+v"(acc_g[u][t]));
             KTileOps ko;              // (the transposed reads fly under the split below)
-#ifndef VIBO_X_NOGT
             if constexpr (pend) ktile_read(std::integral_constant<int, (t == 2 ? u : 0)>{}, std::integral_constant<int, (t == 2 ? 0 : 1)>{}, ko);
-#endif
             // f16 hi/lo pieces of g: hi = rtz(g), lo = f16(g - hi) by two mixed-precision fmas writing the two halves
             half2v hh[4], ll[4];
 #pragma unroll
@@ -643,18 +638,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 ll[k2] = __builtin_bit_cast(half2v, lw);
             }
             const half8 a2h = cat8(hh[0], hh[1], hh[2], hh[3]), a2l = cat8(ll[0], ll[1], ll[2], ll[3]);
-#ifndef VIBO_X_NOGT
             if constexpr (pend) ktile_mfma(ko);
-#endif
-#ifndef VIBO_X_NOGA
             if constexpr (IRT != 1) {
                 acc_ga[u][t] = mfma16(a2h, B2, acc_ga[u][t]);
                 acc_ga[u][t] = mfma16(a2l, B2, acc_ga[u][t]);
             }
-#else
-            asm volatile("" :: "v"(a2h), "v"(a2l));
-#endif
-#ifndef VIBO_X_NOGT
             // LDS image for the transposed read: persons of M-tile 0 = registers 0-1, M-tile 1 = registers 2-3
             _Float16* wp = &wl.tr[0][0][0] + wofs + 256 * (t & 1);
             *reinterpret_cast<uint2*>(wp) = uint2{__builtin_bit_cast(uint32_t, hh[0]), __builtin_bit_cast(uint32_t, hh[1])};
@@ -666,7 +654,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 ktile_read(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, kl);
                 ktile_mfma(kl);
             }
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -736,13 +723,24 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = 0;
         fetch_idx(nxt);
-        {
+        auto burst_a = [&]() {
             const RowSrc sn = row_src(nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 0, j);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        auto pack_a_burst_b = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pack_quarter(nxt, 0, j, cwB0, cwB1, pk);
+            fetch_eps(nxt, par ^ 1);                  // (complete by the second pack: free to carry across the back edge)
+            const RowSrc sn = row_src(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 1, j);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        burst_a();
         MS_T(4)
         __syncthreads();                              // counts of bt and d LL/d theta shares of bt - G are out
         MS_T(5)
@@ -752,11 +750,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         MS_T(7)
         read_theta_ops();
         MS_T(8)
-#ifndef VIBO_X_NOBW
         if constexpr (GRAD) {
             if (bt >= G + (long long)blockIdx.x) person_backward(bt - G, par ^ 1);   // nobody waits for this
         }
-#endif
         MS_T(9)
         f32x4 da0, da1, db0, db1;
         logits(IC0{}, IC0{}, da0, da1);
@@ -765,16 +761,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         tile(IC0{}, IC2{}, da0, da1, db0, db1, cwA0);
         tile(IC0{}, IC3{}, db0, db1, da0, da1, cwA0);
         MS_T(0)
-        {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(nxt, 0, j, cwB0, cwB1, pk);
-            fetch_eps(nxt, par ^ 1);                  // (complete by the second pack: free to carry across the back edge)
-            const RowSrc sn = row_src(nxt);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 1, j);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        pack_a_burst_b();
         MS_T(1)
         tile(IC1{}, IC0{}, da0, da1, db0, db1, cwA1);
         tile(IC1{}, IC1{}, db0, db1, da0, da1, cwA1);
