@@ -19,11 +19,20 @@ Adds to the contract line:
   roofline      the fused kernel's achieved HBM GB/s = algorithmic bytes (5 + 12A/I per term) x terms
                 per launch / its average duration, measured with HIP events on the launch stream (an eager pass of
                 the same step right after the timed region when the step is graph-replayed); peak 8000 GB/s
-                (MI355X_MICROARCH.md), also as a fraction of the 6290 GB/s measured copy ceiling; traffic = recorded
-                2*FETCH_SIZE + WRITE_SIZE of the same command (profiles/r01_bench_profile.txt).
-  cpu_baseline  the CPU oracle port of the reference op sequence (per-term MLP -> PoE -> link -> masked log-lik ->
-                autograd -> Adam, oracle/vibo_oracle.py) timed on this host's cores on a bounded sample (rank 0,
-                N = 1 only).
+                (MI355X_MICROARCH.md), also as a fraction of the 6290 GB/s measured copy ceiling; traffic = the
+                2*FETCH_SIZE + WRITE_SIZE of the kernel PARSED from the committed rocprofv3 summary of this command
+                (profiles/r02_bench_profile.txt, written by tools/collect_profile.sh; null when the file or the kernel's
+                line is missing -- nothing is hard-coded here).
+  elbo_rel_err  |ELBO_hip - ELBO_ref| / |ELBO_ref| on the first 1024 persons of the benchmark matrix, same parameters
+                and noise, in the same run: ref = the CPU restatement of the reference op sequence (fp32, the
+                reference's arithmetic); also against its fp64 evaluation.
+  extra         train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md §8d;
+                rows gathered in the kernel, hipGraph replay); the headline is the full shard.
+  cpu_baseline  the CPU port of the reference op sequence (per-term MLP -> PoE -> link -> masked log-lik -> autograd ->
+                Adam, oracle/vibo_oracle.py) timed on this host's cores (rank 0, N = 1 only): B = 16 and B = 1024, 3
+                warm-ups + 20 steps each, CPU model and thread count stated; `validated_ratio` = port / REAL reference
+                throughput measured in the build container by tools/validate_cpu_port.py (profiles/r02_cpu_port_validation.json).
+  --scaling strong   divides --persons (the whole matrix) over the ranks instead of giving every rank --persons rows.
 """
 import argparse
 import json
@@ -54,8 +63,9 @@ def parse():
     ap.add_argument('--lr', type=float, default=5e-3)
     ap.add_argument('--seed', type=int, default=42)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=2048)
-    ap.add_argument('--cpu-steps', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=20)
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak', help="'strong': --persons is the whole matrix, split over the ranks (BASELINE configs[2]: 1M x 1k over 8 GPUs)")
+    ap.add_argument('--no-extra', action='store_true', help='skip the minibatch-size sweep and the ELBO rel-err check')
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
     ap.add_argument('--ability-merge', choices=['product', 'mean'], default='product', help="'mean': the reference's other encoder (models.py:631-650) through VIBO_POSTERIOR_GIVEN + torch autograd / Adam (implies --torch-optimizer --no-graph)")
     ap.add_argument('--no-format-p', action='store_true', help='skip the extra Format P (1-byte cell codes) measurement of the same step')
@@ -94,25 +104,40 @@ def synth_responses(irt, P, I, A, missing, device, seed):
     return resp, mask
 
 
-def cpu_baseline(args, irt):
-    """Reference op sequence on the host cores (oracle port), train step, bounded sample."""
-    from oracle import vibo_oracle as O
-    A, I, B = args.ability_dim, args.items, args.cpu_batch
-    g = torch.Generator().manual_seed(args.seed)
-    resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=0.0)
-    params = {k: v.requires_grad_(True) for k, v in O.init_params(irt, A, I, generator=g).items()}
-    opt = torch.optim.Adam(list(params.values()), lr=args.lr)
+def cpu_model_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
-    def step():
-        opt.zero_grad()
-        out = O.elbo_forward(params, resp, mask, torch.randn(I, O.item_feat_dim(irt, A)), torch.randn(B, A),
-                             irt_model=irt, ability_dim=A)
-        out['loss'].backward()
-        opt.step()
+
+def cpu_baseline(args, irt):
+    """Reference op sequence on the host cores (oracle port), train step, B = 16 and B = 1024."""
+    from oracle import vibo_oracle as O
+    A, I = args.ability_dim, args.items
+    all_threads = torch.get_num_threads()
+
+    def make_step(B):
+        g = torch.Generator().manual_seed(args.seed)
+        resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=0.0)
+        mask = mask.long()                      # as the reference's train loop hands it over (vibo.py:240)
+        params = {k: v.requires_grad_(True) for k, v in O.init_params(irt, A, I, generator=g).items()}
+        opt = torch.optim.Adam(list(params.values()), lr=args.lr)
+
+        def step():
+            opt.zero_grad()
+            out = O.elbo_forward(params, resp, mask, torch.randn(I, O.item_feat_dim(irt, A)), torch.randn(B, A),
+                                 irt_model=irt, ability_dim=A)
+            out['loss'].backward()
+            opt.step()
+        return step
 
     # the per-term MLP is many mid-sized ops: on a many-core host the default thread count (all cores) is slower than a
     # moderate one, so probe a few and time the best -- the baseline should be the CPU path at its best
-    all_threads = torch.get_num_threads()
+    step = make_step(1024)
     step()
     best, best_dt = all_threads, None
     for nt in sorted({min(all_threads, n) for n in (8, 16, 32, 64, all_threads)}):
@@ -124,18 +149,50 @@ def cpu_baseline(args, irt):
         if best_dt is None or d1 < best_dt:
             best, best_dt = nt, d1
     torch.set_num_threads(best)
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-        step()
-    dt = time.perf_counter() - t0
+    res = {}
+    for B in (16, 1024):
+        st = make_step(B)
+        for _ in range(3):
+            st()
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            st()
+        dt = time.perf_counter() - t0
+        res[B] = B * I * args.cpu_steps / dt
     torch.set_num_threads(all_threads)
+    validated = None
+    try:
+        v = json.load(open(os.path.join(ROOT, 'profiles', 'r02_cpu_port_validation.json')))
+        validated = {'b16': v['b16']['ratio_port_over_reference_throughput'], 'b1024': v['b1024']['ratio_port_over_reference_throughput'],
+                     'threads': v['threads'], 'where': 'build container, tools/validate_cpu_port.py (real reference imported there)'}
+    except (OSError, KeyError, ValueError):
+        pass
     return {
-        'value': B * I * args.cpu_steps / dt, 'unit': 'terms/s', 'cores': best,
-        'kind': 'port', 'host_threads_available': all_threads,
-        'sample': f'{args.cpu_steps} train steps of {B} persons x {I} items (ability_dim {A}, no missing), '
-                  f'oracle/vibo_oracle.py = reference op sequence incl. per-term encoder MLP, autograd, Adam; '
-                  f'thread count = best of a short probe over 8..{all_threads}',
+        'value': res[1024], 'unit': 'terms/s', 'cores': best, 'kind': 'port',
+        'b16': res[16], 'b1024': res[1024], 'cpu_model': cpu_model_name(), 'host_threads_available': all_threads,
+        'validated_ratio': validated,
+        'sample': f'3 warm-ups + {args.cpu_steps} train steps each of 16 and of 1024 persons x {I} items (ability_dim {A}, no '
+                  f'missing, value = the B = 1024 rate), oracle/vibo_oracle.py = reference op sequence incl. per-term encoder MLP '
+                  f'(in-place ELU), torch.distributions Bernoulli, autograd, Adam; thread count = best of a short probe over 8..{all_threads}',
     }
+
+
+def parse_traffic(kernel_tag):
+    """2 * FETCH_SIZE + WRITE_SIZE (KiB counters -> bytes, gfx950 correction of MI355X_MICROARCH.md) of the kernel whose
+    mangled name contains `kernel_tag`, from the committed rocprofv3 summary of this command; None if absent."""
+    path = os.path.join(ROOT, 'profiles', 'r02_bench_profile.txt')
+    vals = {}
+    try:
+        for ln in open(path):
+            t = ln.split()
+            if len(t) >= 3 and kernel_tag in t[0] and t[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                vals.setdefault(t[1], float(t[2]))
+    except OSError:
+        return None, 'profiles/r02_bench_profile.txt not found'
+    if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
+        return None, f'no FETCH_SIZE / WRITE_SIZE line for {kernel_tag} in profiles/r02_bench_profile.txt'
+    return (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, \
+        f'parsed from profiles/r02_bench_profile.txt: 2*FETCH_SIZE + WRITE_SIZE of {kernel_tag} (KiB counters, separate --pmc passes)'
 
 
 def main():
@@ -162,9 +219,11 @@ def main():
     from vibo_amd import ops
     from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
 
-    def measure(A, codes=False):
+    persons_rank = args.persons if args.scaling == 'weak' else (args.persons * (rank + 1)) // world - (args.persons * rank) // world
+
+    def measure(A, codes=False, extra=False):
         """-> dict(dt, kern_ms, final_loss, graph) for ability_dim A on this rank's shard."""
-        P, I = args.persons, args.items
+        P, I = persons_rank, args.items
         resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
         if codes:           # Format P: the same matrix as one byte per cell (VIBO_MASK_CODES)
             resp, mask = ops.pack_cell_codes(resp, mask), None
@@ -185,7 +244,10 @@ def main():
         native = ops._BACKEND['elbo']
         recording = {'on': False}
 
+        last_call = {}
+
         def timed_native(*a, **k):
+            last_call['a'], last_call['k'] = a, k
             if not recording['on']:
                 return native(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -289,25 +351,98 @@ def main():
             torch.cuda.synchronize()
             recording['on'] = False
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+        if last_call:
+            # sustained-load duration of the fused call: the same launch (item_prep + ELBO kernel + finalize) 10 times back to
+            # back between one pair of events -- single launches inside an eager step run ~10 % faster than under the
+            # steady load of the replayed graph (launch gaps let the clocks recover), and that is not the number to quote
+            reps = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            native(*last_call['a'], **last_call['k'])
+            e0.record()
+            for _ in range(reps):
+                native(*last_call['a'], **last_call['k'])
+            e1.record()
+            torch.cuda.synchronize()
+            kern_ms = max(kern_ms, e0.elapsed_time(e1) / reps)
         bytes_per_term = 5.0 + 12.0 * A / I
         achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         ops._BACKEND['elbo'] = native
+        rel, sweep = None, None
+        if extra and not codes and rank == 0:
+            rel = elbo_rel_err(model, resp, mask, A)
+            if trainer is not None and dist is None:
+                sweep = batch_sweep(model, resp, mask, A)
         del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()
-        return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None)
+        return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None, rel=rel, sweep=sweep)
 
-    P, I, A = args.persons, args.items, args.ability_dim
-    m = measure(A)
+    def elbo_rel_err(model, resp, mask, A, n=1024):
+        """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64)."""
+        from oracle import vibo_oracle as O
+        I = args.items
+        n = min(n, resp.shape[0])
+        g = torch.Generator(device=dev).manual_seed(args.seed + 7)
+        eps_i = torch.randn(I, O.item_feat_dim(irt, A), device=dev, generator=g)
+        eps_a = torch.randn(n, A, device=dev, generator=g)
+        r, m = resp[:n].contiguous(), mask[:n].contiguous()
+        with torch.no_grad():
+            hip = float(model.elbo(*model(r, m, eps_item=eps_i, eps_ability=eps_a)))
+        out = {}
+        for name, dt_ in (('fp32', torch.float32), ('fp64', torch.float64)):
+            params = {k: v.detach().cpu().to(dt_) for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                ref = float(O.elbo_forward(params, r.cpu().to(dt_), m.cpu(), eps_i.cpu().to(dt_), eps_a.cpu().to(dt_),
+                                           irt_model=irt, ability_dim=A)['loss'])
+            out[name] = abs(hip - ref) / abs(ref)
+        return {'persons': n, 'vs_reference_op_sequence_fp32': out['fp32'], 'vs_same_in_fp64': out['fp64'], 'elbo_hip': hip}
+
+    def batch_sweep(model, resp, mask, A):
+        """Train-step rate at the minibatch sizes SURVEY.md §8d names (rows gathered in the kernel, hipGraph replay)."""
+        from vibo_amd.trainer import FusedTrainer
+        P, I = resp.shape
+        res = {}
+        for B in (16, 4096, 65536):
+            if B >= P:
+                continue
+            tr = FusedTrainer(model, lr=args.lr, rng='native', seed=args.seed + B)
+            rows = torch.randperm(P, device=dev)[:B].contiguous()
+            st = lambda: tr.step(resp, mask, row_index=rows)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    st()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                st()
+            n_it = max(20, min(1000, int(1e9 // (B * I)) or 20))
+            for _ in range(5):
+                gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                gr.replay()
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - t0) / n_it
+            res[str(B)] = {'us_per_step': d * 1e6, 'terms_per_s': B * I / d}
+            del tr, gr
+        return res
+
+    P, I, A = persons_rank, args.items, args.ability_dim
+    m = measure(A, extra=not args.no_extra)
     dt, kern_ms, final_loss = m['dt'], m['kern_ms'], m['final_loss']
     bytes_per_term = 5.0 + 12.0 * A / I
     achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    total_persons = float(args.persons) * (world if args.scaling == 'weak' else 1)
     also = None
     if args.also_ability_dim and args.also_ability_dim != A:
         A2 = args.also_ability_dim
         m2 = measure(A2)
         b2 = 5.0 + 12.0 * A2 / I
         also = {'workload': f'same, ability_dim={A2} (BASELINE configs[1] shape at 1M persons)',
-                'value': float(P) * I * args.steps * world / m2['dt'], 'ms_per_step': m2['dt'] / args.steps * 1e3,
+                'value': total_persons * I * args.steps / m2['dt'], 'ms_per_step': m2['dt'] / args.steps * 1e3,
                 'kernel_ms': m2['kern_ms'], 'roofline_achieved_GBps': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9,
                 'roofline_frac': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 8000.0,
                 'roofline_frac_of_measured_copy_peak': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 6290.0}
@@ -318,46 +453,45 @@ def main():
         b3 = 1.0 + 12.0 * A / I
         format_p = {'workload': 'same matrix and step as the headline, rows stored as 1-byte cell codes (Format P, VIBO_MASK_CODES): '
                                 'reported separately, its own bytes figure, never mixed with the headline roofline',
-                    'value': float(P) * I * args.steps * world / m3['dt'], 'unit': 'terms/s', 'ms_per_step': m3['dt'] / args.steps * 1e3,
+                    'value': total_persons * I * args.steps / m3['dt'], 'unit': 'terms/s', 'ms_per_step': m3['dt'] / args.steps * 1e3,
                     'kernel_ms': m3['kern_ms'], 'bytes_per_term': b3,
                     'roofline_achieved_GBps': b3 * P * I / (m3['kern_ms'] * 1e-3) / 1e9,
                     'roofline_frac': b3 * P * I / (m3['kern_ms'] * 1e-3) / 1e9 / 8000.0,
-                    'bound': 'valu (latency / issue), not hbm', 'final_loss_per_term': m3['final_loss'] / (P * I * world)}
+                    'bound': 'valu (latency / issue), not hbm', 'final_loss_per_term': m3['final_loss'] / (total_persons * I)}
 
-    # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of
-    # MI355X_MICROARCH.md) cannot be collected from inside this process; for the default workload the value
-    # recorded in profiles/r01_bench_profile.txt is reported, otherwise null.
-    traffic, traffic_note = None, 'not measured for this workload'
-    recorded = {8: (2 * 2461234 + 111894) * 1024.0, 1: (2 * 2453304 + 15751) * 1024.0}     # KiB counters -> bytes
-    recorded_p = {8: (2 * 508101 + 111894) * 1024.0}                                        # Format P launch (cell codes)
-    if (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and A in recorded:
-        traffic = recorded[A]
-        traffic_note = 'recorded measurement: profiles/r01_bench_profile.txt (2*FETCH_SIZE + WRITE_SIZE of vibo::split_kernel, KiB)'
-    if also is not None and (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and args.also_ability_dim in recorded:
-        also['traffic'] = recorded[args.also_ability_dim]
-    if format_p is not None and (P, I, irt, abs(args.missing - 0.1) < 1e-9) == (1_000_000, 1000, 2, True) and A in recorded_p:
-        format_p['traffic'] = recorded_p[A]
+    # HBM bytes per launch: parsed from the committed rocprofv3 summary of this command (tools/collect_profile.sh); only
+    # meaningful for the workload that summary was taken on (the default one)
+    default_wl = (args.persons, I, irt, abs(args.missing - 0.1) < 1e-9, world) == (1_000_000, 1000, 2, True, 1)
+    kernel_tag = f'msplit_kernelILi{irt}ELb{0 if args.eval_only else 1}ELi0E'
+    traffic, traffic_note = (parse_traffic(kernel_tag) if default_wl and A == 8 else (None, 'not measured for this workload'))
+    if format_p is not None and default_wl and A == 8:
+        format_p['traffic'], _ = parse_traffic(f'msplit_kernelILi{irt}ELb{0 if args.eval_only else 1}ELi2E')
     if rank == 0:
-        terms = float(P) * I * args.steps * world
+        terms = total_persons * I * args.steps
         line = {
             'metric': 'person x item ELBO terms/sec (train step: fwd + bwd + all-reduce + Adam)'
                       if not args.eval_only else 'person x item ELBO terms/sec (forward ELBO only)',
             'value': terms / dt, 'unit': 'terms/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU, '
+            'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU{" (" + str(args.persons) + " in total, strong scaling)" if args.scaling == "strong" else ""}, '
                                    f'ability_dim={A}, {args.missing:.0%} missing, {"product-of-experts" if args.ability_merge == "product" else "mean-merge"} encoder, '
                                    f'unconditional posterior, full-shard minibatch',
-                       'global_batch': P * world, 'parallelism': f'person-sharded dp{world}', 'launch': ('hipGraph replay' if (dist is None or args.graph_collective) else 'two hipGraphs around an eager RCCL all-reduce') if m['graph'] else 'eager',
+                       'global_batch': int(total_persons), 'parallelism': f'person-sharded dp{world}', 'launch': ('hipGraph replay' if (dist is None or args.graph_collective) else 'two hipGraphs around an eager RCCL all-reduce') if m['graph'] else 'eager',
                        'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',
                        'noise': 'torch.randn' if (args.torch_optimizer or args.eval_only or args.rng == 'torch') else 'Philox4x32-10 drawn in the prologue kernel (vibo_train_prologue_noise = the vibo_fill_normal streams)',
-                       'final_loss_per_term': final_loss / (P * I * world)},
+                       'final_loss_per_term': final_loss / (total_persons * I)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
                          'traffic': traffic, 'traffic_note': traffic_note,
-                         'kernel': 'vibo::split_kernel (+ item_prep, finalize helpers inside the timed events)',
+                         'kernel': 'vibo::msplit_kernel (+ item_prep, finalize helpers inside the timed events)',
                          'kernel_ms': kern_ms, 'bytes_per_term': bytes_per_term},
         }
+        if m.get('rel') is not None:
+            line['elbo_rel_err'] = m['rel']['vs_reference_op_sequence_fp32']
+            line['elbo_rel_err_detail'] = m['rel']
+        if m.get('sweep'):
+            line['extra'] = {'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
         if also is not None:
             line['also'] = also
         if format_p is not None:

@@ -47,8 +47,9 @@ def item_feat_dim(irt_model, ability_dim):
 
 def encoder_mlp(params, x, prefix='ability_encoder.mlp'):
     """Linear -> ELU -> Linear -> ELU -> Linear on rows of x."""
-    h = F.elu(F.linear(x, params[f'{prefix}.0.weight'], params[f'{prefix}.0.bias']))
-    h = F.elu(F.linear(h, params[f'{prefix}.2.weight'], params[f'{prefix}.2.bias']))
+    # nn.ELU(inplace=True) in the reference (models.py:575-582): the same in-place kernels forward and backward
+    h = F.elu(F.linear(x, params[f'{prefix}.0.weight'], params[f'{prefix}.0.bias']), inplace=True)
+    h = F.elu(F.linear(h, params[f'{prefix}.2.weight'], params[f'{prefix}.2.bias']), inplace=True)
     return F.linear(h, params[f'{prefix}.4.weight'], params[f'{prefix}.4.bias'])
 
 
@@ -95,6 +96,13 @@ def ability_posterior(params, response, mask, item_feat, *, ability_dim,
     mu_set, lv_set = torch.chunk(out, 2, dim=1)
     mu_set = mu_set.reshape(B, I, ability_dim).permute(1, 0, 2)   # [I,B,A]
     lv_set = lv_set.reshape(B, I, ability_dim).permute(1, 0, 2)
+    # the reference's own host-side steps (models.py:597-606): a .item() sync on sum(1 - mask), two zero tensors for the
+    # prior experts (allocated whether or not a cell is missing)
+    has_missing = bool(torch.sum(1 - mask.long()).item()) if mask.dtype != torch.bool else not bool(mask.all())
+    p_mu_set, p_lv_set = torch.zeros_like(mu_set), torch.zeros_like(lv_set)   # noqa: F841  (prior experts, models.py:603-604)
+    if not has_missing:
+        # nothing missing in the batch: the vectorised branch (models.py:626-627), no masking
+        return product_of_experts(mu_set, lv_set)
     obs = mask.to(mu_set.dtype).t().unsqueeze(2)                    # [I,B,1]
     if replace_missing_with_prior:
         mu_set = mu_set * obs            # prior expert: mu 0
@@ -135,7 +143,10 @@ def masked_bernoulli_ll(x, mask, probs):
     """Bernoulli(probs).log_prob(x) * mask with torch.distributions' numerics:
     probs are clamped to [eps, 1-eps] (eps = float32 machine eps), converted to
     logits, and scored with BCE-with-logits."""
-    eps = torch.finfo(probs.dtype).eps
+    if probs.dtype == torch.float32:
+        # the reference's own call (utils.py:46-49): same library path, same host-side cost per step
+        return torch.distributions.Bernoulli(probs=probs, validate_args=False).log_prob(x) * mask.float()
+    eps = torch.finfo(torch.float32).eps if probs.dtype == torch.float32 else torch.finfo(probs.dtype).eps
     pc = probs.clamp(min=eps, max=1.0 - eps)
     logits = torch.log(pc) - torch.log1p(-pc)
     return -F.binary_cross_entropy_with_logits(logits, x, reduction='none') * mask.to(probs.dtype)
@@ -160,8 +171,10 @@ def elbo_forward(params, response, mask, eps_item, eps_ability, *, irt_model,
     """One ELBO evaluation.  Returns a dict with ``loss`` (= -ELBO summed over
     the minibatch, models.py:443) and every intermediate forward() returns."""
     irt_model = int(irt_model)
-    item_mu = params['item_encoder.mu_lookup.weight']
-    item_lv = params['item_encoder.logvar_lookup.weight']
+    # ItemInferenceNetwork (models.py:713-726): both embeddings looked up for ALL items every step
+    item_index = torch.arange(params['item_encoder.mu_lookup.weight'].shape[0])
+    item_mu = F.embedding(item_index, params['item_encoder.mu_lookup.weight'])
+    item_lv = F.embedding(item_index, params['item_encoder.logvar_lookup.weight'])
     item_feat = eps_item * torch.exp(0.5 * item_lv) + item_mu
     amu, alv = ability_posterior(
         params, response, mask, item_feat, ability_dim=ability_dim,

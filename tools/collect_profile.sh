@@ -8,7 +8,8 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 W=/tmp/vibo_prof; rm -rf $W; mkdir -p $W
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $BENCH_ARGS"
+# (--also-ability-dim 0: ability_dim 1 runs the same kernel instantiation and would blur the per-kernel averages)
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --also-ability-dim 0 $BENCH_ARGS"
 S=$OUT/profile_summary.txt
 {
 echo "# command: rocprofv3 --kernel-trace --stats -- $B"
