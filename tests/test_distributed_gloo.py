@@ -83,3 +83,31 @@ def test_two_rank_shard_sum_equals_single_process(case, tmp_path):
         assert torch.equal(a, b), name
         if float(gref.abs().max()) > 0:
             assert rel_err(a, gref) < 1.5e-3, name        # fp32 CPU stand-in; the reference itself is this noisy on 3PL
+
+
+def _cli_worker(rank, world, port, data_dir, out_dir, num_person):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    from oracle import cpu_backend
+    from vibo_amd import config, ops
+    from vibo_amd.torch_core import vibo as cli
+    cpu_backend.install(ops)
+    config.DATA_DIR, config.OUT_DIR = data_dir, out_dir
+    cli.main(['--irt-model', '2pl', '--dataset', '2pl_simulation', '--num-person', str(num_person), '--num-item', '12',
+              '--epochs', '2', '--batch-size', '16', '--num-posterior-samples', '2', '--no-marginal', '--no-predictive',
+              '--out-dir', out_dir])
+
+
+def test_cli_two_ranks_with_uneven_shards_takes_equal_steps(tmp_path):
+    """1002 persons -> 801 train rows -> shards of 400 and 401 rows at 8 rows per rank and step: 50 vs 51 minibatches if
+    every rank cut its own shard by batch size, i.e. one rank would issue an all-reduce its peer never joins (a hang).
+    Both ranks must take the same number of steps and finish."""
+    world, num_person = 2, 1002
+    data_dir, out_dir = str(tmp_path / 'data'), str(tmp_path / 'out')
+    ctx = mp.spawn(_cli_worker, args=(world, _free_port(), data_dir, out_dir, num_person), nprocs=world, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        assert time.time() - t0 < 240, 'person-sharded CLI run did not finish: ranks disagree on the number of collectives'
+    (run_dir,) = os.listdir(out_dir)
+    ck = torch.load(os.path.join(out_dir, run_dir, 'checkpoint.pth.tar'), weights_only=False)
+    assert ck['infer_dict']['ability_mu'].shape[0] == 801

@@ -224,3 +224,33 @@ def test_log_marginal_matches_reference_golden(name, cpu_ops):
                               eps_item=g.eps_item, eps_ability=g.eps_ability)
     ref = float(g.out['logp'])
     assert abs(float(logp) - ref) < 1e-4 * max(1.0, abs(ref))
+
+
+def test_elbo_accepts_a_materialised_response_mu_and_reruns_with_the_row_index(cpu_ops=None):
+    """(a) a caller that builds response_mu through decode() before elbo() (the reference's predictive code does) gets the
+    fused step's loss; (b) elbo(use_kl_divergence=False) after a KL-mode forward on gathered rows re-runs the step on the
+    same rows with the same item noise."""
+    from oracle import cpu_backend
+    from vibo_amd import ops
+    from vibo_amd.torch_core.models import VIBO_2PL
+    restore = cpu_backend.install(ops)
+    try:
+        torch.manual_seed(3)
+        B, I, A = 40, 24, 2
+        model = VIBO_2PL(A, I, ability_merge='product')
+        resp = (torch.rand(B, I) < 0.5).float()
+        mask = torch.rand(B, I) > 0.2
+        rows = torch.tensor([5, 1, 17, 30, 2, 9, 11, 39])
+        outs = model(resp, mask, row_index=rows)
+        loss_a = model.elbo(*outs)
+        rmu = model.decode(outs[3], outs[6])
+        loss_b = model.elbo(outs[0], outs[1], rmu, *outs[3:])
+        assert torch.equal(loss_a, loss_b)
+        # KL-mode forward, sampled-mode elbo with gradients on: the step is redone on the SAME rows and item noise
+        loss_c = model.elbo(*outs, use_kl_divergence=False)
+        eps_i = model._last_ctx.eps_item
+        outs2 = model(resp[rows], mask[rows], eps_item=eps_i, eps_ability=model._last_ctx.eps_ability)
+        loss_d = model.elbo(*outs2, use_kl_divergence=False)
+        assert abs(float(loss_c) - float(loss_d)) <= 1e-4 * abs(float(loss_d))
+    finally:
+        restore()

@@ -103,9 +103,13 @@ class IRTSimulation(_MatrixDataset):
             data = torch.load(path, weights_only=False)
         elif generate_if_missing:
             # the reference requires `python src/simulate.py` first; do the same thing on the fly
+            # (every rank of a torchrun launch may get here at once: the generator is seeded, so all write the same bytes;
+            # write to a private temporary file and rename it into place atomically so no reader sees a partial file)
             data = generate(irt_model, num_person, num_item, ability_dim, seed=42, nonlinear=nonlinear)
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            torch.save(data, path)
+            tmp = f'{path}.{os.getpid()}.tmp'
+            torch.save(data, tmp)
+            os.replace(tmp, path)
         else:
             raise FileNotFoundError(path)
         response = data['response'].numpy()

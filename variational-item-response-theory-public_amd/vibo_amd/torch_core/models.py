@@ -258,6 +258,8 @@ class VIBO_1PL(nn.Module):
         self.apply(self.weights_init)
 
         self._reducer = None          # set by enable_person_sharding()
+        self._last_ctx = None         # the most recent fused step (elbo() with a materialised response_mu finds it here)
+        self._last_eps_item = None
         self._item_gen = None
         self._ability_gen = None
 
@@ -295,6 +297,7 @@ class VIBO_1PL(nn.Module):
         item_mu, item_lv = self.item_encoder()
         if eps_item is None:
             eps_item = self._randn(item_mu.shape, item_mu, self._item_gen)
+        self._last_eps_item = eps_item          # (kept for elbo()'s re-run in the other regulariser mode)
         item_feat = eps_item * torch.exp(0.5 * item_lv) + item_mu
         return item_feat, item_mu, item_lv
 
@@ -329,7 +332,9 @@ class VIBO_1PL(nn.Module):
         ctx = FusedContext(self, response, mask, eps_ability, table, item_k, flow_packed, reg_mode, heads)
         ctx.item_feat, ctx.item_mu, ctx.item_lv = item_feat, item_mu, item_lv
         ctx.item_k, ctx.item_ladj = item_k, item_ladj
-        ctx.eps_item = eps_item
+        ctx.eps_item = self._last_eps_item          # the item noise actually used, drawn here or handed in
+        ctx.row_index = row_index
+        self._last_ctx = ctx
         return ctx
 
     # ---- reference method surface --------------------------------------------
@@ -365,16 +370,22 @@ class VIBO_1PL(nn.Module):
              item_feat, item_feat_mu, item_feat_logvar, annealing_factor=1, use_kl_divergence=True,
              ability_k=None, item_feat_k=None, ability_logabsdetjac=None, item_logabsdetjac=None):
         """-ELBO summed over the minibatch (models.py:380-443)."""
-        if not isinstance(response_mu, DeferredResponseMu):
-            raise TypeError('elbo() expects the outputs of this model\'s forward(); a materialised '
-                            'response_mu tensor would need a second pass over the responses')
-        ctx = response_mu.ctx
+        if isinstance(response_mu, DeferredResponseMu):
+            ctx = response_mu.ctx
+        else:
+            # a caller that materialised response_mu through decode() first (vibo.py:379-style code): the fused step of
+            # the forward() that produced `ability` is still the one to score -- the tensor itself is not needed
+            last = self._last_ctx
+            ctx = last if (last is not None and (ability is last.ability or ability is last.ability_k)) else None
+            if ctx is None:
+                raise TypeError('elbo() expects the outputs of this model\'s forward(); a response_mu tensor that does '
+                                'not come from it would need a second pass over the responses')
         want_mode = _lib.REG_SAMPLED if (self.n_norm_flows > 0 or not use_kl_divergence) else _lib.REG_KL
         if want_mode != ctx.reg_mode:
             if torch.is_grad_enabled() and ctx.ll.requires_grad:
                 # rare: use_kl_divergence=False asked of a KL-mode forward -> redo the step in SAMPLED mode
                 ctx = self._run_fused(ctx.response, ctx.mask, eps_item=ctx.eps_item,
-                                      eps_ability=ctx.eps_ability, reg_mode=want_mode)
+                                      eps_ability=ctx.eps_ability, reg_mode=want_mode, row_index=ctx.row_index)
                 item_feat, item_feat_mu, item_feat_logvar = ctx.item_feat, ctx.item_mu, ctx.item_lv
                 reg = ctx.reg
             else:

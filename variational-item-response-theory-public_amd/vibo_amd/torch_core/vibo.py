@@ -106,6 +106,24 @@ def finalize_args(args):
     return args
 
 
+def check_supported(args):
+    """The flag table is the reference's (drop-in); the choices outside this engine's path fail here, before any data is
+    loaded, instead of deep inside the model constructor."""
+    problems = []
+    if args.ability_merge == 'transformer':
+        problems.append("--ability-merge transformer (the reference asserts it away as well, models.py:262)")
+    if args.generative_model != 'irt':
+        problems.append(f"--generative-model {args.generative_model} (only the 1PL/2PL/3PL logistic link is on this path)")
+    if args.response_dist != 'bernoulli':
+        problems.append("--response-dist gaussian (the reference's loader has no *_continuous datasets either)")
+    if args.dataset in ('duolingo', 'wordbank', 'pisa2015_science'):
+        problems.append(f"--dataset {args.dataset} (loader not part of this engine: simulation and critlangacq are)")
+    if args.ability_merge == 'mean' and args.conditional_posterior:
+        problems.append("--ability-merge mean together with --conditional-posterior")
+    if problems:
+        raise SystemExit('not supported by the MI355X engine: ' + '; '.join(problems))
+
+
 def out_dir_name(args):
     """vibo.py:127-141."""
     return 'VIBO_{}_{}_{}_{}_{}person_{}item_{}maxperson_{}maxitem_{}maskperc_{}ability_{}_{}_seed{}'.format(
@@ -136,15 +154,26 @@ class ResidentSplit:
             return self.response.rows(index), None
         return self.response[index], self.mask[index]
 
-    def num_batches(self, batch_size):
-        return (self.num_person + batch_size - 1) // batch_size
+    def num_batches(self, batch_size, world_rows=None, world=1):
+        """Minibatches per epoch.  Person-sharded: the count of the LARGEST shard (ceil(world_rows / world) rows), the same
+        number on every rank -- every step carries one collective, so all ranks must take the same number of steps."""
+        rows = self.num_person if world_rows is None else -(-world_rows // world)
+        return (rows + batch_size - 1) // batch_size
 
-    def batches(self, batch_size, shuffle, generator=None):
-        """Row-index vectors (int64, on device); the kernel gathers the rows itself."""
+    def batches(self, batch_size, shuffle, generator=None, n_steps=None):
+        """Row-index vectors (int64, on device); the kernel gathers the rows itself.  With n_steps (person-sharded runs) the
+        shard is cut into exactly that many nearly equal minibatches instead of ceil(rows / batch_size) of them: a rank
+        whose shard is one row shorter must not run one step (= one all-reduce) fewer than its peers."""
         if shuffle:
             order = torch.randperm(self.num_person, device=self.device, generator=generator)
         else:
             order = torch.arange(self.num_person, device=self.device)
+        if n_steps is not None and n_steps != (self.num_person + batch_size - 1) // batch_size:
+            if self.num_person < n_steps:
+                raise ValueError(f'{self.num_person} persons on this rank for {n_steps} steps per epoch: raise --batch-size')
+            for part in torch.tensor_split(order, n_steps):
+                yield part
+            return
         for s in range(0, self.num_person, batch_size):
             yield order[s:s + batch_size]
 
@@ -187,12 +216,12 @@ class GraphedTrainStep:
         return self.loss
 
 
-def train_epoch(model, optimizer, data, args, epoch, batch_size, trainer=None, graphed=None):
+def train_epoch(model, optimizer, data, args, epoch, batch_size, trainer=None, graphed=None, n_steps=None):
     model.train()
-    n_batches = data.num_batches(batch_size)
+    n_batches = n_steps if n_steps is not None else data.num_batches(batch_size)
     wsum = torch.zeros((), device=data.device)
     count = 0
-    for batch_idx, rows in enumerate(data.batches(batch_size, shuffle=True)):
+    for batch_idx, rows in enumerate(data.batches(batch_size, shuffle=True, n_steps=n_steps)):
         beta = annealing_factor(args, epoch, batch_idx, n_batches)
         if graphed is not None:          # the same fused step, replayed from a hipGraph
             loss = graphed(rows, beta)
@@ -210,12 +239,12 @@ def train_epoch(model, optimizer, data, args, epoch, batch_size, trainer=None, g
     return avg
 
 
-def test_epoch(model, data, epoch, batch_size):
+def test_epoch(model, data, epoch, batch_size, n_steps=None):
     model.eval()
     wsum = torch.zeros((), device=data.device)
     count = 0
     with torch.no_grad():
-        for rows in data.batches(batch_size, shuffle=False):
+        for rows in data.batches(batch_size, shuffle=False, n_steps=n_steps):
             wsum += model.elbo_step(data.response, data.mask, row_index=rows) * rows.numel()
             count += rows.numel()
     avg = float(wsum) / max(1, count)
@@ -294,6 +323,7 @@ def imputation_accuracy(inferred, missing_indices, missing_labels):
 
 def main(argv=None):
     args = finalize_args(build_parser().parse_args(argv))
+    check_supported(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(args.gpu_device)))
@@ -342,7 +372,10 @@ def main(argv=None):
     train = ResidentSplit(train_dataset, device, shard(train_dataset.num_person), row_format)
     test = ResidentSplit(test_dataset, device, shard(test_dataset.num_person), row_format)
     local_bs = max(1, args.batch_size // world)
-    n_batches = train.num_batches(local_bs)
+    # steps per epoch: identical on every rank (one all-reduce per step), derived from the largest shard
+    n_batches = train.num_batches(local_bs, train_dataset.num_person, world)
+    n_train_steps = n_batches if world > 1 else None
+    n_test_steps = test.num_batches(local_bs, test_dataset.num_person, world) if world > 1 else None
     if args.max_iters != -1:
         args.epochs = int(math.ceil(args.max_iters / float(n_batches)))
         print(f'Found MAX_ITERS={args.max_iters}, setting EPOCHS={args.epochs}')
@@ -357,7 +390,7 @@ def main(argv=None):
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
     trainer = None
     if (args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and args.ability_merge == 'product'
-            and not args.torch_optimizer):
+            and not args.torch_optimizer and args.hidden_dim <= 256):      # (wider encoders: module + torch.optim.Adam)
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)       # same Adam arithmetic, 5-7 launches per step
     graphed = None
@@ -368,13 +401,13 @@ def main(argv=None):
     train_losses, test_losses, train_times = np.zeros(args.epochs), np.zeros(args.epochs), np.zeros(args.epochs)
     for epoch in range(args.epochs):
         t0 = time.time()
-        train_loss = train_epoch(model, optimizer, train, args, epoch, local_bs, trainer, graphed)
+        train_loss = train_epoch(model, optimizer, train, args, epoch, local_bs, trainer, graphed, n_train_steps)
         if args.cuda:
             torch.cuda.synchronize()
         train_losses[epoch] = train_loss
         train_times[epoch] = t0 - time.time()          # negative, like the reference (vibo.py:467)
         if not args.no_test:
-            test_loss = test_epoch(model, test, epoch, local_bs)
+            test_loss = test_epoch(model, test, epoch, local_bs, n_test_steps)
             test_losses[epoch] = test_loss
             is_best, best_loss = test_loss < best_loss, min(test_loss, best_loss)
         else:

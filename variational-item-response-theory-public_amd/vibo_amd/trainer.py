@@ -64,7 +64,7 @@ class FusedTrainer:
         self.rng, self.seed = rng, int(seed)
         self.fused_noise = bool(fused_noise)      # rng='native': draw the noise inside the prologue launch (2 launches fewer)
         self._eps_item = torch.empty_like(self.item_mu) if rng == 'native' else None
-        self._eps_ab = None
+        self._eps_ab = {}
 
     def set_beta(self, beta):
         """KL weight (vibo.py:223-230).  A device scalar: update it between graph replays when annealing."""
@@ -99,9 +99,11 @@ class FusedTrainer:
         ab_stream = 1 + getattr(model, '_shard_rank', 0)      # item noise: the same on every rank; ability noise: per rank
         if self.rng == 'native':
             eps_item = self._eps_item
-            if self._eps_ab is None or self._eps_ab.shape[0] != B:
-                self._eps_ab = torch.empty(B, model.ability_dim, device=dev)
-            eps_ab = self._eps_ab
+            # one buffer per batch size, never freed or replaced: a captured hipGraph keeps the pointer it was recorded
+            # with, and the epoch's last, shorter minibatch runs eagerly in between the replays
+            eps_ab = self._eps_ab.get(B)
+            if eps_ab is None:
+                eps_ab = self._eps_ab[B] = torch.empty(B, model.ability_dim, device=dev)
         else:
             eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
         if self.rng == 'native' and self.fused_noise:       # noise drawn inside the prologue launch
