@@ -72,7 +72,7 @@ def parse():
     ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
     ap.add_argument('--rng', choices=['native', 'torch'], default='native', help='reparameterisation noise: vibo_fill_normal (Philox, in the C ABI) or torch.randn')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
-    ap.add_argument('--graph-collective', action='store_true', help='multi-GPU: capture the all-reduce inside the step graph instead of two graphs around an eager all-reduce')
+    ap.add_argument('--two-graphs', action='store_true', help='multi-GPU: two hipGraphs around an EAGER all-reduce instead of one graph with the collective captured inside (the default; tests/test_gpu_rccl.py pins both bitwise)')
     ap.add_argument('--force-dist', action='store_true', help='create the process group even for one rank (tests the RCCL path)')
     return ap.parse_args()
 
@@ -260,6 +260,7 @@ def main():
         ops._BACKEND['elbo'] = timed_native
 
         graph = None
+        launch_mode = 'eager'
 
         def step():
             if args.eval_only:
@@ -291,29 +292,47 @@ def main():
                         g.register_generator_state(gen)
                 if opt is not None:
                     opt.zero_grad(set_to_none=False)
-                if dist is not None and trainer is not None and not args.graph_collective:
-                    # person-sharded: two graphs around an EAGER all-reduce (a collective inside a captured graph
-                    # is one more thing that can go wrong on a node this script has never run on)
+                def capture_two():
+                    # person-sharded: two graphs around an EAGER all-reduce
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         static_raw = trainer.forward_backward(resp, mask)
                     with torch.cuda.graph(g2, pool=g.pool()):
                         static_loss = trainer.update()
-                    graph = g
 
-                    def step():
-                        graph.replay()
+                    def step2():
+                        g.replay()
                         dist.all_reduce(static_raw.flat)
                         g2.replay()
                         return static_loss
-                else:
+                    return step2
+
+                def capture_one():
+                    # the whole step in ONE graph, the RCCL all-reduce recorded inside it: no host round trip per step
                     with torch.cuda.graph(g):
                         static_loss = step()
-                    graph = g
 
-                    def step():
-                        graph.replay()
+                    def step1():
+                        g.replay()
                         return static_loss
+                    return step1
+
+                launch_mode = 'hipGraph replay'
+                if dist is not None and trainer is not None:
+                    if args.two_graphs:
+                        step_g, launch_mode = capture_two(), 'two hipGraphs around an eager RCCL all-reduce'
+                    else:
+                        try:
+                            step_g, launch_mode = capture_one(), 'one hipGraph, RCCL all-reduce captured inside'
+                        except Exception as exc:
+                            print(f'[bench] capturing the collective failed ({type(exc).__name__}: {exc}); two graphs around an eager all-reduce', file=sys.stderr)
+                            torch.cuda.synchronize()
+                            g = torch.cuda.CUDAGraph()
+                            step_g, launch_mode = capture_two(), 'two hipGraphs around an eager RCCL all-reduce'
+                else:
+                    step_g = capture_one()
+                graph = g
+                step = step_g
             except Exception as exc:             # never lose the measurement to a capture problem
                 print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
                 graph = None
@@ -374,7 +393,8 @@ def main():
                 sweep = batch_sweep(model, resp, mask, A)
         del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()
-        return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None, rel=rel, sweep=sweep)
+        return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None, rel=rel, sweep=sweep,
+                    launch=launch_mode if graph is not None else 'eager')
 
     def elbo_rel_err(model, resp, mask, A, n=1024):
         """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64)."""
@@ -477,7 +497,7 @@ def main():
             'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU{" (" + str(args.persons) + " in total, strong scaling)" if args.scaling == "strong" else ""}, '
                                    f'ability_dim={A}, {args.missing:.0%} missing, {"product-of-experts" if args.ability_merge == "product" else "mean-merge"} encoder, '
                                    f'unconditional posterior, full-shard minibatch',
-                       'global_batch': int(total_persons), 'parallelism': f'person-sharded dp{world}', 'launch': ('hipGraph replay' if (dist is None or args.graph_collective) else 'two hipGraphs around an eager RCCL all-reduce') if m['graph'] else 'eager',
+                       'global_batch': int(total_persons), 'parallelism': f'person-sharded dp{world}', 'launch': m['launch'],
                        'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',
                        'noise': 'torch.randn' if (args.torch_optimizer or args.eval_only or args.rng == 'torch') else 'Philox4x32-10 drawn in the prologue kernel (vibo_train_prologue_noise = the vibo_fill_normal streams)',
                        'final_loss_per_term': final_loss / (total_persons * I)},

@@ -130,9 +130,9 @@ def test_noise_drawn_in_the_prologue_equals_separate_fills(A, I, B):
     for step in range(3):
         l1, l2 = t1.step(resp, mask), t2.step(resp, mask)
         assert torch.equal(l1, l2), step
-        assert torch.equal(t1._eps_item, t2._eps_item) and torch.equal(t1._eps_ab, t2._eps_ab)
+        assert torch.equal(t1._eps_item, t2._eps_item) and torch.equal(t1._eps_ab[B], t2._eps_ab[B])
     assert int(t1.step_count) == 3 and t1._steps.tolist() == [3, 3]
-    first = t1._eps_ab.clone()
+    first = t1._eps_ab[B].clone()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
@@ -141,7 +141,7 @@ def test_noise_drawn_in_the_prologue_equals_separate_fills(A, I, B):
         graph.replay()
         l2 = t2.step(resp, mask)
         assert torch.equal(lg, l2), step
-    assert not torch.equal(first, t1._eps_ab)    # fresh noise on every replay (the step counters live on the device)
+    assert not torch.equal(first, t1._eps_ab[B])    # fresh noise on every replay (the step counters live on the device)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
 
@@ -203,3 +203,41 @@ def test_trained_model_matches_the_reference_cli_run(tmp_path, monkeypatch, gold
     ours, ref = ck['infer_dict']['item_feat_mu'].cpu().numpy(), z['item_feat_mu']
     r_diff = np.corrcoef(ours[:, a['ability_dim']], ref[:, a['ability_dim']])[0, 1]
     assert r_diff > 0.98, r_diff
+
+
+@pytest.mark.gpu
+def test_graph_replay_survives_a_shorter_eager_minibatch_with_native_noise():
+    """An epoch's last, shorter minibatch runs eagerly between replays of the captured full-size step.  The noise buffer the
+    graph recorded must stay alive and untouched by that (it used to be freed and re-allocated: replays then wrote Philox
+    noise into whatever the allocator had handed out in between)."""
+    import copy
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(9)
+    P, I, A, B = 1000, 64, 2, 128
+    resp, mask = O.simulate_responses(2, P, I, A, generator=g, missing_frac=0.1)
+    resp, mask = resp.to(dev), mask.bool().to(dev)
+    torch.manual_seed(5)
+    m1 = VIBO_2PL(A, I, ability_merge='product').to(dev)
+    m2 = copy.deepcopy(m1)
+    t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=3)
+    t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=3)
+    rows = torch.arange(B, device=dev)
+    tail = torch.arange(P - 40, P, device=dev)
+    for _ in range(2):
+        t1.step(resp, mask, row_index=rows); t2.step(resp, mask, row_index=rows)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lg = t1.step(resp, mask, row_index=rows)
+    ptr = t1._eps_ab[B].data_ptr()
+    for it in range(4):
+        graph.replay()
+        l2 = t2.step(resp, mask, row_index=rows)
+        assert torch.equal(lg, l2), it
+        la, lb = t1.step(resp, mask, row_index=tail), t2.step(resp, mask, row_index=tail)      # eager, other batch size
+        junk = [torch.full((B, A), float('nan'), device=dev) for _ in range(4)]                   # allocator churn
+        assert torch.equal(la, lb), it
+        del junk
+    assert t1._eps_ab[B].data_ptr() == ptr
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -835,15 +835,18 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
 
     float* item_prep = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_item_prep);
     float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_partial);
-    hipLaunchKernelGGL(item_prep_kernel, dim3((I + 15 + 255) / 256), dim3(256), 0, s, item, item_prep, I, A, pl.AT, pl.D,
-                       pl.DP, d->irt_model);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "item_prep launch");
+    hipError_t e = hipSuccess;
+    if (!pl.msplit) {            // (the matrix row-split kernel reads the item sample itself)
+        hipLaunchKernelGGL(item_prep_kernel, dim3((I + 15 + 255) / 256), dim3(256), 0, s, item, item_prep, I, A, pl.AT, pl.D,
+                           pl.DP, d->irt_model);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "item_prep launch");
+    }
 
     ElboParams p;
     memset(&p, 0, sizeof(p));
     p.response = response; p.mask = mask; p.row_index = row_index;
-    p.table = table; p.item_prep = item_prep; p.eps = eps;
+    p.table = table; p.item_prep = item_prep; p.item_raw = item; p.eps = eps;
     p.ability_mu = ability_mu; p.ability_logvar = ability_logvar; p.ability = ability;
     p.partial = partial;
     p.resp_stride = d->response_row_stride; p.mask_stride = d->mask_row_stride;
@@ -877,7 +880,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             e = hipGetLastError();
             p.pre_stats = pre;
             p.pre_panels = 1;
-            p.table = item_prep;          // the 2-row expert table is not used in this mode: any finite floats
+            p.table = item;               // the 2-row expert table is not used in this mode: any finite floats (>= 4 A of them)
         } else if (pl.cond) {
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
                 cp.item0 = pn * 1024;

@@ -137,8 +137,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         cl.ctab[(3 * 2 + c) * 8 + a] = m;
     }
 
-    // ---- item operands of this wave's 128 items (prepped rows, log2 units: [na_0..na_7, nb, guess, 1 - guess]) go to
-    //      a wave-private LDS image as f16 hi/lo pieces; the MFMA operands are read from there when needed:
+    // ---- item operands of this wave's 128 items: read from the caller's [I][D] item sample and brought to the kernel's
+    //      form here (log2 units: na_a = -a_ia log2 e, or +log2 e for 1PL; nb = b_i log2 e; guess = sigmoid -- what
+    //      item_prep_kernel does for the other kernels, without its launch), then to a wave-private LDS image as f16
+    //      hi/lo pieces; the MFMA operands are read from there when needed:
     //   logit MFMA, tile (u, t): lane (item 4 (32 q + 16 u + i16) + t, g) reads 16 B: g 0/2 = na hi, 1 = na lo, 3 = bias pieces
     //   d LL/d theta MFMA, (u, kt): lane (col i16, g) gets k = 8 g + kk <-> item (chunk 4 g + (kk & 3), t = 2 kt + (kk >> 2)) by two
     //   transposed reads of the [na_hi | na_lo] rows
@@ -148,16 +150,18 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int xl = 64 * h + lane;                                   // item of the wave, one per lane and pass
         const int il = kMsSpan * q + xl;
         const bool ok = il < I;
-        const float* ir = p.item_prep + (size_t)(p.item0 + (ok ? il : 0)) * p.DP;
+        const float* ir = p.item_raw + (size_t)(p.item0 + (ok ? il : 0)) * p.D;
         _Float16* dst = &wl.img[h][0] + ((xl & 63) >> 2) * kMsItemLane + (xl & 3) * kMsItemRow;
         half8 hi8, lo8;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
+            float na = 0.f;
+            if (ok && kk < A) na = IRT == 1 ? kLog2e : -ir[kk] * kLog2e;      // models.py:731 / 744,759
             _Float16 hi, lo;
-            split16(ok ? ir[kk] : 0.f, hi, lo);
+            split16(na, hi, lo);
             hi8[kk] = hi; lo8[kk] = lo;
         }
-        const float nb = ok ? ir[8] : 0.f;
+        const float nb = ok ? ir[IRT == 1 ? 0 : A] * kLog2e : 0.f;
         _Float16 b0, b1, b2, b3;
         split16(nb, b0, b1);
         split16(nb - (float)b0 - (float)b1, b2, b3);
@@ -171,9 +175,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         for (int t = 0; t < 4; ++t) {
             const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
             const bool ok = IRT == 3 && il < I;
-            const float* ir = p.item_prep + (size_t)(p.item0 + (ok ? il : 0)) * p.DP;
-            gs[u][t] = ok ? ir[9] : 0.f;
-            om[u][t] = ok ? ir[10] : 1.f;
+            const float gv = ok ? 1.0f / (1.0f + expf(-p.item_raw[(size_t)(p.item0 + il) * p.D + A + 1])) : 0.f;   // models.py:758
+            gs[u][t] = gv;
+            om[u][t] = 1.0f - gv;
         }
     // per-lane offsets (halfs) into the operand image
     const int b1ofs = i16 * kMsItemLane + (g == 1 ? 8 : g == 3 ? 16 : 0);

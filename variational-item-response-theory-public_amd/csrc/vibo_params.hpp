@@ -50,6 +50,7 @@ struct ElboParams {
     const int64_t* row_index;
     const float* table;       // [2][2A]
     const float* item_prep;   // [I][DP] prepped item rows (workspace)
+    const float* item_raw;    // [I][D] the caller's item sample (the matrix row-split kernel preps its own operands)
     const float* eps;         // [B][A]
     float* ability_mu;
     float* ability_logvar;
