@@ -350,6 +350,53 @@ def test_saturation_golden_through_kernel():
         assert abs(float(raw.scalars[_lib.S_LL]) - ll_ref) < 5e-4 * abs(ll_ref)
 
 
+def test_saturation_3pl_golden_through_kernel():
+    """3PL in and around the Bernoulli probability clamp, against the reference (tests/golden/saturation_3pl.npz: p = g +
+    (1 - g) sigmoid(l) through irt_model_3pl and masked_bernoulli_log_pdf).  One person with theta = 0, items with unit
+    discrimination, difficulty = the probe logit, three guess logits.  Where the reference's rounded p sits on the clamp
+    threshold 1 - eps32 (1 to 3 ulp below 1: p is constant over ~0.5 logit there, the decision is a coin flip of its last bit)
+    a cell's O(1) gradient legitimately flips; everywhere else -- below the band, and where p has rounded to 1 -- value and
+    both item gradients must be the reference's, zeros included."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'saturation_3pl.npz'))
+    logit = torch.from_numpy(z['logit'])
+    I = logit.numel()
+    I4 = (I + 3) // 4 * 4
+    spec = ElboSpec(irt_model=3, ability_dim=1)
+    table = torch.zeros(2, 2)
+    eps32 = float(np.finfo(np.float32).eps)
+    for gi, gl in enumerate(z['guess_logit']):
+        item = torch.zeros(I4, 3)
+        item[:I, 0], item[:I, 1], item[:, 2] = 1.0, logit, float(gl)
+        p_ref = torch.from_numpy(z[f'p_g{gi}'])
+        # 1 - p in {1, 2, 3} ulp: a 1-ulp difference in p decides between "clamped" (p > 1 - eps32 = 1 - 2 ulp) and not
+        d1 = 1.0 - p_ref.double()
+        on_edge = (d1 >= 0.5 * 2.0 ** -24) & (d1 <= 3.5 * 2.0 ** -24)
+        assert int(on_edge.sum()) < 0.25 * I          # (half the grid is a dense sweep of the band itself)
+        for x in (0, 1):
+            resp = torch.full((1, I4), float(x))
+            mask = torch.zeros(1, I4, dtype=torch.bool)
+            mask[:, :I] = True
+            raw = run_kernel(spec, resp, mask, table, item, torch.zeros(1, 1))
+            g = raw.grad_item((I4, 3)).cpu()[:I]
+            for col, key in ((1, 'dll_db'), (2, 'dll_dguess')):
+                ref = torch.from_numpy(z[f'{key}_g{gi}_x{x}'])
+                ok = ~on_edge
+                err = (g[:, col] - ref).abs()
+                # the reference forms 1 - p in fp32: its own gradient carries a relative error of ~ulp(1) / (1 - p) there
+                # (3 % at logit 13, where 1 - p is 40 ulp); the kernel works from P(wrong) = (1 - g) sigmoid(-l) directly
+                rel = 2e-4 + 2.0 * 2.0 ** -24 / d1.clamp_min(2.0 ** -24).float()
+                assert float((err[ok] - rel[ok] * ref[ok].abs()).max()) < 3e-6, (gi, x, key)
+                # exact zeros of the reference (p clamped): zero here as well, away from the threshold plateau
+                zero = ok & (ref == 0)
+                assert float(g[zero, col].abs().max() if zero.any() else 0.0) < 1e-6, (gi, x, key)
+            ll_ref = torch.from_numpy(z[f'll_g{gi}_x{x}']).double()
+            # (edge cells can differ by the clamp's jump in the VALUE only through p's last bit: tiny)
+            assert abs(float(raw.scalars[_lib.S_LL]) - float(ll_ref.sum())) < 5e-4 * abs(float(ll_ref.sum()))
+
+
 # ---------------------------------------------------------------------------
 # encode / decode entry points
 # ---------------------------------------------------------------------------

@@ -67,6 +67,7 @@ def make_data(irt, B, I, A, missing, seed):
 CASES = [
     # name, irt, A, B, I, cond, missing, drop, flows, beta, use_kl
     ('2pl_a1_uncond',            2, 1, 16, 20, False, 0.0, False, 0, 1.0, True),
+    ('2pl_a1_config1_b16_i100',  2, 1, 16, 100, False, 0.0, False, 0, 1.0, True),      # BASELINE configs[0]: 100 items, A = 1, batch 16
     ('2pl_a1_uncond_beta05',     2, 1, 37, 95, False, 0.0, False, 0, 0.5, True),
     ('2pl_a8_uncond',            2, 8, 37, 130, False, 0.0, False, 0, 1.0, True),
     ('2pl_a2_uncond_miss_prior', 2, 2, 37, 95, False, 0.2, False, 0, 1.0, True),
@@ -300,6 +301,90 @@ def saturation_case(ref_utils, out_dir):
     np.savez_compressed(os.path.join(out_dir, 'saturation.npz'), **rec)
 
 
+def saturation_3pl_case(ref_models, ref_utils, out_dir):
+    """3PL inside and around the Bernoulli probability clamp: p = g + (1 - g) sigmoid(l) through the reference's own
+    irt_model_3pl (models.py:748-766) and masked_bernoulli_log_pdf (utils.py:46-49), one person with theta = 0 so that the
+    logit of item i is its difficulty.  Stored per guess logit and response value: p (fp32, as the reference rounds it),
+    the log-likelihood and its gradients w.r.t. the difficulty and the guess logit."""
+    l = torch.cat([torch.linspace(-30, 30, 1201, dtype=torch.float64),
+                   torch.linspace(13.0, 19.0, 1201, dtype=torch.float64)]).float()
+    rec = {'logit': l.numpy(), 'guess_logit': np.asarray([-4.0, 0.0, 3.0], dtype=np.float32)}
+    for gi, gl in enumerate(rec['guess_logit']):
+        for x in (0.0, 1.0):
+            item = torch.stack([torch.ones_like(l), l, torch.full_like(l, float(gl))], dim=1).requires_grad_(True)
+            ability = torch.zeros(1, 1)
+            p = ref_models.irt_model_3pl(ability, item)                      # [1, I, 1]
+            ll = ref_utils.masked_bernoulli_log_pdf(torch.full_like(p, x), torch.ones_like(p), p)
+            g, = torch.autograd.grad(ll.sum(), item)
+            rec[f'p_g{gi}'] = p.detach().reshape(-1).numpy()
+            rec[f'll_g{gi}_x{int(x)}'] = ll.detach().reshape(-1).numpy()
+            rec[f'dll_db_g{gi}_x{int(x)}'] = g[:, 1].numpy()
+            rec[f'dll_dguess_g{gi}_x{int(x)}'] = g[:, 2].numpy()
+    np.savez_compressed(os.path.join(out_dir, 'saturation_3pl.npz'), **rec)
+
+
+def seeded_init_case(ref_models, out_dir):
+    """state_dict of the reference classes right after construction under torch.manual_seed: constructor order and
+    weights_init (models.py:281-329, 512-518) -- the drop-in classes must draw the same numbers."""
+    rec = {}
+    cfgs = [('1pl_a1', 1, 1, 12, 'product', False, 0), ('2pl_a2_cond', 2, 2, 12, 'product', True, 0),
+            ('3pl_a1_flows2', 3, 1, 12, 'product', False, 2), ('2pl_a3_mean', 2, 3, 12, 'mean', False, 0)]
+    rec['meta'] = json.dumps([dict(name=n, irt_model=i, ability_dim=a, num_item=I, ability_merge=m, conditional_posterior=c,
+                                   n_norm_flows=f, seed=100 + k) for k, (n, i, a, I, m, c, f) in enumerate(cfgs)])
+    for k, (n, irt, A, I, merge, cond, flows) in enumerate(cfgs):
+        torch.manual_seed(100 + k)
+        cls = {1: ref_models.VIBO_1PL, 2: ref_models.VIBO_2PL, 3: ref_models.VIBO_3PL}[irt]
+        model = cls(A, I, ability_merge=merge, conditional_posterior=cond, n_norm_flows=flows)
+        for key, v in model.state_dict().items():
+            rec[f'{n}.{key}'] = v.detach().numpy().copy()
+        rec[f'{n}.next_randn'] = torch.randn(4).numpy()            # the generator state after construction
+    np.savez_compressed(os.path.join(out_dir, 'seeded_init.npz'), **rec)
+
+
+def critlangacq_case(out_dir):
+    """The reference's CritLangAcq loader (datasets.py:283-440) on a synthetic data.csv: 95 q* columns in the file's own
+    (scrambled) order plus metadata columns, 503 rows, some cells -1.  Stored: the csv's columns as arrays (the test rebuilds
+    the file), and what the reference loads for train / test, with and without max_num_person / max_num_item."""
+    import tempfile
+    import pandas as pd
+    from src import datasets as ref_ds
+    rs = np.random.RandomState(11)
+    keys = ['q1', 'q2', 'q3', 'q5', 'q6', 'q7', 'q9_1', 'q9_4', 'q10_2', 'q10_4', 'q11_3', 'q11_4', 'q12_1', 'q12_2', 'q12_4',
+            'q13_3', 'q13_4', 'q14_3', 'q14_4', 'q15_1', 'q15_2', 'q15_3', 'q16_3', 'q16_4', 'q17_1', 'q17_3', 'q17_4', 'q18_2',
+            'q18_3', 'q18_4', 'q19_1', 'q19_2', 'q19_3', 'q19_4', 'q20_1', 'q20_2', 'q20_3', 'q20_4', 'q21_1', 'q21_2', 'q21_3',
+            'q21_4', 'q22_1', 'q22_2', 'q22_3', 'q22_4', 'q23_3', 'q23_4', 'q24_1', 'q24_2', 'q24_3', 'q24_4', 'q25_1', 'q25_2',
+            'q25_3', 'q25_4', 'q26_1', 'q26_2', 'q26_3', 'q26_4', 'q27_1', 'q27_2', 'q27_3', 'q27_4', 'q28_1', 'q28_2', 'q29_1',
+            'q29_2', 'q29_3', 'q29_4', 'q30_1', 'q30_2', 'q30_3', 'q30_4', 'q31_1', 'q31_4', 'q32_5', 'q32_6', 'q32_8', 'q33_4',
+            'q33_5', 'q33_6', 'q33_7', 'q34_1', 'q34_2', 'q34_3', 'q34_4', 'q34_6', 'q34_8', 'q35_1', 'q35_2', 'q35_4', 'q35_5',
+            'q35_7', 'q35_8']
+    n = 503
+    cols = {'id': np.arange(n), 'age': rs.randint(7, 80, n), 'education': rs.randint(0, 6, n)}
+    file_order = list(keys)
+    rs.shuffle(file_order)                              # the loader must select by name, not by position
+    file_order.insert(7, 'q4_decoy')                    # a q-column that is NOT one of the 95 items
+    for k in file_order:
+        v = (rs.rand(n) < 0.6).astype(np.int64)
+        v[rs.rand(n) < 0.03] = -1
+        cols[k] = v
+    df = pd.DataFrame(cols)
+    rec = {'columns': json.dumps(list(df.columns)), 'table': df.to_numpy().astype(np.int64)}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, 'critlangacq'))
+        df.to_csv(os.path.join(tmp, 'critlangacq', 'data.csv'), index=False)
+        ref_ds.CHILDREN_LANG_DIR = os.path.join(tmp, 'critlangacq')
+        for name, kw in (('train', dict(train=True)), ('test', dict(train=False)),
+                         ('train_cap', dict(train=True, max_num_person=100, max_num_item=40))):
+            d = ref_ds.Children_LanguageAcquisition(**kw)
+            rec[f'{name}.response'] = np.asarray(d.response).astype(np.int64)
+            rec[f'{name}.mask'] = np.asarray(d.mask).astype(np.int64)
+            rec[f'{name}.item_id'] = np.asarray(d.item_id).astype(np.int64)
+            idx, r, iid, m = d[3]
+            rec[f'{name}.getitem3.response'] = r.numpy()
+            rec[f'{name}.getitem3.item_id'] = iid.numpy()
+            rec[f'{name}.getitem3.mask'] = m.numpy()
+    np.savez_compressed(os.path.join(out_dir, 'critlangacq_loader.npz'), **rec)
+
+
 def log_marginal_case(ref_models, out_dir):
     """log_marginal (models.py:445-504) with S=8 under a fixed seed; the eps
     sequence (item then ability, per sample) is stored so it can be replayed."""
@@ -373,6 +458,9 @@ def main():
         print(f'{case[0]:34s} loss={run_mle_case(ref_models, case, out_dir):.6f}')
     if not args.only:
         saturation_case(ref_utils, out_dir)
+        saturation_3pl_case(ref_models, ref_utils, out_dir)
+        seeded_init_case(ref_models, out_dir)
+        critlangacq_case(out_dir)
         log_marginal_case(ref_models, out_dir)
         artificial_mask_case(out_dir)
     print('wrote', out_dir)
