@@ -153,7 +153,10 @@ def test_noise_drawn_in_the_prologue_equals_separate_fills(A, I, B):
 def test_trained_model_matches_the_reference_cli_run(tmp_path, monkeypatch, golden_name):
     """SURVEY §8c trained-model parity: the same seeded dataset and flags through this CLI on the GPU (different noise
     stream) against what the REAL reference CLI produced on CPU (tools/gen_cli_golden.py -> tests/golden/cli_trained_2pl.npz):
-    final train loss within 1 %, head of the test-loss series within 5 %, imputation accuracy within 1 point, inferred ability means and item difficulties correlated > 0.99 / 0.98."""
+    final train loss within max(0.5 %, 1.5 x the reference's own seed-to-seed spread), imputation accuracy within 0.5 point,
+    inferred ability means and item difficulties correlated > 0.99; head of the test-loss series within 5 % (the reference's
+    own seeds differ by 8 % there).  The six shorter runs of the other encoders / links keep 1.5 % / 1.5 points (10-15 epochs:
+    their seed noise was not sampled)."""
     import json
     import os
     import numpy as np
@@ -178,7 +181,21 @@ def test_trained_model_matches_the_reference_cli_run(tmp_path, monkeypatch, gold
     assert run == a['run_dir']                                            # same out-dir name as the reference produced
     ck = torch.load(tmp_path / 'out' / run / 'checkpoint.pth.tar', weights_only=False)
     tr, te = np.load(tmp_path / 'out' / run / 'train_losses.npy'), np.load(tmp_path / 'out' / run / 'test_losses.npy')
-    assert abs(tr[-1] - z['train_losses'][-1]) < 0.015 * z['train_losses'][-1], (tr, z['train_losses'])
+    if golden_name == 'cli_trained_2pl':
+        # Tolerances = SURVEY §8c's contract (final loss 0.5 %, accuracy 0.5 point, r >= 0.99), widened only where the
+        # REFERENCE ITSELF scatters by more from one --seed to the next on this very dataset (tools/gen_cli_golden.py
+        # vibo_seed43 / vibo_seed44: final train loss 469.9 / 466.6 / 467.5, accuracy 0.6297 / 0.6301 / 0.6289, difficulties
+        # r = 0.998 between seeds): our GPU run is one more noise stream, it cannot sit closer to seed 42 than seed 43 does.
+        sib = [np.load(os.path.join(GOLDEN_DIR, f'cli_trained_vibo_seed{k}_2pl.npz')) for k in (43, 44)]
+        ref_loss_spread = max(abs(float(s_['train_losses'][-1]) - float(z['train_losses'][-1])) for s_ in sib) / float(z['train_losses'][-1])
+        ref_acc_spread = max(abs(float(s_['missing_imputation_accuracy']) - float(z['missing_imputation_accuracy'])) for s_ in sib)
+        tol_loss = max(0.005, 1.5 * ref_loss_spread)          # 0.72 % between the reference's own seeds -> 1.1 %
+        tol_acc = max(0.005, 1.5 * ref_acc_spread)            # 0.08 points between seeds -> the contract's 0.5 points
+        assert tol_loss < 0.012 and tol_acc == 0.005
+        assert abs(tr[-1] - z['train_losses'][-1]) < tol_loss * z['train_losses'][-1], (tr, z['train_losses'])
+        assert abs(ck['missing_imputation_accuracy'] - float(z['missing_imputation_accuracy'])) < tol_acc
+    else:
+        assert abs(tr[-1] - z['train_losses'][-1]) < 0.015 * z['train_losses'][-1], (tr, z['train_losses'])
     if golden_name != 'cli_trained_2pl':        # the shorter runs of the other encoders / links: losses (and what the flags leave
         assert abs(tr[0] - z['train_losses'][0]) < 0.05 * z['train_losses'][0]      # switched on) only
         if 'infer_dict' in ck and not np.isnan(float(z['missing_imputation_accuracy'])):
@@ -202,7 +219,7 @@ def test_trained_model_matches_the_reference_cli_run(tmp_path, monkeypatch, gold
     assert abs(r) > 0.99, r
     ours, ref = ck['infer_dict']['item_feat_mu'].cpu().numpy(), z['item_feat_mu']
     r_diff = np.corrcoef(ours[:, a['ability_dim']], ref[:, a['ability_dim']])[0, 1]
-    assert r_diff > 0.98, r_diff
+    assert r_diff > 0.99, r_diff
 
 
 @pytest.mark.gpu

@@ -40,6 +40,12 @@ VARIANTS = {      # extra reference-CLI flags of the additional VIBO runs
 
 def main(script='vibo'):
     variant, extra = script, []
+    cli_seed = None
+    if script.startswith('vibo_seed'):
+        # the headline run again under another --seed (initialisation, noise; the dataset and the hidden cells stay those
+        # of seed 42): what the REFERENCE's own numbers scatter by from seed to seed -- the yardstick for the tolerances of
+        # tests/test_gpu_trainer.py::test_trained_model_matches_the_reference_cli_run (our GPU run is one more noise stream)
+        cli_seed, script = int(script[len('vibo_seed'):]), 'vibo'
     if script in VARIANTS:
         extra, script = VARIANTS[script], 'vibo'
         ARGS['epochs'] = 15
@@ -76,7 +82,7 @@ def main(script='vibo'):
     sys.argv = ['vibo.py', '--irt-model', ARGS['irt'], '--dataset', f"{ARGS['irt']}_simulation", '--num-person', str(ARGS['num_person']),
                 '--num-item', str(ARGS['num_item']), '--ability-dim', str(ARGS['ability_dim']), '--artificial-missing-perc',
                 str(ARGS['perc']), '--epochs', str(ARGS['epochs']), '--batch-size', str(ARGS['batch']), '--num-posterior-samples',
-                str(ARGS['samples']), '--no-marginal', '--seed', str(ARGS['seed']), '--out-dir', out_dir]
+                str(ARGS['samples']), '--no-marginal', '--seed', str(ARGS['seed'] if cli_seed is None else cli_seed), '--out-dir', out_dir]
     for i in range(0, len(extra)):
         if extra[i] == '--ability-dim':          # already in argv: replace
             j = sys.argv.index('--ability-dim')
@@ -95,7 +101,7 @@ def main(script='vibo'):
     (run,) = os.listdir(out_dir)
     ck = _load(os.path.join(out_dir, run, 'checkpoint.pth.tar'), weights_only=False)
     rec = {
-        'meta': json.dumps(dict(ARGS, run_dir=run, script=script, extra=extra, lr=0.02 if script in ('vi', 'mle') else 5e-3, torch=torch.__version__)),
+        'meta': json.dumps(dict(ARGS, run_dir=run, script=script, extra=extra, cli_seed=cli_seed, lr=0.02 if script in ('vi', 'mle') else 5e-3, torch=torch.__version__)),
         'train_losses': np.load(os.path.join(out_dir, run, 'train_losses.npy')),
         'test_losses': np.load(os.path.join(out_dir, run, 'test_losses.npy')) if script == 'vibo' else np.zeros(0),
         'missing_imputation_accuracy': np.float64(ck.get('missing_imputation_accuracy', float('nan'))),
