@@ -49,8 +49,7 @@ enum { VIBO_MASK_U8 = 0,         /* torch.bool / uint8, 1 byte per cell (dataset
                                     traffic instead of 5.  Produced by vibo_pack_codes from the reference's layout
                                     (fp32 responses with -1 for missing + a separate mask, datasets.py:928-940).
                                     Row-split paths only: 4..32767 items, code rows 4-byte aligned with a stride that
-                                    is a multiple of 4 (cells past num_item are ignored); the conditional posterior
-                                    additionally needs ability_dim <= 4.  Anything else returns -8.            */
+                                    is a multiple of 4 (cells past num_item are ignored).  Anything else returns -8.  */
 enum { VIBO_REG_KL = 0,          /* elbo(use_kl_divergence=True): analytic KL (models.py:427-430) */
        VIBO_REG_SAMPLED = 1 };   /* use_kl_divergence=False / flows: log q - log p at the sample
                                     (models.py:406-424, 432-441)                             */

@@ -485,6 +485,29 @@ def test_full_size_shard_additivity_permutation_determinism(A, P):
     compare_raw(run(sl), ref, (I, A + 1))
 
 
+@pytest.mark.parametrize('A,I,codes', [(8, 1000, False), (6, 1100, False), (8, 420, True), (5, 2100, True)])
+def test_wide_conditional_posterior_is_deterministic(A, I, codes):
+    """conditional_posterior with ability_dim 5..8 (utils.py:85-113 product of per-cell experts, models.py:607-640):
+    the per-row statistics / per-item gradient passes run once per 4 ability dims, so these widths take the same
+    block-partial + fixed-order-finalize path as A <= 4 -- no float atomics: two runs agree bit for bit, and with the oracle."""
+    irt, B = 2, 900
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=True)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.25, seed=A * I, cond=True)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp.double(), mask, eps.double(), irt_model=irt,
+                           ability_dim=A, mode='kl', conditional_posterior=True)
+    d = dev()
+    if codes:
+        cells = ops.pack_cell_codes(resp.to(d), mask.to(d)).codes
+        run = lambda: ops._hip_launch_elbo(spec, cells, cells, _lib.MASK_CODES, None, table.to(d).contiguous(),
+                                           item.to(d).contiguous(), eps.to(d).contiguous(), None, _lib.REG_KL, True, B)
+    else:
+        run = lambda: run_kernel(spec, resp, mask, table, item, eps)
+    a, b = run(), run()
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat, b.flat) and torch.equal(a.grad_table(0), b.grad_table(0))
+    compare_raw(a, ref, (I, A + 1))
+
+
 @pytest.mark.parametrize('irt,A,I,cond,n_flows', [(2, 1, 95, False, 0), (2, 8, 1003, False, 0), (3, 2, 333, False, 2),
                                                    (2, 1, 2501, False, 0), (2, 2, 201, True, 0)])
 def test_ragged_item_count_with_padded_row_strides(irt, A, I, cond, n_flows):

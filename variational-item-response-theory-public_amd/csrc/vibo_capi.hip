@@ -119,7 +119,7 @@ static bool rows_vec_ok(const vibo_desc* d, const float* response, const void* m
 }
 static int codes_unsupported() {
     return fail(-8, "cell codes (VIBO_MASK_CODES) need the row-split paths: 4..32767 items, rows 4-byte aligned with a "
-                    "stride that pads them to a multiple of 4 cells, ability_dim <= 4 with the conditional posterior");
+                    "stride that pads them to a multiple of 4 cells");
 }
 
 // cell-code rows leave room for a third wave per SIMD in the narrower row-split kernels (see split_kernel's launch bounds)
@@ -165,7 +165,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
     if (is_given && !(I >= 4 && I <= 32767 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64))
         return fail(-8, "VIBO_POSTERIOR_GIVEN needs the row-split path: 4..32767 items, rows chunkable in 4 cells, no int64 mask");
     if (I >= 4 && I <= 32767 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64 &&
-        ((is_cond && A <= 4) || is_given || (!is_cond && I > 1024))) {
+        (is_cond || is_given || (!is_cond && I > 1024))) {
         // panel mode (item counts up to 32767: the whole-row counts are packed as n_correct << 16 | n_observed in an
         // int): one row-split launch per 1024 items (the backward is linear in d LL/d theta, so the panels
         // backpropagate their partial sums independently).  Unconditional posterior: a row-count pass supplies the
@@ -709,7 +709,6 @@ static size_t encode_scratch_bytes(const vibo_desc* d) {
     const int I = d->num_item, A = d->ability_dim;
     if (I < 4 || I > 32767 || !rows_chunkable(d) || d->mask_dtype == VIBO_MASK_I64) return 0;
     if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) {
-        if (A > 4) return 0;
         return (size_t)((I + 1023) / 1024) * d->num_person * (2 * A + 1) * 4 + 256;
     }
     return (size_t)d->num_person * 4 + 256;
@@ -868,6 +867,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         float* cpart = reinterpret_cast<float*>(wsb + pl.off_cpart);
         CondParams cp;
         memset(&cp, 0, sizeof(cp));
+        const int cond_blocks = pl.split_nblk;
         cp.response = response; cp.mask = mask; cp.row_index = row_index; cp.table = table;
         cp.resp_stride = d->response_row_stride; cp.mask_stride = d->mask_row_stride;
         cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;
@@ -886,7 +886,8 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                 cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
-                e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.split_nblk, s);   // own template width (3PL widens the split kernel's)
+                for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)      // 4 ability dims per launch
+                    e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);   // own template width (3PL widens the split kernel's)
             }
             p.pre_stats = pre;
             p.pre_panels = pl.panels;
@@ -912,10 +913,11 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
-                cp.partial = cpart + (size_t)pn * pl.split_nblk * pl.cond_rec;
-                e = launch_cond_post(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.split_nblk, s);
+                cp.partial = cpart + (size_t)pn * cond_blocks * pl.cond_rec;
+                for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
+                    e = launch_cond_post(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);
             }
-            if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.split_nblk, pl.cond_rec, s);
+            if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, cond_blocks, pl.cond_rec, s);
         }
         if (pl.given && grad && e == hipSuccess) {
             const long long n = (long long)d->num_person * A;
@@ -1111,7 +1113,8 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
                     cp.item0 = pn * 1024;
                     cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                     cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
-                    e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, grid, s);
+                    for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
+                        e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, grid, s);
                 }
                 if (e == hipSuccess) {
                     hipLaunchKernelGGL(encode_finish_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, s, nullptr, pre, panels,

@@ -12,7 +12,8 @@
 //                     in registers; at the end  d/d mu = S1 tau,  d/d logvar = -(S1 mu + S2) tau^2 exp(logvar)
 //   cond_finalize_kernel  fixed-order fp64 sum of the per-workgroup records -> grad_table[2 heads][2][I][2A]
 // Three passes over the response matrix (5 B/term each) instead of one; every kernel streams rows exactly like the
-// row-split kernel (16-byte loads one batch ahead).  ability_dim <= 4 (8 A accumulators per item in cond_post).
+// row-split kernel (16-byte loads one batch ahead).  A launch covers 4 ability dims (8 x 4 accumulators per item in
+// cond_post); wider posteriors (ability_dim 5..8) run cond_pre / cond_post twice, dims [0,4) and [4,A): deterministic, no atomics.
 #include <hip/hip_runtime.h>
 #include "../../include/vibo_hip.h"
 #include "vibo_cond.hpp"
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
 #pragma unroll
             for (int a = 0; a < AT; ++a) {
                 float t = 0.f, mm = 0.f;
-                if (item_ok && a < A) {
-                    t = 1.0f / (expf(te[A + a]) + kPoeEps);       // utils.py:105-113
-                    mm = te[a] * t;
+                if (item_ok && p.a0 + a < A) {
+                    t = 1.0f / (expf(te[A + p.a0 + a]) + kPoeEps);       // utils.py:105-113
+                    mm = te[p.a0 + a] * t;
                 }
                 tau[j][c][a] = t;
                 mt[j][c][a] = mm;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
             for (int w = 0; w < nq; ++w) t += part[w][r][k];
             const long long row = row0 + r;
             // [lam 0..A) | s 0..A) | nobs]: drop the padded dims
-            const int a = k < AT ? k : k - AT;
+            const int a = p.a0 + (k < AT ? k : k - AT);
             if (row < p.B) {
                 if (k == 2 * AT) p.pre_out[row * (2 * A + 1) + 2 * A] = t;
                 else if (a < A) p.pre_out[row * (2 * A + 1) + (k < AT ? a : A + a)] = t;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
         if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
         // this batch's coefficients (sum over the panels' shares), wave-private copy
         for (int e = lane; e < kCR * NC; e += 64) {
-            const int r = e / NC, k = e % NC, a = k % AT, hk = k / AT;
+            const int r = e / NC, k = e % NC, a = p.a0 + k % AT, hk = k / AT;
             float t = 0.f;
             if (row0 + r < p.B && a < A)
                 for (int pn = 0; pn < p.coef_panels; ++pn)
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int a = 0; a < AT; ++a) {
+            for (int al = 0; al < AT; ++al) {
+                const int a = p.a0 + al;
                 if (a >= A) continue;
                 float tauv[4], muv[4], esv[4];
 #pragma unroll
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
                     float gm[4], gl[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float s1 = S[j][c][(h * 2 + 0) * AT + a], s2 = S[j][c][(h * 2 + 1) * AT + a];
+                        const float s1 = S[j][c][(h * 2 + 0) * AT + al], s2 = S[j][c][(h * 2 + 1) * AT + al];
                         gm[j] = s1 * tauv[j];
                         gl[j] = -(s1 * muv[j] + s2) * tauv[j] * tauv[j] * esv[j];
                     }

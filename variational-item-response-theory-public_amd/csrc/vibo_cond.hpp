@@ -15,6 +15,7 @@ struct CondParams {
     float* partial;            // cond_post: [grid][rec_stride] records of this panel
     long long resp_stride, mask_stride;
     int B, I, I_total, item0, A, mask_dtype, coef_panels, rec_stride;
+    int a0;                    // first ability dim of this launch (dims a0 .. a0 + AT - 1: more than 4 dims take two launches)
 };
 
 hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s);

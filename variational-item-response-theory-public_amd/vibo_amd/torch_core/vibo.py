@@ -364,7 +364,7 @@ def main(argv=None):
     def shard(n):
         return slice(rank * n // world, (rank + 1) * n // world) if world > 1 else None
     row_format = args.row_format
-    codes_ok = bool(args.cuda) and 4 <= num_item <= 32767 and not (args.conditional_posterior and args.ability_dim > 4)
+    codes_ok = bool(args.cuda) and 4 <= num_item <= 32767
     if row_format == 'auto':
         row_format = 'codes' if codes_ok else 'f32'
     elif row_format == 'codes' and not codes_ok:
