@@ -60,6 +60,7 @@ struct Plan {
     int row_nblk;
     bool split_ok;            // row-split register kernel (ability_dim 3..8) is applicable (subject to alignment)
     int split_nq, split_nblk;
+    int cond_nblk;            // workgroups of the conditional posterior's cond_pre / cond_post launches
     bool msplit;              // the row-split launches go to the matrix-pipe kernel (vibo_msplit_kernel.hpp): split_nq = waves of
                               // 128 items per workgroup, batches of 32 rows
     int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
@@ -80,6 +81,11 @@ static hipError_t launch_split(const ElboParams& p, int AT, bool codes, int irt,
                                bool msplit = false) {
     if (msplit) {
         const int nw = (p.I + 127) / 128;
+        if (p.n_flows > 0) {
+            if (codes) return launch_elbo_msplit_fc(p, irt, grad, nw, grid, s);
+            if (p.row_index) return launch_elbo_msplit_fg(p, irt, grad, nw, grid, s);
+            return launch_elbo_msplit_fa(p, irt, grad, nw, grid, s);
+        }
         if (codes) return launch_elbo_msplit_c(p, irt, grad, nw, grid, s);
         if (p.row_index) return launch_elbo_msplit_g(p, irt, grad, nw, grid, s);
         return launch_elbo_msplit_a(p, irt, grad, nw, grid, s);
@@ -128,9 +134,8 @@ static bool codes_three_waves(const vibo_desc* d, int AT) {
 }
 
 // Which row-split kernel: the matrix-pipe kernel (contractions as f16 hi/lo MFMAs) or the VALU kernel.  VIBO_MSPLIT=0/1 in the
-// environment forces one of them (A/B measurements, tests of both paths); planar flows stay on the VALU kernel.
+// environment forces one of them (A/B measurements, tests of both paths).
 static bool want_msplit(const vibo_desc* d) {
-    if (d->n_flows > 0) return false;
     const char* e = getenv("VIBO_MSPLIT");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
@@ -186,6 +191,8 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         pl->split_nq = 4;
         pl->split_nblk = g_num_cu * ((d->want_grad && !codes_three_waves(d, pl->AT)) ? 2 : 3);
         if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
+        pl->cond_nblk = g_num_cu * 2;
+        if (pl->cond_nblk > (d->num_person + 7) / 8) pl->cond_nblk = (d->num_person + 7) / 8;
         if (allow_msplit && want_msplit(d)) {
             pl->msplit = true;
             pl->AT = 8;
@@ -210,7 +217,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
             pl->off_coef = off;
             off += up((size_t)pl->panels * d->num_person * 4 * A * 4);
             pl->off_cpart = off;
-            off += up((size_t)pl->panels * pl->split_nblk * pl->cond_rec * 4);
+            off += up((size_t)pl->panels * pl->cond_nblk * pl->cond_rec * 4);
         } else if (is_given) {
             pl->off_pre = off;
             off += up((size_t)d->num_person * (2 * A + 1) * 4);
@@ -867,7 +874,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         float* cpart = reinterpret_cast<float*>(wsb + pl.off_cpart);
         CondParams cp;
         memset(&cp, 0, sizeof(cp));
-        const int cond_blocks = pl.split_nblk;
+        const int cond_blocks = pl.cond_nblk;
         cp.response = response; cp.mask = mask; cp.row_index = row_index; cp.table = table;
         cp.resp_stride = d->response_row_stride; cp.mask_stride = d->mask_row_stride;
         cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;

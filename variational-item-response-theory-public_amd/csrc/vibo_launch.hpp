@@ -35,10 +35,14 @@ hipError_t launch_elbo_split_c2(const ElboParams& p, int irt, bool grad, int nq,
 hipError_t launch_elbo_split_c4(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
 hipError_t launch_elbo_split_c8(const ElboParams& p, int irt, bool grad, int nq, int grid, hipStream_t s);
 
-// matrix-pipe row-split kernel (vibo_msplit_kernel.hpp): any ability_dim <= 8, 1PL/2PL/3PL, no flows, I <= 1024, rows chunkable
+// matrix-pipe row-split kernel (vibo_msplit_kernel.hpp): any ability_dim <= 8, 1PL/2PL/3PL, I <= 1024, rows chunkable
 // in 4 cells; nw = ceil(I / 128) waves per workgroup; fp32 rows in order / through row_index / 1-byte cell codes
 hipError_t launch_elbo_msplit_a(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 hipError_t launch_elbo_msplit_g(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 hipError_t launch_elbo_msplit_c(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
+// ... the same with planar flows on the ability sample
+hipError_t launch_elbo_msplit_fa(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
+hipError_t launch_elbo_msplit_fg(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
+hipError_t launch_elbo_msplit_fc(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 
 }  // namespace vibo

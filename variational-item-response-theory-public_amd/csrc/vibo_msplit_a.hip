@@ -3,7 +3,7 @@
 #include "vibo_launch.hpp"
 namespace vibo {
 hipError_t launch_elbo_msplit_a(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s) {
-    return launch_msplit_rm<0>(p, irt, grad, nw, grid, s);
+    return launch_msplit_rm<0, false>(p, irt, grad, nw, grid, s);
 }
 }  // namespace vibo
 #ifdef VIBO_MS_TIMING

@@ -3,6 +3,6 @@
 #include "vibo_launch.hpp"
 namespace vibo {
 hipError_t launch_elbo_msplit_g(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s) {
-    return launch_msplit_rm<1>(p, irt, grad, nw, grid, s);
+    return launch_msplit_rm<1, false>(p, irt, grad, nw, grid, s);
 }
 }  // namespace vibo

@@ -72,7 +72,24 @@ struct alignas(16) MsCommonLds {
     float tacc[2][12][256];       // [batch parity][k][(person, dim) pair]: running sums of the pair's table-gradient terms
                                   // (k < 8) and of its kl | logq0 | logp | nobs terms: one LDS add per value and batch
 };
-inline size_t msplit_lds_bytes(int nw) { return sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds); }
+constexpr int kMsMF = VIBO_MAX_FLOWS;
+struct alignas(16) MsFlowLds {      // planar flows only (appended to the dynamic LDS of the FLOWS instantiations)
+    float fpar[kMsMF][2][8];        // uhat | w per ability dim
+    float fsc[kMsMF][2];            // b, w.uhat
+    float tps[2][kMsMF][2][kMsRows];   // [batch parity][flow][tanh | psi][person]: forward state kept for the backward
+    float lacc[2][kMsRows];         // running sums of the persons' log|det| terms
+    float facc[2][4][2][kMsMF][3][8];   // [batch parity][slot][set: LL | REG][flow][uhat | w | b][dim]: running flow-parameter gradients
+};
+inline size_t msplit_lds_bytes(int nw, bool flows = false) {
+    return sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (flows ? sizeof(MsFlowLds) : 0);
+}
+// sum over the 8 consecutive lanes that hold one person's ability dims (every lane of the group gets it)
+__device__ __forceinline__ float ms_group_sum(float v) {
+    v += dpp_f<0xb1>(v);                           // quad_perm [1,0,3,2]
+    v += dpp_f<0x4e>(v);                           // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);                          // row_half_mirror
+    return v;
+}
 
 __device__ __forceinline__ half2v pkrtz(float a, float b) {
     return __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a, b));
@@ -106,8 +123,9 @@ __device__ __forceinline__ half8 cat8(const half2v a, const half2v b, const half
 
 // IRT: 1/2/3PL.  GRAD: also gradients.  RM (row mode): 0 = fp32 responses + mask bytes, rows in order; 1 = the same
 // through p.row_index; 2 = 1-byte cell codes (VIBO_MASK_CODES, through p.mask), with or without p.row_index.
-// blockDim.x = 64 nw, dynamic LDS = msplit_lds_bytes(nw).
-template <int IRT, bool GRAD, int RM>
+// FLOWS: planar flows on the ability sample (flows.py:21-66, models.py:342-348) in the (person, dim) lanes.
+// blockDim.x = 64 nw, dynamic LDS = msplit_lds_bytes(nw, FLOWS).
+template <int IRT, bool GRAD, int RM, bool FLOWS>
 __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     constexpr bool CODES = RM == 2;
     constexpr int R = kMsRows;
@@ -121,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = (int)(blockDim.x >> 6);
     MsWaveLds& wl = wls[q];
+    MsFlowLds& fl = *reinterpret_cast<MsFlowLds*>(ms_smem + sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds));   // (FLOWS only)
     const int I = p.I, A = p.A;
     const int n4 = (I + 3) >> 2;
     const int i16 = lane & 15, g = lane >> 4;
@@ -135,6 +154,26 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         cl.ctab[(1 * 2 + c) * 8 + a] = m * tau;
         cl.ctab[(2 * 2 + c) * 8 + a] = tau * tau * es;
         cl.ctab[(3 * 2 + c) * 8 + a] = m;
+    }
+    if constexpr (FLOWS) {
+        if (tid < kMsMF * 8) {
+            const int f = tid >> 3, a = tid & 7;
+            const bool ok = f < p.n_flows && a < A;
+            fl.fpar[f][0][a] = ok ? p.flow[(size_t)f * (2 * A + 1) + a] : 0.f;
+            fl.fpar[f][1][a] = ok ? p.flow[(size_t)f * (2 * A + 1) + A + a] : 0.f;
+        }
+        if (tid < kMsMF) {
+            float cwu = 0.f, b = 0.f;
+            if (tid < p.n_flows) {
+                const float* fp = p.flow + (size_t)tid * (2 * A + 1);
+                for (int a = 0; a < A; ++a) cwu = fmaf(fp[A + a], fp[a], cwu);
+                b = fp[2 * A];
+            }
+            fl.fsc[tid][0] = b;
+            fl.fsc[tid][1] = cwu;
+        }
+        for (int k = tid; k < 2 * kMsRows; k += (int)blockDim.x) (&fl.lacc[0][0])[k] = 0.f;
+        for (int k = tid; k < 2 * 4 * 2 * kMsMF * 3 * 8; k += (int)blockDim.x) (&fl.facc[0][0][0][0][0][0])[k] = 0.f;
     }
 
     // ---- item operands of this wave's 128 items: read from the caller's [I][D] item sample and brought to the kernel's
@@ -388,13 +427,39 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const float amu = smu * inv_lam;
         const float sig = fast_rsq(lam);
         const float th0 = live ? amu + sig * eps_c : 0.f;
-        const float thv = th0;
+        float thv = th0;
+        float ladj = 0.f;
+        if constexpr (FLOWS) {              // z <- z + uhat tanh(w.z + b)
+#pragma unroll
+            for (int f = 0; f < kMsMF; ++f) {
+                if (f < p.n_flows) {
+                    const float ud = fl.fpar[f][0][ed], wd = fl.fpar[f][1][ed];
+                    const float aa = ms_group_sum(thv * wd) + fl.fsc[f][0];
+                    // tanh(x) = 1 - 2 / (1 + e^2x), |x| clamped so that e^2x stays finite (tanh(+-15) = +-1 in fp32)
+                    const float t = 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2((2.0f * kLog2e) * med3(aa, -15.f, 15.f)));
+                    const float psi = 1.0f + (1.0f - t * t) * fl.fsc[f][1];
+                    if (GRAD && ed == 0) {
+                        fl.tps[par][f][0][pp] = t;
+                        fl.tps[par][f][1][pp] = psi;
+                    }
+                    ladj += kLn2 * fast_log2(fabsf(psi) + 1e-8f);
+                    thv = fmaf(ud, t, thv);
+                }
+            }
+        }
         if (live && p.primary) {
             const long long o = (row0 + pp) * A + ed;
             const float alv = -kLn2 * fast_log2(lam);
             p.ability_mu[o] = amu;
             p.ability_logvar[o] = alv;
             p.ability[o] = th0;
+            if constexpr (FLOWS) {
+                p.ability_k[o] = thv;
+                if (ed == 0) {
+                    p.ability_ladj[row0 + pp] = ladj;
+                    lds_add(&fl.lacc[par][pp], ladj);
+                }
+            }
             lds_add(&cl.tacc[par][8][e], -0.5f * (1.0f + alv - amu * amu - inv_lam));
             lds_add(&cl.tacc[par][9][e], -0.5f * kLog2Pi - 0.5f * alv - 0.5f * eps_c * eps_c);
             lds_add(&cl.tacc[par][10][e], -0.5f * kLog2Pi - 0.5f * thv * thv);
@@ -426,13 +491,56 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll 1
             for (int w = 0; w < nw; ++w) g0 += wls[w].gth[par][pp][ed];
         }
-        const float gz0 = live ? g0 * kLn2 : 0.f;
+        float gz0 = live ? g0 * kLn2 : 0.f;
         const float amu = cl.st[par][0][e], sig = cl.st[par][1][e], inv_lam = cl.st[par][2][e], eps_c = cl.st[par][3][e];
         const int cnt = __builtin_bit_cast(int, cl.st[par][4][e]);
         const float n1 = (float)(cnt >> 16), n0 = (float)(cnt & 0xffff) - n1;
-        const float thv = live ? amu + sig * eps_c : 0.f;
+        float thv = live ? amu + sig * eps_c : 0.f;
         const bool reg_on = live && p.primary;
-        const float gz1 = (reg_on && p.reg_mode != 0) ? thv : 0.f;
+        float gz1 = 0.f;
+        if constexpr (!FLOWS) {
+            gz1 = (reg_on && p.reg_mode != 0) ? thv : 0.f;        // d REG / d theta_K (-log p)
+        } else {
+            // the sample after the flows again (the forward's arithmetic on the kept tanh values: same bits)
+#pragma unroll
+            for (int f = 0; f < kMsMF; ++f)
+                if (f < p.n_flows) thv = fmaf(fl.fpar[f][0][ed], fl.tps[par][f][0][pp], thv);
+            gz1 = (reg_on && p.reg_mode != 0) ? thv : 0.f;
+            float znext = thv;                  // output of the flow being backpropagated
+            const float lv = live ? 1.0f : 0.f, lv1 = reg_on ? 1.0f : 0.f;
+            const int sl = (e >> 6) & 3;
+            auto flow_back = [&](const int f) {
+                const float ud = fl.fpar[f][0][ed], wd = fl.fpar[f][1][ed];
+                const float cwu = fl.fsc[f][1];
+                const float t = fl.tps[par][f][0][pp], psi = fl.tps[par][f][1][pp];
+                const float zin = fmaf(-ud, t, znext);       // its input (to an ulp of the forward's value)
+                znext = zin;
+                const float omt = 1.0f - t * t;
+                const float unit = ((psi >= 0.f) ? 1.0f : -1.0f) / (fabsf(psi) + 1e-8f);
+                // set 0 (LL): no log-det term
+                const float g_a0 = ms_group_sum(gz0 * ud) * omt;
+                const float f00 = gz0 * t, f01 = lv * g_a0 * zin, f02 = lv * g_a0;
+                gz0 = fmaf(g_a0, wd, gz0) * lv;
+                // set 1 (REG = log q0 - sum log|det| - log p): d REG / d ladj = -1
+                const float dl_dpsi = -unit;
+                const float g_t = dl_dpsi * (-2.0f * t * cwu) + ms_group_sum(gz1 * ud);
+                const float g_c = dl_dpsi * omt;
+                const float g_a1 = g_t * omt;
+                const float f10 = lv1 * (gz1 * t + g_c * wd), f11 = lv1 * (g_a1 * zin + g_c * ud), f12 = lv1 * g_a1;
+                gz1 = fmaf(g_a1, wd, gz1) * lv1;
+                // the slot's 8 persons (lanes 8 apart) -> lanes 0..7, then one running sum per (slot, set, kind, dim)
+                auto fold = [&](float v, float* dst) {
+                    v += dpp_f<0x128>(v);               // row_ror 8
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (lane < 8) lds_add(dst, v);
+                };
+                fold(f00, &fl.facc[par][sl][0][f][0][ed]); fold(f01, &fl.facc[par][sl][0][f][1][ed]); fold(f02, &fl.facc[par][sl][0][f][2][ed]);
+                fold(f10, &fl.facc[par][sl][1][f][0][ed]); fold(f11, &fl.facc[par][sl][1][f][1][ed]); fold(f12, &fl.facc[par][sl][1][f][2][ed]);
+            };
+#pragma unroll 1
+            for (int f = p.n_flows - 1; f >= 0; --f) flow_back(f);
+        }
         const float h = 0.5f * sig * eps_c;
         float gmu[2], glv[2];
         gmu[0] = gz0;
@@ -805,7 +913,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         float t = 0.f;
         for (int w = 0; w < nw; ++w) t += wls[w].red[0];
         out[0] = t;
-        out[4] = 0.f; out[6] = 0.f; out[7] = 0.f;
+        float la = 0.f;
+        if constexpr (FLOWS) {
+            for (int par2 = 0; par2 < 2; ++par2)
+                for (int e = 0; e < kMsRows; ++e) la += fl.lacc[par2][e];
+        }
+        out[4] = la; out[6] = 0.f; out[7] = 0.f;
     }
     if (tid < 4) {                            // sums of the (person, dim) pairs' running terms, fixed order
         const int k = 8 + tid;
@@ -822,6 +935,17 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 for (int e = a; e < 256; e += 8) t += cl.tacc[par2][k][e];
             const int st = k >> 2, c = (k >> 1) & 1, ms = k & 1;
             out[p.lay.off_table + (st * 2 + c) * 2 * A + ms * A + a] = t;
+        }
+        if constexpr (FLOWS) {
+            const int per = 2 * A + 1;
+            for (int idx = tid; idx < 2 * p.n_flows * per; idx += (int)blockDim.x) {
+                const int st = idx / (p.n_flows * per), f = (idx / per) % p.n_flows, j = idx % per;
+                const int kind = j < A ? 0 : j < 2 * A ? 1 : 2;
+                const int a = kind == 0 ? j : kind == 1 ? j - A : 0;
+                float t = 0.f;
+                for (int k = 0; k < 8; ++k) t += fl.facc[k >> 2][k & 3][st][f][kind][a];
+                out[p.lay.off_flow + idx] = t;
+            }
         }
         // item gradients.  d LL/d a: lane (col i16, g) holds items 4 g + j of tile (u, t): cols a and 8 + a add up
 #pragma unroll
@@ -853,24 +977,24 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     }
 }
 
-template <int IRT, bool GRAD, int RM>
+template <int IRT, bool GRAD, int RM, bool FLOWS>
 static hipError_t launch_msplit_one(const ElboParams& p, int nw, int grid, hipStream_t s) {
     // more than 64 KB of dynamic LDS has to be opted into (once per kernel; gfx950 has 160 KB per CU)
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msplit_kernel<IRT, GRAD, RM>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)msplit_lds_bytes(8));
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msplit_kernel<IRT, GRAD, RM, FLOWS>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)msplit_lds_bytes(8, FLOWS));
         if (e != hipSuccess) return e;
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw), s, p);
+    hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM, FLOWS>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw, FLOWS), s, p);
     return hipGetLastError();
 }
-template <int RM>
+template <int RM, bool FLOWS>
 static hipError_t launch_msplit_rm(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s) {
-    if (irt == 1) return grad ? launch_msplit_one<1, true, RM>(p, nw, grid, s) : launch_msplit_one<1, false, RM>(p, nw, grid, s);
-    if (irt == 2) return grad ? launch_msplit_one<2, true, RM>(p, nw, grid, s) : launch_msplit_one<2, false, RM>(p, nw, grid, s);
-    return grad ? launch_msplit_one<3, true, RM>(p, nw, grid, s) : launch_msplit_one<3, false, RM>(p, nw, grid, s);
+    if (irt == 1) return grad ? launch_msplit_one<1, true, RM, FLOWS>(p, nw, grid, s) : launch_msplit_one<1, false, RM, FLOWS>(p, nw, grid, s);
+    if (irt == 2) return grad ? launch_msplit_one<2, true, RM, FLOWS>(p, nw, grid, s) : launch_msplit_one<2, false, RM, FLOWS>(p, nw, grid, s);
+    return grad ? launch_msplit_one<3, true, RM, FLOWS>(p, nw, grid, s) : launch_msplit_one<3, false, RM, FLOWS>(p, nw, grid, s);
 }
 
 }  // namespace vibo
