@@ -258,3 +258,51 @@ def test_graph_replay_survives_a_shorter_eager_minibatch_with_native_noise():
     assert t1._eps_ab[B].data_ptr() == ptr
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cls,kw', [(VIBO_3PL, dict(conditional_posterior=True, n_norm_flows=4)),
+                                    (VIBO_2PL, dict(conditional_posterior=True)),
+                                    (VIBO_2PL, dict(ability_merge='mean')),
+                                    (VIBO_2PL, dict(n_norm_flows=2))])
+def test_graphed_module_step_follows_the_eager_module_step(cls, kw):
+    """vibo_amd.torch_core.vibo.GraphedModuleStep replays the module-path step (elbo_step, backward, capturable Adam:
+    vibo.py:243-268 for --conditional-posterior / --n-norm-flows / --ability-merge mean) from a hipGraph.  Same seed ->
+    the same noise stream as the eager loop, so both models must follow the same trajectory; rows and beta are refreshed
+    between replays through device buffers."""
+    import copy
+    from vibo_amd.torch_core.vibo import GraphedModuleStep
+
+    class Data:
+        pass
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    P, I, A, B = 640, 120, 2, 64
+    resp, mask = O.simulate_responses(cls.IRT, P, I, A, generator=g, missing_frac=0.1)
+    data = Data()
+    data.response, data.mask, data.device = resp.to(dev), mask.bool().to(dev), dev
+    torch.manual_seed(2)
+    kw = dict(dict(ability_merge='product'), **kw)
+    m1 = cls(A, I, **kw).to(dev)
+    m2 = copy.deepcopy(m1)
+    o1 = torch.optim.Adam(m1.parameters(), lr=5e-3, capturable=True)
+    o2 = torch.optim.Adam(m2.parameters(), lr=5e-3)
+    step = GraphedModuleStep(m1, o1, data, B)
+    perm = torch.randperm(P, generator=g).to(dev)
+    losses = []
+    for it in range(8):
+        rows = perm[(it * B) % P:(it * B) % P + B]
+        beta = 0.5 + 0.05 * it
+        torch.manual_seed(50 + it)
+        l1 = step(rows, beta)
+        torch.manual_seed(50 + it)
+        o2.zero_grad()
+        l2 = m2.elbo_step(data.response, data.mask, annealing_factor=beta, row_index=rows)
+        l2.backward()
+        o2.step()
+        losses.append((float(l1), float(l2)))
+    assert step.graph is not None
+    for a, b in losses:
+        assert abs(a - b) < 1e-4 * abs(b), losses
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert (a - b).abs().max() < 1e-4 * max(1.0, float(b.abs().max())), k

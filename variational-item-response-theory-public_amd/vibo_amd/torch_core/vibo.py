@@ -216,6 +216,59 @@ class GraphedTrainStep:
         return self.loss
 
 
+class GraphedModuleStep:
+    """The module-path train step (vibo.py:243-268: zero_grad, model.elbo(*model(r, m), beta), backward, Adam) over
+    `batch_size` gathered rows as one hipGraph, for the configurations FusedTrainer's three-kernel step does not cover
+    (conditional posterior, planar flows, mean merge): ~100 small launches are recorded once and replayed with one host
+    call, the row-index vector and the KL weight live in device buffers that are refreshed before each replay.
+    `optimizer` must be torch.optim.Adam(capturable=True) (its step counter stays on the device).  Noise comes from the
+    default CUDA generator, whose Philox offset torch advances per replay.  Full-size minibatches only."""
+    WARMUP = 3
+
+    def __init__(self, model, optimizer, data, batch_size):
+        self.model, self.optimizer, self.data, self.batch_size = model, optimizer, data, batch_size
+        self.rows = torch.zeros(batch_size, dtype=torch.int64, device=data.device)
+        self.beta = torch.ones((), device=data.device)
+        self.graph, self.loss, self.seen = None, None, 0
+        # the warm-up steps and the capture share one side stream: autograd keeps each parameter's AccumulateGrad node
+        # (and the stream it was created on) alive across steps, and a node from the default stream breaks the capture
+        self.side = torch.cuda.Stream(device=data.device)
+
+    def _eager(self, rows, beta):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.model.elbo_step(self.data.response, self.data.mask, annealing_factor=beta, row_index=rows)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, rows, beta):
+        if rows.numel() != self.batch_size:
+            return self._eager(rows, beta)
+        self.seen += 1
+        if self.graph is None and self.seen <= self.WARMUP:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                loss = self._eager(rows, beta)
+            torch.cuda.current_stream().wait_stream(self.side)
+            return loss
+        self.rows.copy_(rows)
+        self.beta.fill_(float(beta))
+        if self.graph is None:
+            self.model._last_ctx = None                      # (drops the last step's autograd graph)
+            self.optimizer.zero_grad(set_to_none=True)       # gradients are then allocated from the graph's own pool
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.side):
+                loss = self.model.elbo_step(self.data.response, self.data.mask, annealing_factor=self.beta, row_index=self.rows)
+                loss.backward()
+                self.optimizer.step()
+                self.loss = loss.detach()
+            self.model._last_ctx = None
+            self.graph = g
+        self.graph.replay()
+        return self.loss
+
+
 def train_epoch(model, optimizer, data, args, epoch, batch_size, trainer=None, graphed=None, n_steps=None):
     model.train()
     n_batches = n_steps if n_steps is not None else data.num_batches(batch_size)
@@ -387,15 +440,19 @@ def main(argv=None):
         n_norm_flows=args.n_norm_flows).to(device)
     if world > 1:
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
     trainer = None
     if (args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and args.ability_merge == 'product'
             and not args.torch_optimizer and args.hidden_dim <= 256):      # (wider encoders: module + torch.optim.Adam)
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)       # same Adam arithmetic, 5-7 launches per step
     graphed = None
+    module_graph = trainer is None and args.cuda and world == 1 and not args.no_graph
+    # (capturable: Adam's step counter and bias corrections stay on the device -- required inside a captured graph)
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=bool(module_graph))
     if trainer is not None and world == 1 and not args.no_graph:
         graphed = GraphedTrainStep(trainer, train, local_bs)      # (multi-GPU: eager steps around the all-reduce)
+    elif module_graph:
+        graphed = GraphedModuleStep(model, optimizer, train, local_bs)      # conditional / flows / mean merge: module path, replayed
 
     best_loss = np.inf
     train_losses, test_losses, train_times = np.zeros(args.epochs), np.zeros(args.epochs), np.zeros(args.epochs)
