@@ -287,6 +287,37 @@ int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* re
                             const int64_t* row_index, const float* table, const float* item, const float* eps,
                             const float* flow, float* out_scalars, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * The per-term MLP decoders of --generative-model link | deep | residual (LinkedIRT / DeepIRT / ResidualIRT,
+ * models.py:769-919) -- masked Bernoulli log-likelihood, forward and backward, of
+ *     z1[p][i][:] = U[i][:] + V[p][:] + w1[:] L[p][i]
+ *     o[p][i]     = w3 . elu(W2 . elu(z1) + b2) + b3 + resid L[p][i]
+ *     P(response[p][i] = 1) = sigmoid(o)   or   guess[i] + (1 - guess[i]) sigmoid(o)   when guess != NULL
+ * with hidden_dim = 64.  The caller (PyTorch autograd) forms the per-item / per-person halves of the first layer:
+ *   deep / residual:  U = mlp_concat[0].weight[:, :64] . mlp_item_feat(item) [I][64],
+ *                     V = mlp_concat[0].weight[:, 64:] . mlp_ability(ability) + bias [B][64];  residual: L = the IRT logit
+ *                     (irt_model_*pl(return_logit=True), models.py:729-766), resid = 1, w1 = NULL;  deep: L = NULL
+ *   link:             U = NULL, V = link[0].bias broadcast [B][64], w1 = link[0].weight [64], L = the IRT logit, resid = 0
+ * and backpropagates the returned gradients through them.  response [B][I] fp32 (row stride in d), mask u8 or NULL.
+ * Outputs are partial records in a fixed order (sum them; n_ib = ceil(I / 64), n_wave = 4 n_ib person_chunks):
+ *   ll_part [n_wave]; dW2_part [n_wave][64][64]; dvec_part [n_wave][4][64] = d b2 | d w3 | d w1 | (d b3, 0...);
+ *   dU_part [person_chunks][I][64]; dV_part [4 n_ib][B][64]; dL [B][I] (complete, not partial);
+ *   dguess_part [person_chunks][I] (w.r.t. the guess probability).
+ * want_grad = 0: only ll_part and, when prob_out != NULL, prob_out [B][I] = P(response = 1) (decode()).
+ * person_chunks: vibo_decoder_person_chunks(B, I), or any value in 1..B.
+ */
+typedef struct vibo_decoder_desc {
+    int32_t num_person, num_item, hidden_dim, want_grad, person_chunks;
+    float resid;
+    int64_t response_row_stride, mask_row_stride;
+} vibo_decoder_desc;
+int vibo_decoder_person_chunks(int num_person, int num_item);
+int vibo_decoder_fwd_bwd(const vibo_decoder_desc* d, const float* response, const uint8_t* mask,
+                         const float* U, const float* V, const float* L, const float* guess, const float* w1,
+                         const float* W2, const float* b2, const float* w3, const float* b3,
+                         float* ll_part, float* dU_part, float* dV_part, float* dL, float* dguess_part,
+                         float* dW2_part, float* dvec_part, float* prob_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

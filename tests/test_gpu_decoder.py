@@ -1,0 +1,71 @@
+"""The per-term MLP decoder kernel (vibo_decoder_fwd_bwd: --generative-model link | deep | residual, models.py:769-919)
+against a plain PyTorch float64 statement of the same network with autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vibo_amd import decoder as D
+
+pytestmark = pytest.mark.gpu
+EPS32 = 1.1920928955078125e-07
+
+
+def torch_reference(resp, mask, U, V, W2, b2, w3, b3, logit, w1, guess, resid):
+    """[B, I, 64] the slow way (float64)."""
+    z1 = V.unsqueeze(1) + (U.unsqueeze(0) if U is not None else 0.0)
+    if w1 is not None:
+        z1 = z1 + logit.unsqueeze(2) * w1
+    h2 = F.elu(F.elu(z1) @ W2.t() + b2)
+    o = h2 @ w3 + b3
+    if resid:
+        o = o + resid * logit
+    p = torch.sigmoid(o)
+    if guess is not None:
+        p = guess + (1 - guess) * p
+    pc = p.clamp(EPS32, 1 - EPS32)                       # torch.distributions.Bernoulli(probs=...) clamp (utils.py:46-49)
+    ll = torch.where(resp > 0.5, pc.log(), torch.log1p(-pc))
+    if mask is not None:
+        ll = ll * mask
+    return ll.sum(), p
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('mode,B,I,missing', [('deep', 37, 130, 0.2), ('residual', 16, 64, 0.0), ('link', 33, 95, 0.3),
+                                             ('residual3', 50, 200, 0.1), ('link3', 7, 20, 0.0), ('deep', 300, 1000, 0.1)])
+def test_decoder_kernel_matches_float64_autograd(mode, B, I, missing):
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B * 1000 + I)
+    H = 64
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).double()
+    resp = (torch.rand(B, I, generator=g) < 0.5).double()
+    mask = (torch.rand(B, I, generator=g) >= missing).double() if missing > 0 else None
+    t = dict(V=rn(B, H, sc=0.7), W2=rn(H, H, sc=0.18), b2=rn(H, sc=0.1), w3=rn(H, sc=0.25), b3=rn(1, sc=0.1))
+    has_l = mode != 'deep'
+    t['U'] = rn(I, H, sc=0.7) if not mode.startswith('link') else None
+    t['logit'] = rn(B, I, sc=1.5) if has_l else None
+    t['w1'] = rn(H, sc=0.5) if mode.startswith('link') else None
+    t['guess'] = torch.sigmoid(rn(I)) if mode.endswith('3') else None
+    resid = 1.0 if mode.startswith('residual') else 0.0
+    leaves = {k: v.clone().requires_grad_(True) for k, v in t.items() if v is not None}
+    ll_ref, p_ref = torch_reference(resp, mask, leaves.get('U'), leaves['V'], leaves['W2'], leaves['b2'], leaves['w3'], leaves['b3'],
+                                    leaves.get('logit'), leaves.get('w1'), leaves.get('guess'), resid)
+    ll_ref.backward()
+
+    dl = {k: v.float().to(dev).requires_grad_(True) for k, v in t.items() if v is not None}
+    args = dict(U=dl.get('U'), V=dl['V'], W2=dl['W2'], b2=dl['b2'], w3=dl['w3'], b3=dl['b3'], logit=dl.get('logit'),
+                w1=dl.get('w1'), guess=dl.get('guess'), resid=resid)
+    r32 = resp.float().to(dev)
+    m8 = mask.bool().to(dev) if mask is not None else None
+    ll = D.decoder_log_lik(r32, m8, **args)
+    ll.backward()
+    assert abs(float(ll) - float(ll_ref)) < 2e-5 * abs(float(ll_ref))
+    for k in leaves:
+        assert rel(dl[k].grad.double().cpu(), leaves[k].grad) < 2e-4, k
+    p = D.decoder_probs(B, I, **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in args.items()})
+    assert (p.double().cpu() - p_ref.detach()).abs().max() < 2e-5
+    # fixed-order partial records: bitwise reproducible
+    ll2 = D.decoder_log_lik(r32, m8, **args)
+    assert torch.equal(ll.detach(), ll2.detach())

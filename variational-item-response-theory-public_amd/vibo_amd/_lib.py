@@ -43,10 +43,25 @@ class ViboDesc(ctypes.Structure):
     ]
 
 
+class ViboDecoderDesc(ctypes.Structure):
+    """struct vibo_decoder_desc (include/vibo_hip.h)."""
+    _fields_ = [
+        ('num_person', ctypes.c_int32),
+        ('num_item', ctypes.c_int32),
+        ('hidden_dim', ctypes.c_int32),
+        ('want_grad', ctypes.c_int32),
+        ('person_chunks', ctypes.c_int32),
+        ('resid', ctypes.c_float),
+        ('response_row_stride', ctypes.c_int64),
+        ('mask_row_stride', ctypes.c_int64),
+    ]
+
+
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
-                    'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise')
+                    'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise',
+                    'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd')
 
 _lib = None
 
@@ -107,6 +122,10 @@ def load():
     lib.vibo_pack_codes.argtypes = [dp, fp, vp, vp, ctypes.c_int64, vp]
     lib.vibo_decode_mean.restype = ctypes.c_int
     lib.vibo_decode_mean.argtypes = [dp, ctypes.c_int, fp, fp, fp, vp]
+    lib.vibo_decoder_person_chunks.restype = ctypes.c_int
+    lib.vibo_decoder_person_chunks.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.vibo_decoder_fwd_bwd.restype = ctypes.c_int
+    lib.vibo_decoder_fwd_bwd.argtypes = [ctypes.POINTER(ViboDecoderDesc)] + [vp] * 19 + [vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib
