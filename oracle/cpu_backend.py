@@ -104,7 +104,54 @@ def install(ops):
         from oracle.vibo_oracle import irt_link
         return torch.stack([irt_link(spec.irt_model, abilities[s], items[s]) for s in range(abilities.shape[0])]).mean(0)
 
-    ops._BACKEND.update(elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts, mean_fwd=mean_fwd,
+    def decoder(response, mask, U, V, L, guess, w1, W2, b2, w3, b3, resid, want_grad, want_prob=False):
+        """vibo_decoder_fwd_bwd's outputs (one partial record each) from plain fp32 autograd."""
+        with torch.enable_grad():
+            return _decoder(response, mask, U, V, L, guess, w1, W2, b2, w3, b3, resid, want_grad, want_prob)
+
+    def _decoder(response, mask, U, V, L, guess, w1, W2, b2, w3, b3, resid, want_grad, want_prob):
+        F = torch.nn.functional
+        names = ('U', 'V', 'L', 'guess', 'w1', 'W2', 'b2', 'w3', 'b3')
+        leaves = {k: (v.clone().requires_grad_(True) if v is not None else None)
+                  for k, v in zip(names, (U, V, L, guess, w1, W2, b2, w3, b3))}
+        z1 = leaves['V'].unsqueeze(1) + (leaves['U'].unsqueeze(0) if U is not None else 0.0)
+        if w1 is not None:
+            z1 = z1 + leaves['L'].unsqueeze(2) * leaves['w1']
+        o = F.elu(F.elu(z1) @ leaves['W2'].t() + leaves['b2']) @ leaves['w3'] + leaves['b3']
+        if resid:
+            o = o + resid * leaves['L']
+        p = torch.sigmoid(o)
+        if guess is not None:
+            p = leaves['guess'] + (1.0 - leaves['guess']) * p
+        pc = p.clamp(1.1920928955078125e-07, 1.0 - 1.1920928955078125e-07)
+        ll = torch.where(response > 0.5, pc.log(), torch.log1p(-pc))
+        if mask is not None:
+            ll = ll * (mask != 0)
+        ll = ll.sum()
+        out = {'ll_part': ll.detach().reshape(1)}
+        if want_prob:
+            out['prob'] = p.detach()
+        if want_grad:
+            live = [k for k in names if leaves[k] is not None and not (k == 'L' and w1 is None and not resid)]
+            grads = dict(zip(live, torch.autograd.grad(ll, [leaves[k] for k in live], allow_unused=True)))
+            z = lambda k, ref: grads[k] if grads.get(k) is not None else torch.zeros_like(ref)
+            out['dW2'] = z('W2', W2).unsqueeze(0)
+            dvec = torch.zeros(1, 4, W2.shape[0])
+            dvec[0, 0], dvec[0, 1] = z('b2', b2), z('w3', w3)
+            if w1 is not None:
+                dvec[0, 2] = z('w1', w1)
+            dvec[0, 3, 0] = z('b3', b3)[0]
+            out['dvec'] = dvec
+            out['dV'] = z('V', V).unsqueeze(0)
+            if U is not None:
+                out['dU'] = z('U', U).unsqueeze(0)
+            if L is not None:
+                out['dL'] = z('L', L)
+            if guess is not None:
+                out['dguess'] = z('guess', guess).unsqueeze(0)
+        return out
+
+    ops._BACKEND.update(decoder=decoder, elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts, mean_fwd=mean_fwd,
                         mean_bwd=mean_bwd)
 
     def restore():

@@ -19,6 +19,7 @@ Reference lines each function follows (paths relative to the reference repo):
   product_of_experts     src/utils.py:105-113
   ability_posterior      src/torch_core/models.py:596-629 (uncond), 695-710 (cond)
   irt_link               src/torch_core/models.py:729-766
+  decoder_probs          src/torch_core/models.py:769-919 (LinkedIRT / DeepIRT / ResidualIRT)
   planar_flows           src/torch_core/flows.py:21-41, 58-66
   masked_bernoulli_ll    src/utils.py:46-49 (+ torch.distributions.Bernoulli
                          probs->logits clamp, binary_cross_entropy_with_logits)
@@ -123,6 +124,39 @@ def irt_link(irt_model, ability, item_feat):
     return guess + (1.0 - guess) * torch.sigmoid(logit)
 
 
+def irt_logit(irt_model, ability, item_feat):
+    """irt_model_*pl(..., return_logit=True) (models.py:729-766): ([B,I] logit, 3PL guess [1,I] or None)."""
+    A = ability.shape[1]
+    if irt_model == 1:
+        return ability.sum(1, keepdim=True) + item_feat.t(), None
+    logit = ability @ (-item_feat[:, :A].t()) + item_feat[:, A:A + 1].t()
+    guess = torch.sigmoid(item_feat[:, A + 1:A + 2]).t() if irt_model == 3 else None
+    return logit, guess
+
+
+def decoder_probs(params, generative_model, irt_model, ability, item_feat):
+    """P(response = 1) [B,I] of the per-term MLP decoders (models.py:769-919), evaluated per (person, item) term the
+    way the reference does: LinkedIRT.forward :783-801, DeepIRT.forward :851-866, ResidualIRT.forward :900-916."""
+    def mlp(prefix, x, sigmoid=False):
+        h = F.elu(F.linear(x, params[f'{prefix}.0.weight'], params[f'{prefix}.0.bias']))
+        h = F.elu(F.linear(h, params[f'{prefix}.2.weight'], params[f'{prefix}.2.bias']))
+        o = F.linear(h, params[f'{prefix}.4.weight'], params[f'{prefix}.4.bias'])
+        return torch.sigmoid(o) if sigmoid else o
+    B, I = ability.shape[0], item_feat.shape[0]
+    if generative_model == 'link':
+        logit, guess = irt_logit(irt_model, ability, item_feat)
+        mu = mlp('decoder.link', logit.reshape(B * I, 1), sigmoid=True).reshape(B, I)
+        return mu if guess is None else guess + (1.0 - guess) * mu
+    hid_a = mlp('decoder.mlp_ability', ability).unsqueeze(1).expand(B, I, -1)
+    hid_i = mlp('decoder.mlp_item_feat', item_feat).unsqueeze(0).expand(B, I, -1)
+    res = mlp('decoder.mlp_concat', torch.cat([hid_i, hid_a], dim=2).reshape(B * I, -1)).reshape(B, I)
+    if generative_model == 'deep':
+        return torch.sigmoid(res)
+    logit, guess = irt_logit(irt_model, ability, item_feat)
+    mu = torch.sigmoid(res + logit)
+    return mu if guess is None else guess + (1.0 - guess) * mu
+
+
 def planar_flows(params, prefix, z, n_flows):
     """Sequence of planar flows; returns (z_K, sum of log|det J|) per row."""
     ladj = torch.zeros(z.shape[0], dtype=z.dtype)
@@ -167,7 +201,7 @@ def std_normal_logpdf(x):
 def elbo_forward(params, response, mask, eps_item, eps_ability, *, irt_model,
                  ability_dim, conditional_posterior=False,
                  replace_missing_with_prior=True, n_norm_flows=0,
-                 annealing_factor=1.0, use_kl_divergence=True):
+                 annealing_factor=1.0, use_kl_divergence=True, generative_model='irt'):
     """One ELBO evaluation.  Returns a dict with ``loss`` (= -ELBO summed over
     the minibatch, models.py:443) and every intermediate forward() returns."""
     irt_model = int(irt_model)
@@ -189,9 +223,10 @@ def elbo_forward(params, response, mask, eps_item, eps_ability, *, irt_model,
         item_k, i_ladj = planar_flows(params, 'item_norm_flows', item_feat, n_norm_flows)
         out.update(ability_k=ability_k, ability_logabsdetjac=a_ladj,
                    item_feat_k=item_k, item_feat_logabsdetjac=i_ladj)
-        probs = irt_link(irt_model, ability_k, item_k)
+        th, it = ability_k, item_k
     else:
-        probs = irt_link(irt_model, ability, item_feat)
+        th, it = ability, item_feat
+    probs = irt_link(irt_model, th, it) if generative_model == 'irt' else decoder_probs(params, generative_model, irt_model, th, it)
     out['response_mu'] = probs
 
     ll = masked_bernoulli_ll(response, mask, probs).sum()

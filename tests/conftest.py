@@ -50,7 +50,8 @@ class Golden:
                     replace_missing_with_prior=m['replace_missing_with_prior'],
                     n_norm_flows=m['n_norm_flows'],
                     annealing_factor=m['annealing_factor'],
-                    use_kl_divergence=m['use_kl_divergence'])
+                    use_kl_divergence=m['use_kl_divergence'],
+                    **({'generative_model': m['generative_model']} if m.get('generative_model', 'irt') != 'irt' else {}))
 
     def __repr__(self):
         return os.path.basename(self.path)

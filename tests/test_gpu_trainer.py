@@ -88,7 +88,11 @@ def test_fused_trainer_native_rng_trains():
 @pytest.mark.gpu
 @pytest.mark.parametrize('extra', [[], ['--no-graph'], ['--rng', 'native'], ['--artificial-missing-perc', '0.2', '--conditional-posterior'],
                                    ['--n-norm-flows', '2', '--irt-model', '3pl', '--dataset', '3pl_simulation'],
-                                   ['--num-item', '95', '--ability-dim', '3']])
+                                   ['--num-item', '95', '--ability-dim', '3'],
+                                   ['--generative-model', 'deep', '--ability-dim', '2'],
+                                   ['--generative-model', 'link', '--artificial-missing-perc', '0.2'],
+                                   ['--generative-model', 'residual', '--irt-model', '3pl', '--dataset', '3pl_simulation',
+                                    '--ability-merge', 'mean']])
 def test_cli_end_to_end_on_the_gpu(tmp_path, monkeypatch, extra):
     """The drop-in CLI with --cuda: fused trainer replayed from a hipGraph (or eager / module + torch.optim for the
     conditional posterior and flows), resident padded rows, post-hoc enrichment; same checkpoint layout as on CPU."""

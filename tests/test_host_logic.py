@@ -30,7 +30,7 @@ def build_model(golden):
     model = CLS[m['irt_model']](m['ability_dim'], m['num_item'], hidden_dim=m['hidden_dim'],
                                 ability_merge=m.get('ability_merge', 'product'), conditional_posterior=m['conditional_posterior'],
                                 replace_missing_with_prior=m['replace_missing_with_prior'],
-                                n_norm_flows=m['n_norm_flows'])
+                                n_norm_flows=m['n_norm_flows'], generative_model=m.get('generative_model', 'irt'))
     model.load_state_dict(golden.sd, strict=True)      # same keys and shapes as the reference
     return model
 

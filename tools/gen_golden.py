@@ -95,18 +95,26 @@ CASES = [
     ('3pl_a8_uncond_mean_miss',      3, 8, 16, 130, False, 0.2, False, 0, 1.0, True, 'mean'),
     ('1pl_a3_uncond_mean_flows2',    1, 3, 16, 20, False, 0.0, False, 2, 1.0, False, 'mean'),
     ('2pl_a1_uncond_mean_miss_nokl', 2, 1, 37, 95, False, 0.2, False, 0, 1.0, False, 'mean'),
+    # --generative-model link | deep | residual (models.py:769-919): 13th field
+    ('2pl_a2_deep_miss',             2, 2, 16, 20, False, 0.2, False, 0, 1.0, True, 'product', 'deep'),
+    ('3pl_a1_residual',              3, 1, 16, 70, False, 0.0, False, 0, 0.5, True, 'product', 'residual'),
+    ('2pl_a1_link_miss',             2, 1, 37, 20, False, 0.2, False, 0, 1.0, True, 'product', 'link'),
+    ('3pl_a2_link_flows2',           3, 2, 16, 20, False, 0.0, False, 2, 1.0, False, 'product', 'link'),
+    ('1pl_a3_residual_mean_miss_drop', 1, 3, 16, 20, False, 0.2, True, 0, 1.0, True, 'mean', 'residual'),
+    ('2pl_a8_deep_nokl',             2, 8, 16, 20, False, 0.0, False, 0, 1.0, False, 'product', 'deep'),
 ]
 
 
 def run_case(ref_models, case, out_dir):
     name, irt, A, B, I, cond, missing, drop, flows, beta, use_kl = case[:11]
     merge = case[11] if len(case) > 11 else 'product'
+    gen = case[12] if len(case) > 12 else 'irt'
     seed = 1000 + sum(ord(c) for c in name)
     resp, mask = make_data(irt, B, I, A, missing, seed)
     cls = {1: ref_models.VIBO_1PL, 2: ref_models.VIBO_2PL, 3: ref_models.VIBO_3PL}[irt]
     torch.manual_seed(seed)
     model = cls(A, I, hidden_dim=64, ability_merge=merge, conditional_posterior=cond,
-                generative_model='irt', response_dist='bernoulli',
+                generative_model=gen, response_dist='bernoulli',
                 replace_missing_with_prior=not drop, n_norm_flows=flows)
     D = model.item_feat_dim
 
@@ -143,7 +151,7 @@ def run_case(ref_models, case, out_dir):
         'meta': json.dumps(dict(name=name, irt_model=irt, ability_dim=A, num_person=B, num_item=I,
                                 conditional_posterior=cond, missing_frac=missing,
                                 replace_missing_with_prior=not drop, n_norm_flows=flows,
-                                annealing_factor=beta, use_kl_divergence=use_kl, ability_merge=merge,
+                                annealing_factor=beta, use_kl_divergence=use_kl, ability_merge=merge, generative_model=gen,
                                 hidden_dim=64, torch=torch.__version__)),
         'response': resp.numpy().astype(np.int8),
         'mask': mask.numpy().astype(np.uint8),

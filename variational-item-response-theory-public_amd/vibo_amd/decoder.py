@@ -52,6 +52,9 @@ def _launch(response, mask, U, V, L, guess, w1, W2, b2, w3, b3, resid, want_grad
     return out
 
 
+ops._BACKEND.setdefault('decoder', _launch)      # (tests without a GPU swap in oracle/cpu_backend.py's stand-in)
+
+
 def _prep(t):
     return None if t is None else t.detach().contiguous().float()
 
@@ -62,8 +65,8 @@ class _DecoderLogLik(torch.autograd.Function):
     @staticmethod
     def forward(ctx, response, mask, resid, U, V, L, guess, w1, W2, b2, w3, b3):
         want_grad = any(t is not None and t.requires_grad for t in (U, V, L, guess, w1, W2, b2, w3, b3))
-        out = _launch(response, mask, _prep(U), _prep(V), _prep(L), _prep(guess), _prep(w1), _prep(W2), _prep(b2), _prep(w3),
-                      _prep(b3), resid, want_grad)
+        out = ops._BACKEND['decoder'](response, mask, _prep(U), _prep(V), _prep(L), _prep(guess), _prep(w1), _prep(W2), _prep(b2),
+                                      _prep(w3), _prep(b3), resid, want_grad)
         ctx.out = out if want_grad else None
         ctx.has = (U is not None, L is not None, guess is not None, w1 is not None)
         return out['ll_part'].sum()
@@ -83,9 +86,9 @@ class _DecoderLogLik(torch.autograd.Function):
 
 
 def _rows(response, mask):
-    response = ops.prepare_response(response)
     if isinstance(response, ops.CellCodes):
         response, mask = response.unpack()
+    response = ops.prepare_response(response)
     if mask is not None:
         mask = ops.prepare_mask(mask)[0]
     return response.float(), mask
@@ -102,8 +105,8 @@ def decoder_log_lik(response, mask, *, U, V, W2, b2, w3, b3, logit=None, w1=None
 def decoder_probs(B, I, *, U, V, W2, b2, w3, b3, logit=None, w1=None, guess=None, resid=0.0):
     """P(response = 1) [B, I] of the per-term network (decode(): models.py:373-378 with a non-IRT generative model)."""
     dummy = torch.zeros(B, I, device=V.device)
-    out = _launch(dummy, None, _prep(U), _prep(V), _prep(logit), _prep(guess), _prep(w1), _prep(W2), _prep(b2), _prep(w3), _prep(b3),
-                  resid, False, want_prob=True)
+    out = ops._BACKEND['decoder'](dummy, None, _prep(U), _prep(V), _prep(logit), _prep(guess), _prep(w1), _prep(W2), _prep(b2),
+                                  _prep(w3), _prep(b3), resid, False, want_prob=True)
     return out['prob']
 
 

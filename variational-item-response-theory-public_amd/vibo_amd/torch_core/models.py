@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, ops
+from ..decoder import DeepIRT, LinkedIRT, ResidualIRT
 from ..ops import ElboSpec, decode_probs, encode_posterior, fused_elbo, item_feat_dim
 
 LOG_2PI = math.log(2.0 * math.pi)
@@ -202,6 +203,28 @@ class DeferredResponseMu:
         return 'DeferredResponseMu(call .materialize() for the [B,I,1] tensor)'
 
 
+class DecoderContext:
+    """One forward of a --generative-model link|deep|residual model: the posterior side is ordinary autograd (it only
+    needs the row counts), the log-likelihood is the decoder kernel's (vibo_amd/decoder.py), evaluated when elbo() asks."""
+
+    def __init__(self, model, response, mask, row_index):
+        self.model, self.response, self.mask, self.row_index = model, response, mask, row_index
+        self._ll = None
+
+    @property
+    def ll(self):
+        if self._ll is None:
+            r, m = self.response, self.mask
+            if self.row_index is not None:          # the decoder kernel walks dense rows: gather the minibatch here
+                if isinstance(r, ops.CellCodes):
+                    r = r.rows(self.row_index)
+                else:
+                    r = ops.prepare_response(r)[self.row_index]
+                    m = None if m is None else ops.prepare_mask(m)[0][self.row_index]
+            self._ll = self.model.decoder.log_lik(r, m, self.ability_k, self.item_k)
+        return self._ll
+
+
 # ---------------------------------------------------------------------------
 # the model
 # ---------------------------------------------------------------------------
@@ -224,8 +247,9 @@ class VIBO_1PL(nn.Module):
         if ability_merge == 'mean' and conditional_posterior:
             # per-(code, item) feature vectors of width hidden_dim: a [B, 2I] x [2I, H] contraction per step
             raise NotImplementedError("--ability-merge mean with --conditional-posterior is not implemented by the HIP engine")
-        if generative_model != 'irt':
-            raise NotImplementedError("only --generative-model irt is implemented by the HIP engine")
+        if generative_model != 'irt' and conditional_posterior:
+            raise NotImplementedError("--generative-model link|deep|residual with --conditional-posterior is not "
+                                      "implemented by the HIP engine")
         if response_dist != 'bernoulli':
             raise NotImplementedError("only --response-dist bernoulli is implemented by the HIP engine")
 
@@ -255,6 +279,13 @@ class VIBO_1PL(nn.Module):
         if n_norm_flows > 0:
             self.ability_norm_flows = FlowStack(latent_dim, n_norm_flows)
             self.item_norm_flows = FlowStack(self.item_feat_dim, n_norm_flows)
+        # per-term MLP decoders (models.py:310-327, 769-919), built after the flows like the reference
+        if generative_model == 'link':
+            self.decoder = LinkedIRT(irt_model=self.IRT, hidden_dim=hidden_dim)
+        elif generative_model == 'deep':
+            self.decoder = DeepIRT(latent_dim, irt_model=self.IRT, hidden_dim=hidden_dim)
+        elif generative_model == 'residual':
+            self.decoder = ResidualIRT(latent_dim, irt_model=self.IRT, hidden_dim=hidden_dim)
         self.apply(self.weights_init)
 
         self._reducer = None          # set by enable_person_sharding()
@@ -337,9 +368,50 @@ class VIBO_1PL(nn.Module):
         self._last_ctx = ctx
         return ctx
 
+    def _posterior_from_counts(self, counts):
+        """(mu, logvar) [B, A] of the unconditional product of experts (models.py:596-629, utils.py:105-113) from the packed
+        row counts: every observed cell contributes one of two experts, every missing one the N(0,1) prior (or nothing)."""
+        A = self.ability_dim
+        table = self.ability_encoder.expert_table(None)                      # [2, 2A]: rows = response 0 / 1
+        n1 = (counts >> 16).to(table.dtype).unsqueeze(1)
+        nobs = (counts & 0xffff).to(table.dtype).unsqueeze(1)
+        n0 = nobs - n1
+        tau = 1.0 / (torch.exp(table[:, A:]) + 1e-8)                          # [2, A]
+        lam = n0 * tau[0] + n1 * tau[1]
+        smu = n0 * (table[0, :A] * tau[0]) + n1 * (table[1, :A] * tau[1])
+        if self.replace_missing_with_prior:
+            lam = lam + (self.num_item - nobs) * (1.0 / (1.0 + 1e-8))
+        return smu / lam, torch.log(1.0 / lam)
+
+    def _run_decoder(self, response, mask, *, eps_item=None, eps_ability=None, row_index=None):
+        """forward() with a per-term MLP decoder: item sample, posterior from the row counts, sample, flows."""
+        if self._reducer is not None:
+            raise NotImplementedError('person sharding covers --generative-model irt')
+        item_feat, item_mu, item_lv = self._item_side(eps_item)
+        counts = ops.row_counts(response, mask, row_index)
+        if self.ability_merge == 'mean':
+            amu, alv = torch.chunk(self.ability_encoder.posterior(counts), 2, dim=1)
+        else:
+            amu, alv = self._posterior_from_counts(counts)
+        if eps_ability is None:
+            eps_ability = self._randn(amu.shape, item_mu, self._ability_gen)
+        ctx = DecoderContext(self, response, mask, row_index)
+        ctx.eps_item, ctx.eps_ability = self._last_eps_item, eps_ability
+        ctx.ability_mu, ctx.ability_logvar = amu, alv
+        ctx.ability = eps_ability * torch.exp(0.5 * alv) + amu
+        ctx.item_feat, ctx.item_mu, ctx.item_lv = item_feat, item_mu, item_lv
+        if self.n_norm_flows > 0:
+            ctx.ability_k, ctx.ability_ladj = self.ability_norm_flows(ctx.ability)
+            ctx.item_k, ctx.item_ladj = self.item_norm_flows(item_feat)
+        else:
+            ctx.ability_k, ctx.ability_ladj, ctx.item_k, ctx.item_ladj = ctx.ability, None, item_feat, None
+        self._last_ctx = ctx
+        return ctx
+
     # ---- reference method surface --------------------------------------------
     def forward(self, response, mask, eps_item=None, eps_ability=None, row_index=None):
-        ctx = self._run_fused(response, mask, eps_item=eps_item, eps_ability=eps_ability, row_index=row_index)
+        run = self._run_fused if self.generative_model == 'irt' else self._run_decoder
+        ctx = run(response, mask, eps_item=eps_item, eps_ability=eps_ability, row_index=row_index)
         if self.n_norm_flows > 0:
             rmu = DeferredResponseMu(ctx, ctx.ability_k, ctx.item_k)
             return (response, mask, rmu, ctx.ability_k, ctx.ability, ctx.ability_mu, ctx.ability_logvar,
@@ -364,6 +436,8 @@ class VIBO_1PL(nn.Module):
 
     def decode(self, ability, item_feat):
         """response_mu [B,I,1] (models.py:373-378, 529-533, 544-548)."""
+        if self.generative_model != 'irt':
+            return self.decoder(ability, item_feat)
         return decode_probs(self.spec, ability, item_feat).unsqueeze(2)
 
     def elbo(self, response, mask, response_mu, ability, ability_mu, ability_logvar,
@@ -380,6 +454,8 @@ class VIBO_1PL(nn.Module):
             if ctx is None:
                 raise TypeError('elbo() expects the outputs of this model\'s forward(); a response_mu tensor that does '
                                 'not come from it would need a second pass over the responses')
+        if isinstance(ctx, DecoderContext):
+            return self._decoder_elbo(ctx, annealing_factor, use_kl_divergence)
         want_mode = _lib.REG_SAMPLED if (self.n_norm_flows > 0 or not use_kl_divergence) else _lib.REG_KL
         if want_mode != ctx.reg_mode:
             if torch.is_grad_enabled() and ctx.ll.requires_grad:
@@ -407,6 +483,23 @@ class VIBO_1PL(nn.Module):
         log_p_d = _std_normal_logpdf(item_feat).sum()
         return -(ll + log_p_d - reg - log_q_d)
 
+    def _decoder_elbo(self, ctx, annealing_factor, use_kl_divergence):
+        """models.py:380-443 with the decoder kernel's log-likelihood; the small per-person / per-item terms are autograd."""
+        ll = ctx.ll
+        if self.n_norm_flows > 0:
+            log_q = (_normal_logpdf(ctx.ability, ctx.ability_mu, ctx.ability_logvar).sum() - ctx.ability_ladj.sum()
+                     + _normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum() - ctx.item_ladj.sum())
+            log_p = ll + _std_normal_logpdf(ctx.ability_k).sum() + _std_normal_logpdf(ctx.item_k).sum()
+            return -(log_p - log_q)
+        if use_kl_divergence:
+            kl_u = (-0.5 * (1.0 + ctx.ability_logvar - ctx.ability_mu.pow(2) - ctx.ability_logvar.exp())).sum()
+            kl_d = (-0.5 * (1.0 + ctx.item_lv - ctx.item_mu.pow(2) - ctx.item_lv.exp())).sum()
+            return -(ll - annealing_factor * kl_u - annealing_factor * kl_d)
+        log_p = ll + _std_normal_logpdf(ctx.ability).sum() + _std_normal_logpdf(ctx.item_feat).sum()
+        log_q = (_normal_logpdf(ctx.ability, ctx.ability_mu, ctx.ability_logvar).sum()
+                 + _normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum())
+        return -(log_p - log_q)
+
     def log_marginal(self, response, mask, num_samples=100, eps_item=None, eps_ability=None):
         """Importance-weighted bound with batch-level weights (models.py:445-504).  eps_item [S,I,D] / eps_ability
         [S,B,A] replay a fixed noise sequence (tests); by default it is drawn item-then-ability per sample like the
@@ -414,6 +507,13 @@ class VIBO_1PL(nn.Module):
         (vibo_elbo_multi_forward); otherwise one forward launch per sample."""
         with torch.no_grad():
             S = int(num_samples)
+            if self.generative_model != 'irt':
+                log_w = []
+                for s in range(S):
+                    ctx = self._run_decoder(response, mask, eps_item=None if eps_item is None else eps_item[s],
+                                            eps_ability=None if eps_ability is None else eps_ability[s])
+                    log_w.append(-self._decoder_elbo(ctx, 1.0, False))
+                return torch.logsumexp(torch.stack(log_w), 0) - math.log(S)
             if not self.conditional_posterior and self.ability_merge == 'product':
                 if not isinstance(response, ops.CellCodes):
                     response = ops.prepare_response(response)

@@ -112,8 +112,10 @@ def check_supported(args):
     problems = []
     if args.ability_merge == 'transformer':
         problems.append("--ability-merge transformer (the reference asserts it away as well, models.py:262)")
-    if args.generative_model != 'irt':
-        problems.append(f"--generative-model {args.generative_model} (only the 1PL/2PL/3PL logistic link is on this path)")
+    if args.generative_model != 'irt' and args.conditional_posterior:
+        problems.append(f"--generative-model {args.generative_model} together with --conditional-posterior")
+    if args.generative_model != 'irt' and args.hidden_dim != 64:
+        problems.append(f"--generative-model {args.generative_model} with --hidden-dim != 64 (the per-term decoder kernel's width)")
     if args.response_dist != 'bernoulli':
         problems.append("--response-dist gaussian (the reference's loader has no *_continuous datasets either)")
     if args.dataset in ('duolingo', 'wordbank', 'pisa2015_science'):
@@ -346,6 +348,11 @@ def posterior_predictive(model, data, args, batch_size, keep_samples):
                 per = [model.decode(a_s[s], i_s[s]).squeeze(2).cpu() for s in range(S)]
                 stacks.append(torch.stack(per))
                 means.append(stacks[-1].mean(0))
+            elif model.generative_model != 'irt':      # per-term MLP decoders: one decoder launch per draw, mean kept on the device
+                acc = model.decode(a_s[0], i_s[0]).squeeze(2)
+                for s in range(1, S):
+                    acc += model.decode(a_s[s], i_s[s]).squeeze(2)
+                means.append((acc / S).cpu())
             else:        # one kernel: mean over the S draws, no [S,B,I] intermediate (vibo_decode_mean)
                 means.append(ops.decode_probs_mean(model.spec, a_s, i_s).cpu())
     if keep_samples:
@@ -442,6 +449,7 @@ def main(argv=None):
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
     trainer = None
     if (args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and args.ability_merge == 'product'
+            and args.generative_model == 'irt'
             and not args.torch_optimizer and args.hidden_dim <= 256):      # (wider encoders: module + torch.optim.Adam)
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)       # same Adam arithmetic, 5-7 launches per step
