@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 F=$1; shift
 W=/tmp/vibo_pmc; rm -rf $W; mkdir -p $W
 cd /tmp && export TMPDIR=/tmp
-B="python $R/tools/profile_kernel.py --iters 5 $*"
+B="python $R/tools/${PROFILE_SCRIPT:-profile_kernel.py} --iters 5 $*"
 echo "# $B"
 rocprofv3 --kernel-trace --stats -d $W/kt -o kt -- $B > $W/kt.log 2>&1
 python $R/tools/rocpd_summary.py $W/kt/kt_results.db $F | head -6

@@ -37,6 +37,9 @@ typedef _Float16 dh2 __attribute__((ext_vector_type(2)));
 typedef float df4 __attribute__((ext_vector_type(4)));
 typedef short ds4 __attribute__((ext_vector_type(4)));
 
+#ifndef DEC_MIN_WG
+#define DEC_MIN_WG 1
+#endif
 constexpr int kH = 64;             // hidden width of the per-term network (models.py:777, 824: hidden_dim = 64)
 constexpr int kXRow = 72;          // halfs per row of the transposition image (64 + 8 of padding: 144-byte rows)
 
@@ -66,11 +69,15 @@ __device__ __forceinline__ dh4 dtr16(const _Float16* p) {
 }
 __device__ __forceinline__ dh2 dpk(float a, float b) { return __builtin_bit_cast(dh2, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 // 8 floats -> f16 hi and lo pieces (x = hi + lo to 2^-22)
+// (hi = round-toward-zero pair; lo = f16(x - hi) by two mixed-precision fmas that write the two halves of one register)
 __device__ __forceinline__ void split8(const float* x, dh8& hi, dh8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         const dh2 h = dpk(x[e], x[e + 1]);
-        const dh2 l = dpk(x[e] - (float)h[0], x[e + 1] - (float)h[1]);
+        uint32_t lw;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(h), "v"(x[e]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(h), "v"(x[e + 1]));
+        const dh2 l = __builtin_bit_cast(dh2, lw);
         hi[e] = h[0]; hi[e + 1] = h[1];
         lo[e] = l[0]; lo[e + 1] = l[1];
     }
@@ -79,7 +86,7 @@ __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : fast_exp2(z
 
 // HASL: the network sees the IRT logit l (link: through w1; residual: added to the output).
 template <bool GRAD, bool HASL>
-__global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
+__global__ __launch_bounds__(256, DEC_MIN_WG) void decoder_kernel(const DecParams p) {
     __shared__ DecLds sm;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
@@ -133,27 +140,42 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
 
     const long long p_begin = (long long)blockIdx.y * p.ppc;
     const long long p_end = p_begin + p.ppc < p.B ? p_begin + p.ppc : p.B;
+    // the pair's inputs are loaded one iteration ahead (one wave per SIMD: nobody else hides the load latency)
+    struct PersonIn { float4 v[4]; float x, l; unsigned m; };
+    PersonIn cur[2], nxt[2];
+    auto load_pair = [&](const long long pp, PersonIn (&d)[2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long long pr = pp + r;
+            const long long prc = pr < p_end ? pr : p_end - 1;
+            d[r].x = p.response[prc * p.resp_stride + it];
+            d[r].m = p.mask ? (unsigned)p.mask[prc * p.mask_stride + it] : 1u;
+            d[r].l = 0.f;
+            if constexpr (HASL) d[r].l = p.L[prc * (long long)p.I + it];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) d[r].v[kt] = *reinterpret_cast<const float4*>(p.V + (size_t)prc * kH + 16 * kt + 4 * g);
+        }
+    };
+    if (p_begin < p_end) load_pair(p_begin, cur);
 #pragma unroll 1
     for (long long pp = p_begin; pp < p_end; pp += 2) {
+        load_pair(pp + 2, nxt);
         dh8 h1h[2][2], h1l[2][2], dzh[2][2], dzl[2][2];        // [person of the pair][K step]
         float h1f[2][16], lgt[2];
-        uint32_t z1neg[2] = {0u, 0u}, z2neg[2] = {0u, 0u};     // bit a: pre-activation a was <= 0
         float dov[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const long long pr = pp + r;
             const bool ok = pr < p_end && item_ok;
-            const long long prc = pr < p_end ? pr : p_end - 1;
-            const float x = p.response[prc * p.resp_stride + it];
-            const bool obs = ok && (p.mask ? p.mask[prc * p.mask_stride + it] != 0 : true);
-            float l = 0.f;
-            if constexpr (HASL) l = p.L[prc * (long long)p.I + it];
+            const float x = cur[r].x;
+            const bool obs = ok && cur[r].m != 0;
+            const float l = cur[r].l;
             lgt[r] = l;
             // ---- layer 1 (element-wise in the operand layout) ----
             float z1[16];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const float4 v = *reinterpret_cast<const float4*>(p.V + (size_t)prc * kH + 16 * kt + 4 * g);
+                const float4 v = cur[r].v[kt];
                 z1[4 * kt] = u[4 * kt] + v.x; z1[4 * kt + 1] = u[4 * kt + 1] + v.y;
                 z1[4 * kt + 2] = u[4 * kt + 2] + v.z; z1[4 * kt + 3] = u[4 * kt + 3] + v.w;
             }
@@ -161,7 +183,6 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
             for (int a = 0; a < 16; ++a) {
                 if constexpr (HASL) z1[a] = fmaf(w1v[a], l, z1[a]);
                 h1f[r][a] = elu(z1[a]);
-                z1neg[r] |= (z1[a] > 0.f ? 0u : 1u) << a;
             }
             split8(&h1f[r][0], h1h[r][0], h1l[r][0]);
             split8(&h1f[r][8], h1h[r][1], h1l[r][1]);
@@ -183,7 +204,6 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
                 for (int j = 0; j < 4; ++j) {
                     const float z2 = acc[j] + b2v[4 * nt + j];
                     h2[4 * nt + j] = elu(z2);
-                    z2neg[r] |= (z2 > 0.f ? 0u : 1u) << (4 * nt + j);
                     opart = fmaf(w3v[4 * nt + j], h2[4 * nt + j], opart);
                 }
             }
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
                 float dz2[16];
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {
-                    const float d = d_o * w3v[a] * (((z2neg[r] >> a) & 1u) ? h2[a] + 1.0f : 1.0f);
+                    const float d = d_o * w3v[a] * (h2[a] > 0.f ? 1.0f : h2[a] + 1.0f);       // ELU' = 1 | e^z = h + 1
                     dz2[a] = d;
                     db2[a] += d;
                     dw3[a] = fmaf(d_o, h2[a], dw3[a]);
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
                 split8(&dz2[8], dzh[r][1], dzl[r][1]);
             }
         }
-        if constexpr (!GRAD) continue;
+        if constexpr (!GRAD) { cur[0] = nxt[0]; cur[1] = nxt[1]; continue; }
         // ---- backward through layer 2: dH1^T = W2^T . dz2^T, then the ELU of layer 1 ----
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -247,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int a = 4 * kt + j;
-                    dz1[a] = acc[j] * (((z1neg[r] >> a) & 1u) ? h1f[r][a] + 1.0f : 1.0f);
+                    dz1[a] = acc[j] * (h1f[r][a] > 0.f ? 1.0f : h1f[r][a] + 1.0f);
                     dU[a] += dz1[a];
                 }
             }
@@ -313,6 +333,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
                 acc = dmfma(Al[nt], Bh[kt], acc);
                 accW[nt][kt] = acc;
             }
+        cur[0] = nxt[0]; cur[1] = nxt[1];
     }
 
     // ================= partial records =================
