@@ -61,7 +61,7 @@ def test_decoder_kernel_matches_float64_autograd(mode, B, I, missing):
     m8 = mask.bool().to(dev) if mask is not None else None
     ll = D.decoder_log_lik(r32, m8, **args)
     ll.backward()
-    assert abs(float(ll) - float(ll_ref)) < 2e-5 * abs(float(ll_ref))
+    assert abs(float(ll.detach()) - float(ll_ref.detach())) < 2e-5 * abs(float(ll_ref.detach()))
     for k in leaves:
         assert rel(dl[k].grad.double().cpu(), leaves[k].grad) < 2e-4, k
     p = D.decoder_probs(B, I, **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in args.items()})

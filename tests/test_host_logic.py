@@ -159,14 +159,15 @@ def test_table_ref_matches_autograd_oracle(golden):
     mean = golden.meta.get('ability_merge', 'product') == 'mean'
     if mean:      # the kernel takes the per-person posterior as given (VIBO_POSTERIOR_GIVEN): table = [B, 2A]
         table = torch.cat(O.ability_posterior(sd, golden.response.double(), golden.mask, item_feat, ability_dim=A,
-                                              conditional_posterior=False, replace_missing_with_prior=True), dim=1)
+                                              conditional_posterior=cfg['conditional_posterior'],
+                                              replace_missing_with_prior=True), dim=1)
         table = table.detach().requires_grad_(True)
     else:
         table = T.encoder_table(sd, item_feat, cfg['conditional_posterior']).detach().requires_grad_(True)
     item_leaf = item_k.detach().requires_grad_(True)
     out = T.fused_elbo_ref(table.detach(), item_leaf.detach(), golden.response.double(), golden.mask,
                            golden.eps_ability.double(), irt_model=cfg['irt_model'], ability_dim=A,
-                           conditional_posterior=cfg['conditional_posterior'],
+                           conditional_posterior=cfg['conditional_posterior'] and not mean,
                            replace_missing_with_prior=cfg['replace_missing_with_prior'], mode=mode,
                            flow_uhat_w_b=flows, exact_saturation=False, given_posterior=mean)
 

@@ -95,6 +95,8 @@ CASES = [
     ('3pl_a8_uncond_mean_miss',      3, 8, 16, 130, False, 0.2, False, 0, 1.0, True, 'mean'),
     ('1pl_a3_uncond_mean_flows2',    1, 3, 16, 20, False, 0.0, False, 2, 1.0, False, 'mean'),
     ('2pl_a1_uncond_mean_miss_nokl', 2, 1, 37, 95, False, 0.2, False, 0, 1.0, False, 'mean'),
+    ('2pl_a2_cond_mean_miss',        2, 2, 37, 95, True, 0.2, False, 0, 1.0, True, 'mean'),
+    ('3pl_a2_cond_mean_flows2',      3, 2, 16, 20, True, 0.0, False, 2, 1.0, False, 'mean'),
     # --generative-model link | deep | residual (models.py:769-919): 13th field
     ('2pl_a2_deep_miss',             2, 2, 16, 20, False, 0.2, False, 0, 1.0, True, 'product', 'deep'),
     ('3pl_a1_residual',              3, 1, 16, 70, False, 0.0, False, 0, 0.5, True, 'product', 'residual'),

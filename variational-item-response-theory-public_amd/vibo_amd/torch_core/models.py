@@ -94,14 +94,36 @@ class MeanAbilityEncoder(nn.Module):
     the mean over a person's OBSERVED items is therefore (n0 h(0) + n1 h(1)) / n_obs with the counts of
     vibo_row_counts, and mlp2 -- the one dense [B,H] x [H,H] contraction of the path -- maps it to (mu, logvar)."""
 
-    def __init__(self, ability_dim, hidden_dim):
+    def __init__(self, ability_dim, hidden_dim, item_dim=0, conditional=False):
         super().__init__()
         self.ability_dim = ability_dim
-        self.conditional = False
-        self.mlp1 = nn.Sequential(nn.Linear(1, hidden_dim), nn.ELU(inplace=True), nn.Linear(hidden_dim, hidden_dim))
-        self.mlp2 = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ELU(inplace=True),
-                                  nn.Linear(hidden_dim, 2 * ability_dim))
+        self.conditional = conditional
+
+        def nets(in_dim):
+            return (nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.ELU(inplace=True), nn.Linear(hidden_dim, hidden_dim)),
+                    nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ELU(inplace=True), nn.Linear(hidden_dim, 2 * ability_dim)))
+        if conditional:
+            nets(1)      # the reference builds (and discards) the unconditional nets first (models.py:675-693): same RNG draws
+        self.mlp1, self.mlp2 = nets(1 + (item_dim if conditional else 0))
         self.register_buffer('_response_values', torch.tensor([[0.0], [1.0]]), persistent=False)
+
+    def posterior_conditional(self, response, mask, item_feat, reducer=None):
+        """--conditional-posterior (models.py:695-710 with _forward_mean :631-650): the per-term feature depends on the item
+        too, h[c, i] = elu(mlp1([c, item_i])), so a person's mean over its observed items is the [B, 2I] x [2I, H]
+        contraction of its one-hot coded row with the 2 x I feature table -- two dense GEMMs on the observed / correct
+        indicator matrices (the GEMM library's job), then mlp2.  response [B, I] fp32, mask [B, I] bool/u8 or None."""
+        I = item_feat.shape[0]
+        vals = self._response_values.to(item_feat.dtype)
+        x = torch.cat([vals.unsqueeze(1).expand(2, I, 1), item_feat.unsqueeze(0).expand(2, I, -1)], dim=2)
+        h = F.elu(self.mlp1(x.reshape(2 * I, -1))).view(2, I, -1)                 # [2, I, H]
+        l0, l2 = self.mlp2[0], self.mlp2[2]
+        w0, b0, w2, b2 = l0.weight, l0.bias, l2.weight, l2.bias
+        if reducer is not None:      # person-sharded: these see only this rank's persons
+            h, w0, b0, w2, b2 = (_SumGradAcrossRanks.apply(t, reducer) for t in (h, w0, b0, w2, b2))
+        obs = torch.ones_like(response) if mask is None else (mask != 0).to(response.dtype)
+        right = (response == 1).to(response.dtype) * obs
+        hid_mean = (obs @ h[0] + right @ (h[1] - h[0])) / obs.sum(1, keepdim=True)   # (no observed item: 0/0 = NaN like the reference)
+        return F.linear(F.elu(F.linear(hid_mean, w0, b0)), w2, b2)
 
     def posterior(self, counts, reducer=None):
         """[B, 2A] = (mu | logvar) of every person from the packed row counts (0 observed items -> NaN, as the
@@ -244,9 +266,6 @@ class VIBO_1PL(nn.Module):
             raise AssertionError('bad response_dist')
         # the fused HIP path covers the 1PL/2PL/3PL logistic link with the product-of-experts
         # encoder on Bernoulli responses (BASELINE.json north_star); nothing else is in scope
-        if ability_merge == 'mean' and conditional_posterior:
-            # per-(code, item) feature vectors of width hidden_dim: a [B, 2I] x [2I, H] contraction per step
-            raise NotImplementedError("--ability-merge mean with --conditional-posterior is not implemented by the HIP engine")
         if generative_model != 'irt' and conditional_posterior:
             raise NotImplementedError("--generative-model link|deep|residual with --conditional-posterior is not "
                                       "implemented by the HIP engine")
@@ -265,14 +284,15 @@ class VIBO_1PL(nn.Module):
         self.n_norm_flows = n_norm_flows
         self.irt_num = self.IRT
         self.item_feat_dim = item_feat_dim(self.IRT, latent_dim)
-        self.spec = ElboSpec(irt_model=self.IRT, ability_dim=latent_dim, conditional=conditional_posterior,
+        self.spec = ElboSpec(irt_model=self.IRT, ability_dim=latent_dim,
+                             conditional=conditional_posterior and ability_merge != 'mean',
                              drop_missing=not replace_missing_with_prior, n_flows=n_norm_flows,
                              given=ability_merge == 'mean')
         self.spec.check_supported(num_item)
 
         # construction order = the reference's (models.py:281-309) so seeded init matches
         if ability_merge == 'mean':
-            self.ability_encoder = MeanAbilityEncoder(latent_dim, hidden_dim)
+            self.ability_encoder = MeanAbilityEncoder(latent_dim, hidden_dim, self.item_feat_dim, conditional_posterior)
         else:
             self.ability_encoder = AbilityEncoder(latent_dim, self.item_feat_dim, hidden_dim, conditional_posterior)
         self.item_encoder = ItemEncoder(num_item, self.item_feat_dim)
@@ -350,7 +370,7 @@ class VIBO_1PL(nn.Module):
                     if row_index is not None:
                         response, m2, row_index = response[row_index], (m2[row_index] if m2 is not None else None), None
                     response, mask = ops.pad_rows(response, m2)
-            table = self.ability_encoder.posterior(ops.row_counts(response, mask, row_index), reducer=self._reducer)
+            table = self._mean_posterior(response, mask, row_index, item_feat)
         else:
             table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
         B = int(row_index.numel()) if row_index is not None else response.shape[0]
@@ -367,6 +387,22 @@ class VIBO_1PL(nn.Module):
         ctx.row_index = row_index
         self._last_ctx = ctx
         return ctx
+
+    def _mean_posterior(self, response, mask, row_index, item_feat, counts=None):
+        """(mu | logvar) [B, 2A] of the --ability-merge mean encoder: from the row counts, or (conditional posterior) from
+        the minibatch's dense rows and the item sample."""
+        if not self.conditional_posterior:
+            if counts is None:
+                counts = ops.row_counts(response, mask, row_index)
+            return self.ability_encoder.posterior(counts, reducer=self._reducer)
+        if isinstance(response, ops.CellCodes):
+            r, m = (response.rows(row_index) if row_index is not None else response).unpack()
+        else:
+            r = ops.prepare_response(response)
+            m = None if mask is None else ops.prepare_mask(mask)[0]
+            if row_index is not None:
+                r, m = r[row_index], (None if m is None else m[row_index])
+        return self.ability_encoder.posterior_conditional(r, m, item_feat, reducer=self._reducer)
 
     def _posterior_from_counts(self, counts):
         """(mu, logvar) [B, A] of the unconditional product of experts (models.py:596-629, utils.py:105-113) from the packed
@@ -390,7 +426,7 @@ class VIBO_1PL(nn.Module):
         item_feat, item_mu, item_lv = self._item_side(eps_item)
         counts = ops.row_counts(response, mask, row_index)
         if self.ability_merge == 'mean':
-            amu, alv = torch.chunk(self.ability_encoder.posterior(counts), 2, dim=1)
+            amu, alv = torch.chunk(self._mean_posterior(response, mask, row_index, item_feat, counts), 2, dim=1)
         else:
             amu, alv = self._posterior_from_counts(counts)
         if eps_ability is None:
@@ -426,7 +462,7 @@ class VIBO_1PL(nn.Module):
         item_feat, item_mu, item_lv = self._item_side()
         with torch.no_grad():
             if self.ability_merge == 'mean':
-                amu, alv = torch.chunk(self.ability_encoder.posterior(ops.row_counts(response, mask, row_index)), 2, dim=1)
+                amu, alv = torch.chunk(self._mean_posterior(response, mask, row_index, item_feat), 2, dim=1)
             else:
                 table = self.ability_encoder.expert_table(item_feat if self.conditional_posterior else None)
                 amu, alv = encode_posterior(self.spec, table, response, mask, row_index=row_index)

@@ -120,8 +120,6 @@ def check_supported(args):
         problems.append("--response-dist gaussian (the reference's loader has no *_continuous datasets either)")
     if args.dataset in ('duolingo', 'wordbank', 'pisa2015_science'):
         problems.append(f"--dataset {args.dataset} (loader not part of this engine: simulation and critlangacq are)")
-    if args.ability_merge == 'mean' and args.conditional_posterior:
-        problems.append("--ability-merge mean together with --conditional-posterior")
     if problems:
         raise SystemExit('not supported by the MI355X engine: ' + '; '.join(problems))
 
@@ -348,7 +346,7 @@ def posterior_predictive(model, data, args, batch_size, keep_samples):
                 per = [model.decode(a_s[s], i_s[s]).squeeze(2).cpu() for s in range(S)]
                 stacks.append(torch.stack(per))
                 means.append(stacks[-1].mean(0))
-            elif model.generative_model != 'irt':      # per-term MLP decoders: one decoder launch per draw, mean kept on the device
+            elif getattr(model, 'generative_model', 'irt') != 'irt':      # per-term MLP decoders: one decoder launch per draw, mean kept on the device
                 acc = model.decode(a_s[0], i_s[0]).squeeze(2)
                 for s in range(1, S):
                     acc += model.decode(a_s[s], i_s[s]).squeeze(2)
