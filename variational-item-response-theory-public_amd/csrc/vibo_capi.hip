@@ -75,7 +75,12 @@ struct Plan {
     size_t off_item_prep, off_partial, total_bytes;
 };
 
-static int g_num_cu = 0;
+// compute units of the current device (asked per call: the library keeps no state between calls)
+static int device_cus() {
+    int dev = 0, n = 0;
+    return (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+}
 
 static hipError_t launch_split(const ElboParams& p, int AT, bool codes, int irt, bool grad, int nq, int grid, hipStream_t s,
                                bool msplit = false) {
@@ -149,6 +154,7 @@ static int msplit_blocks(int num_cu, int items, long long persons) {
 }
 
 static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
+    const int num_cu = device_cus();
     const int I = d->num_item, A = d->ability_dim;
     pl->msplit = false;
     pl->AT = padded_ability_dim(A);
@@ -177,11 +183,6 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         // whole-row counts.  Conditional posterior (any item count): cond_pre_kernel supplies the product-of-experts
         // sums, cond_post_kernel scatters the table gradient (vibo_cond.hip).  The wave-per-person kernel remains
         // the fallback for unaligned rows (decided at launch).
-        if (g_num_cu == 0) {
-            int dev = 0, n = 0;
-            g_num_cu = (hipGetDevice(&dev) == hipSuccess &&
-                        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-        }
         pl->panels = (I + 1023) / 1024;
         pl->cond = is_cond;
         pl->given = is_given;
@@ -189,15 +190,15 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
         pl->split_nq = 4;
-        pl->split_nblk = g_num_cu * ((d->want_grad && !codes_three_waves(d, pl->AT)) ? 2 : 3);
+        pl->split_nblk = num_cu * ((d->want_grad && !codes_three_waves(d, pl->AT)) ? 2 : 3);
         if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
-        pl->cond_nblk = g_num_cu * 2;
+        pl->cond_nblk = num_cu * 2;
         if (pl->cond_nblk > (d->num_person + 7) / 8) pl->cond_nblk = (d->num_person + 7) / 8;
         if (allow_msplit && want_msplit(d)) {
             pl->msplit = true;
             pl->AT = 8;
             pl->DP = prepped_item_width(d->irt_model, 8);
-            pl->split_nblk = msplit_blocks(g_num_cu, I < 1024 ? I : 1024, d->num_person);
+            pl->split_nblk = msplit_blocks(num_cu, I < 1024 ? I : 1024, d->num_person);
         }
         pl->nblk = 0;
         pl->lds_main = 0;
@@ -251,25 +252,17 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
                  + (size_t)waves * 16 * 20 * 4                         // per-wave G-tile transpose slab
                  + 2 * kTilePersons * 4 + 4 * 2 * pl->AT * 4;          // counts, encoder-table constants
     lds = (lds + 255) & ~(size_t)255;
-    if (g_num_cu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_num_cu = n;
-        else
-            g_num_cu = 256;
-    }
     const size_t lds_cu = 160 * 1024;
     int per_cu = (int)(lds_cu / lds);
     const int wave_cap = 16 / waves;             // 4 waves per SIMD (launch bound) = 16 per CU
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
-    int nblk = g_num_cu * per_cu;
+    int nblk = num_cu * per_cu;
     if (nblk > pl->n_tiles) nblk = pl->n_tiles;
     pl->nblk = nblk;
     // wave-per-row kernel (A <= 2, 1PL/2PL, 192 <= I <= 1024): 4 workgroups of 4 waves per CU
     pl->row_ok = A <= 2 && d->irt_model <= 2 && I >= 192 && I <= 1024 && (I % 4 == 0) && d->n_flows == 0;
-    pl->row_nblk = g_num_cu * 2;          // 16 items x (params + grads) per lane: 2 workgroups (8 waves) per CU
+    pl->row_nblk = num_cu * 2;          // 16 items x (params + grads) per lane: 2 workgroups (8 waves) per CU
     if (pl->row_nblk > (d->num_person + 3) / 4) pl->row_nblk = (d->num_person + 3) / 4;
     // row-split kernel (192 <= I <= 1024, u8 / no mask): nq waves share a row, 8 waves per CU.
     // Preferred over the wave-per-row kernel (1.03 vs 1.10 ms at A = 1, 1.03 vs 1.49 ms at A = 2 on 1M x 1k),
@@ -283,13 +276,13 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
             pl->DP = prepped_item_width(d->irt_model, at_min);
         }
     }
-    pl->split_nblk = g_num_cu * (((d->want_grad && !codes_three_waves(d, pl->AT)) ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
+    pl->split_nblk = num_cu * (((d->want_grad && !codes_three_waves(d, pl->AT)) ? 8 : 12) / pl->split_nq);   // forward-only fits 3 waves per SIMD
     if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
     if (pl->split_ok && allow_msplit && want_msplit(d)) {
         pl->msplit = true;
         pl->AT = 8;
         pl->DP = prepped_item_width(d->irt_model, 8);
-        pl->split_nblk = msplit_blocks(g_num_cu, I, d->num_person);
+        pl->split_nblk = msplit_blocks(num_cu, I, d->num_person);
     }
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
@@ -790,6 +783,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                       float* out_scalars, float* ability_mu, float* ability_logvar, float* ability,
                       float* ability_k, float* ability_ladj, float* grad_table, float* grad_item,
                       float* grad_flow, void* workspace, size_t workspace_bytes, void* stream) {
+    const int num_cu = device_cus();
     int rc = check_desc(d);
     if (rc) return rc;
     if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !table || !item || !eps || !out_scalars || !ability_mu || !ability_logvar || !ability)
@@ -833,8 +827,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         g.B = d->num_person; g.I = I; g.A = A; g.D = pl.D; g.irt = d->irt_model;
         g.conditional = d->posterior == VIBO_POSTERIOR_CONDITIONAL; g.missing_mode = d->missing_mode;
         g.mask_dtype = d->mask_dtype; g.reg_mode = d->reg_mode; g.n_flows = d->n_flows; g.want_grad = d->want_grad;
-        if (g_num_cu == 0) g_num_cu = 256;
-        ge = launch_elbo_general(g, g_num_cu, s);
+        ge = launch_elbo_general(g, num_cu, s);
         if (ge != hipSuccess) return hip_fail(ge, "general elbo kernel launch");
         return 0;
     }
@@ -900,7 +893,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             p.pre_panels = pl.panels;
         } else {
             int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
-            int cgrid = g_num_cu * 8;
+            int cgrid = num_cu * 8;
             if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
             hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
                                (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
@@ -992,6 +985,7 @@ size_t vibo_multi_workspace_bytes(const vibo_desc* d, int num_samples) {
 int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* response, const void* mask,
                             const int64_t* row_index, const float* table, const float* item, const float* eps,
                             const float* flow, float* out_scalars, void* workspace, size_t workspace_bytes, void* stream) {
+    const int num_cu = device_cus();
     int rc = check_desc(d);
     if (rc) return rc;
     if (num_samples < 1) return fail(-3, "num_samples must be >= 1");
@@ -1027,7 +1021,7 @@ int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* re
     hipError_t e = hipSuccess;
     if (pl.panels > 0) {                       // sample-independent: whole-row counts
         int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
-        int cgrid = g_num_cu * 8;
+        int cgrid = num_cu * 8;
         if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
         hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
                            (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
@@ -1087,6 +1081,7 @@ int vibo_decode_mean(const vibo_desc* d, int num_samples, const float* ability, 
 int vibo_encode(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index,
                 const float* table, float* ability_mu, float* ability_logvar, void* workspace,
                 size_t workspace_bytes, void* stream) {
+    const int num_cu = device_cus();
     int rc = check_desc(d);
     if (rc) return rc;
     if (d->posterior == VIBO_POSTERIOR_GIVEN) return fail(-3, "vibo_encode: the posterior is the caller's own with VIBO_POSTERIOR_GIVEN");
@@ -1099,17 +1094,12 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
         const bool vec = need > 0 && rows_vec_ok(d, response, mask);
         if (vec && workspace && workspace_bytes >= need && (((uintptr_t)workspace & 255) == 0)) {
             hipStream_t s = (hipStream_t)stream;
-            if (g_num_cu == 0) {
-                int dev = 0, n = 0;
-                g_num_cu = (hipGetDevice(&dev) == hipSuccess &&
-                            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-            }
             const long long BA = (long long)d->num_person * A;
             hipError_t e = hipSuccess;
             if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) {
                 float* pre = static_cast<float*>(workspace);
                 const int panels = (I + 1023) / 1024;
-                int grid = g_num_cu * 3;
+                int grid = num_cu * 3;
                 if (grid > (d->num_person + 7) / 8) grid = (d->num_person + 7) / 8;
                 CondParams cp;
                 memset(&cp, 0, sizeof(cp));
@@ -1130,7 +1120,7 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
                 }
             } else {
                 int* cnt = static_cast<int*>(workspace);
-                int cgrid = g_num_cu * 8;
+                int cgrid = num_cu * 8;
                 if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
                 hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
                                    (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
@@ -1159,19 +1149,15 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
 
 int vibo_row_counts(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index, int32_t* counts,
                     void* stream) {
+    const int num_cu = device_cus();
     int rc = check_desc(d);
     if (rc) return rc;
     if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !counts) return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
     if (d->num_item > 32767) return fail(-3, "vibo_row_counts: the packed counts hold up to 32767 items");
     hipStream_t s = (hipStream_t)stream;
-    if (g_num_cu == 0) {
-        int dev = 0, n = 0;
-        g_num_cu = (hipGetDevice(&dev) == hipSuccess &&
-                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
     if (d->num_item >= 4 && d->mask_dtype != VIBO_MASK_I64 && rows_vec_ok(d, response, mask)) {
-        int cgrid = g_num_cu * 8;
+        int cgrid = num_cu * 8;
         if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
         hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, counts,
                            (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, d->num_item, d->mask_dtype);

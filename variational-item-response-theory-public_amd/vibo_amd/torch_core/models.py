@@ -41,6 +41,44 @@ def _encoder_mlp(in_dim, hidden_dim, out_dim):
     )
 
 
+class _TableMLP(torch.autograd.Function):
+    """Linear -> ELU -> Linear -> ELU -> Linear on the rows of the conditional expert table ([2I, 1 + D] inputs), with the
+    backward written out as GEMMs over row blocks of 1024 (weight and bias gradients: batched short-K products).  Same
+    arithmetic as nn.Sequential + autograd; the point is hipGraph capture: on this PyTorch / ROCm stack the captured
+    column reduction of a [>= 12 000, 64] gradient starts returning wrong bias gradients after a dozen replays
+    (tests/test_gpu_trainer.py::test_graphed_module_step_follows_the_eager_module_step, 12 800-row case)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2):
+        h0 = F.elu(torch.addmm(b0, x, w0.t()))
+        h1 = F.elu(torch.addmm(b1, h0, w1.t()))
+        ctx.save_for_backward(x, w0, w1, w2, h0, h1)
+        return torch.addmm(b2, h1, w2.t())
+
+    @staticmethod
+    def _wgrad(g, x):
+        """g^T x and the column sums of g, rows taken 1024 at a time (batched GEMMs with a short contraction + a small
+        sum: no long-K GEMM / reduction kernel in the captured graph)."""
+        n = g.shape[0]
+        c = (n + 1023) // 1024
+        if c * 1024 != n:
+            g, x = F.pad(g, (0, 0, 0, c * 1024 - n)), F.pad(x, (0, 0, 0, c * 1024 - n))
+        g3, x3 = g.view(c, 1024, -1), x.view(c, 1024, -1)
+        return torch.bmm(g3.transpose(1, 2), x3).sum(0), g3.sum(1).sum(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w0, w1, w2, h0, h1 = ctx.saved_tensors
+        g = g.contiguous()
+        gz1 = (g @ w2) * torch.where(h1 > 0, torch.ones_like(h1), h1 + 1.0)          # ELU' = 1 | e^z = h + 1
+        gz0 = (gz1 @ w1) * torch.where(h0 > 0, torch.ones_like(h0), h0 + 1.0)
+        gx = gz0 @ w0 if ctx.needs_input_grad[0] else None
+        gw0, gb0 = _TableMLP._wgrad(gz0, x)
+        gw1, gb1 = _TableMLP._wgrad(gz1, h0)
+        gw2, gb2 = _TableMLP._wgrad(g, h1)
+        return gx, gw0, gb0, gw1, gb1, gw2, gb2
+
+
 class AbilityEncoder(nn.Module):
     """Holds ``mlp`` (keys ability_encoder.mlp.{0,2,4}.*; models.py:575-582).
 

@@ -224,6 +224,7 @@ class GraphedModuleStep:
     `optimizer` must be torch.optim.Adam(capturable=True) (its step counter stays on the device).  Noise comes from the
     default CUDA generator, whose Philox offset torch advances per replay.  Full-size minibatches only."""
     WARMUP = 3
+    MAX_TABLE_ROWS = 2048      # conditional posterior: largest 2 x I-row encoder table the captured step is used for
 
     def __init__(self, model, optimizer, data, batch_size):
         self.model, self.optimizer, self.data, self.batch_size = model, optimizer, data, batch_size
@@ -255,10 +256,15 @@ class GraphedModuleStep:
         self.beta.fill_(float(beta))
         if self.graph is None:
             self.model._last_ctx = None                      # (drops the last step's autograd graph)
-            self.optimizer.zero_grad(set_to_none=True)       # gradients are then allocated from the graph's own pool
+            # gradient buffers are allocated here, outside the capture, and zeroed / accumulated into by captured kernels.
+            # (Letting the captured backward allocate them from the graph's pool went wrong on this stack: after a dozen
+            # replays the two 64-float bias gradients of the conditional encoder came back holding another tensor's data.)
+            for p in self.model.parameters():
+                p.grad = torch.zeros_like(p)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.side):
+                self.optimizer.zero_grad(set_to_none=False)
                 loss = self.model.elbo_step(self.data.response, self.data.mask, annealing_factor=self.beta, row_index=self.rows)
                 loss.backward()
                 self.optimizer.step()
@@ -452,7 +458,11 @@ def main(argv=None):
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)       # same Adam arithmetic, 5-7 launches per step
     graphed = None
-    module_graph = trainer is None and args.cuda and world == 1 and not args.no_graph
+    # (the conditional posterior's 2 x I-row encoder table: captured steps are verified up to 2 000 rows; from 2 048 rows on
+    #  the replayed backward goes wrong on this PyTorch / ROCm stack after a dozen replays -- DESIGN.md section 4 -- so those
+    #  configurations keep the eager module step)
+    module_graph = (trainer is None and args.cuda and world == 1 and not args.no_graph
+                    and not (args.conditional_posterior and 2 * num_item >= GraphedModuleStep.MAX_TABLE_ROWS))
     # (capturable: Adam's step counter and bias corrections stay on the device -- required inside a captured graph)
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=bool(module_graph))
     if trainer is not None and world == 1 and not args.no_graph:
