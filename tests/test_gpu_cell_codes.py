@@ -13,6 +13,13 @@ from vibo_amd.torch_core.models import VIBO_2PL, VIBO_3PL
 from vibo_amd.trainer import FusedTrainer
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=['1', '0'], ids=['matrix-kernel', 'valu-kernel'])
+def row_split_kernel_choice(request, monkeypatch):
+    """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
+    above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; VIBO_MSPLIT pins one for the whole test."""
+    monkeypatch.setenv('VIBO_MSPLIT', request.param)
 dev = torch.device('cuda:0')
 
 

@@ -20,6 +20,13 @@ from vibo_amd.ops import ElboSpec
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=['1', '0'], ids=['matrix-kernel', 'valu-kernel'])
+def row_split_kernel_choice(request, monkeypatch):
+    """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
+    above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; VIBO_MSPLIT pins one for the whole test."""
+    monkeypatch.setenv('VIBO_MSPLIT', request.param)
+
 TOL_ELBO = 1e-4
 
 

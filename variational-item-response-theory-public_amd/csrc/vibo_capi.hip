@@ -144,7 +144,10 @@ static bool want_msplit(const vibo_desc* d) {
     const char* e = getenv("VIBO_MSPLIT");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    return true;
+    // small minibatches (the reference CLI's default is 16 persons): the matrix kernel's fixed cost -- operand images, 512-thread
+    // workgroups, one batch of 32 rows per workgroup -- loses to the VALU kernel's 8-row batches below ~3 000 rows
+    // (tools/batch_sweep.py at ability_dim 8: 42 vs 50 us per step at 16 rows, 46 vs 52 at 1 024, 59 vs 54 at 4 096)
+    return d->num_person > 2048;
 }
 static int msplit_blocks(int num_cu, int items, long long persons) {
     const int nw = (items + 127) / 128;

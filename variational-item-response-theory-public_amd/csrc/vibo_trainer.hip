@@ -137,7 +137,8 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, const 
     p -= (lr / bc1) * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n_item_entries, int n_kl_parts,
+constexpr int kEpiThreads = 1024;      // block 0's chain of small dependent stages is latency-bound: more lanes per stage, fewer passes
+__global__ __launch_bounds__(kEpiThreads) void train_epilogue_kernel(int H, int O, int n_item_entries, int n_kl_parts,
                                                              const float* __restrict__ flat, const float* __restrict__ saved_h,
                                                              const float* __restrict__ kl_parts, const float* __restrict__ eps,
                                                              const float* __restrict__ beta_p, const float* __restrict__ lr_p,
@@ -149,23 +150,25 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
     const float t = (float)(*step_count);
     const float bc1 = 1.0f - powf(0.9f, t), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t));
     const int n_table = 2 * O;
+    constexpr int BS = kEpiThreads;
     if (blockIdx.x == 0) {
         if (tid == 0) const_cast<int32_t*>(step_count)[1] += 1;      // completed steps: the noise counter of the NEXT step
         const MlpOffsets o = mlp_offsets(H, O);
-        for (int k = tid; k < 2 * H; k += 256) {
+        for (int k = tid; k < 2 * H; k += BS) {
             h1[k / H][k % H] = saved_h[k];
             h2[k / H][k % H] = saved_h[2 * H + k];
         }
         // d loss / d table = -dLL + beta dREG     (flat: [8 scalars | grad_table set 0 | set 1 | grad_item])
-        for (int k = tid; k < n_table; k += 256) gout[k / O][k % O] = -flat[VIBO_NUM_SCALARS + k] + beta * flat[VIBO_NUM_SCALARS + n_table + k];
-        if (tid == 0) {
+        for (int k = tid; k < n_table; k += BS) gout[k / O][k % O] = -flat[VIBO_NUM_SCALARS + k] + beta * flat[VIBO_NUM_SCALARS + n_table + k];
+        if (tid < 64) {                  // item KL: the prologue's partial sums, fixed order (lane-strided, then the wave sum)
             float kl = 0.f;
-            for (int k = 0; k < n_kl_parts; ++k) kl += kl_parts[k];
-            *loss_out = -flat[VIBO_S_LL] + beta * (flat[VIBO_S_REG] + kl);
+            for (int k = tid; k < n_kl_parts; k += 64) kl += kl_parts[k];
+            kl = wave_total(kl);
+            if (tid == 0) *loss_out = -flat[VIBO_S_LL] + beta * (flat[VIBO_S_REG] + kl);
         }
         __syncthreads();
         // g_h2 = W2^T g_out * elu'(pre2),  elu'(x) = x > 0 ? 1 : elu(x) + 1
-        for (int k = tid; k < 2 * H; k += 256) {
+        for (int k = tid; k < 2 * H; k += BS) {
             const int r = k / H, j = k % H;
             float a = 0.f;
 #pragma unroll 16
@@ -174,23 +177,36 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
             gh2[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
         }
         __syncthreads();
-        for (int k = tid; k < 2 * H; k += 256) {
-            const int r = k / H, j = k % H;
-            float a = 0.f;
-#pragma unroll 16
-            for (int q = 0; q < H; ++q) a = fmaf(P[o.w1 + q * H + j], gh2[r][q], a);
-            const float h = h1[r][j];
-            gh1[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
+        // g_h1 = W1^T g_h2 * elu'(pre1): each of the 2 H dot products over H is cut into 8 pieces (8 neighbouring lanes)
+        {
+            const int len = (H + 7) / 8;
+            for (int k0 = 0; k0 < 2 * H * 8; k0 += BS) {
+                const int k = k0 + tid;
+                const int out = k >> 3, part = k & 7;
+                const int r = out / H, j = out % H;
+                float a = 0.f;
+                if (out < 2 * H) {
+                    const int q1 = min(H, (part + 1) * len);
+                    for (int q = part * len; q < q1; ++q) a = fmaf(P[o.w1 + q * H + j], gh2[r][q], a);
+                }
+                a += __shfl_xor(a, 1);
+                a += __shfl_xor(a, 2);
+                a += __shfl_xor(a, 4);
+                if (out < 2 * H && part == 0) {
+                    const float h = h1[r][j];
+                    gh1[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
+                }
+            }
         }
         __syncthreads();      // all reads of the OLD weights are done: parameters may now be updated in place
         // Adam over the MLP parameters: 8 independent elements per thread and pass, all loads issued before the
         // first store (P, M, V are not restrict-qualified, so a store would otherwise fence the next loads)
         constexpr int U = 8;
-        for (int k0 = tid; k0 < o.total; k0 += 256 * U) {
+        for (int k0 = tid; k0 < o.total; k0 += BS * U) {
             float pv[U], mv[U], vv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = k0 + 256 * u;
+                const int k = k0 + BS * u;
                 const bool ok = k < o.total;
                 pv[u] = ok ? P[k] : 0.f;
                 mv[u] = ok ? M[k] : 0.f;
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = k0 + 256 * u;
+                const int k = k0 + BS * u;
                 if (k >= o.total) continue;
                 float g;
                 if (k < o.b0) {                         // W0[j]: input of row r is r
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256) void train_epilogue_kernel(int H, int O, int n
         }
         return;
     }
-    const int idx = (blockIdx.x - 1) * 256 + tid;
+    const int idx = (blockIdx.x - 1) * BS + tid;
     if (idx < n_item_entries) {
         const float m = mu[idx], l = lv[idx];
         const float gf = -flat[VIBO_NUM_SCALARS + 2 * n_table + idx];          // d loss / d item_feat = -dLL/ditem
@@ -299,9 +315,9 @@ extern "C" int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const flo
                                    void* stream) {
     if (!d || hidden_dim < 1 || hidden_dim > kMaxHidden || d->posterior != VIBO_POSTERIOR_UNCONDITIONAL || d->n_flows != 0) return -6;
     const int n = d->num_item * item_dim_of(d);
-    const int parts = (n + 255) / 256;
-    hipLaunchKernelGGL(train_epilogue_kernel, dim3(1 + parts), dim3(256), 0, (hipStream_t)stream, hidden_dim, 2 * d->ability_dim, n,
-                       parts, flat, saved_h, kl_parts, eps_item, beta, lr, step_count, mlp_params, mlp_m, mlp_v, item_mu,
+    const int parts = (n + 255) / 256;                       // the prologue's item-KL partial sums (256 entries each)
+    hipLaunchKernelGGL(train_epilogue_kernel, dim3(1 + (n + kEpiThreads - 1) / kEpiThreads), dim3(kEpiThreads), 0, (hipStream_t)stream,
+                       hidden_dim, 2 * d->ability_dim, n, parts, flat, saved_h, kl_parts, eps_item, beta, lr, step_count, mlp_params, mlp_m, mlp_v, item_mu,
                        item_logvar, item_m, item_v, loss_out);
     return (int)hipGetLastError();
 }
