@@ -195,7 +195,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         pl->split_nq = 4;
         pl->split_nblk = num_cu * ((d->want_grad && !codes_three_waves(d, pl->AT)) ? 2 : 3);
         if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
-        pl->cond_nblk = num_cu * 2;
+        pl->cond_nblk = num_cu * 2;      // (4 per CU for one ability dim was tried: the fp32-row variants spill 35-46 registers, 2x slower)
         if (pl->cond_nblk > (d->num_person + 7) / 8) pl->cond_nblk = (d->num_person + 7) / 8;
         if (allow_msplit && want_msplit(d)) {
             pl->msplit = true;
@@ -890,7 +890,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                 cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
                 for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)      // 4 ability dims per launch
-                    e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);   // own template width (3PL widens the split kernel's)
+                    e = launch_cond_pre(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);   // own template width (3PL widens the split kernel's)
             }
             p.pre_stats = pre;
             p.pre_panels = pl.panels;
@@ -918,7 +918,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                 cp.partial = cpart + (size_t)pn * cond_blocks * pl.cond_rec;
                 for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
-                    e = launch_cond_post(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);
+                    e = launch_cond_post(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);
             }
             if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, cond_blocks, pl.cond_rec, s);
         }
@@ -1114,7 +1114,7 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
                     cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                     cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
                     for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
-                        e = launch_cond_pre(cp, A <= 2 ? 2 : 4, (cp.I + 255) / 256, grid, s);
+                        e = launch_cond_pre(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, grid, s);
                 }
                 if (e == hipSuccess) {
                     hipLaunchKernelGGL(encode_finish_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, s, nullptr, pre, panels,

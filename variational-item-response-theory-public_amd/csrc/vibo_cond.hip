@@ -292,7 +292,10 @@ __global__ __launch_bounds__(1024) void cond_finalize_kernel(const float* __rest
 
 hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
     const bool codes = p.mask_dtype == 3;      // VIBO_MASK_CODES
-    if (at <= 2) {
+    if (at <= 1) {
+        if (codes) hipLaunchKernelGGL((cond_pre_kernel<1, true>), dim3(grid), dim3(64 * nq), 0, s, p);
+        else hipLaunchKernelGGL((cond_pre_kernel<1, false>), dim3(grid), dim3(64 * nq), 0, s, p);
+    } else if (at <= 2) {
         if (codes) hipLaunchKernelGGL((cond_pre_kernel<2, true>), dim3(grid), dim3(64 * nq), 0, s, p);
         else hipLaunchKernelGGL((cond_pre_kernel<2, false>), dim3(grid), dim3(64 * nq), 0, s, p);
     } else {
@@ -303,7 +306,10 @@ hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStr
 }
 hipError_t launch_cond_post(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
     const bool codes = p.mask_dtype == 3;
-    if (at <= 2) {
+    if (at <= 1) {
+        if (codes) hipLaunchKernelGGL((cond_post_kernel<1, true>), dim3(grid), dim3(64 * nq), 0, s, p);
+        else hipLaunchKernelGGL((cond_post_kernel<1, false>), dim3(grid), dim3(64 * nq), 0, s, p);
+    } else if (at <= 2) {
         if (codes) hipLaunchKernelGGL((cond_post_kernel<2, true>), dim3(grid), dim3(64 * nq), 0, s, p);
         else hipLaunchKernelGGL((cond_post_kernel<2, false>), dim3(grid), dim3(64 * nq), 0, s, p);
     } else {
