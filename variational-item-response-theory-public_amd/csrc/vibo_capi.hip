@@ -68,6 +68,8 @@ struct Plan {
     bool cond;                // panel mode with the conditional posterior: cond_pre / split / cond_post per panel
     bool given;               // panel mode with a caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN)
     size_t off_pre, off_coef, off_cpart;
+    size_t off_codes;         // fp32 rows read by more than one pass: the first pass's 1-byte cell codes [B][codes_stride] (0: not used)
+    long long codes_stride;
     int cond_rec;             // floats per cond_post workgroup record
     int AT, D, DP, n_tiles, nblk, lds_main;
     LaunchGeom geom;
@@ -140,6 +142,11 @@ static bool codes_three_waves(const vibo_desc* d, int AT) {
 
 // Which row-split kernel: the matrix-pipe kernel (contractions as f16 hi/lo MFMAs) or the VALU kernel.  VIBO_MSPLIT=0/1 in the
 // environment forces one of them (A/B measurements, tests of both paths).
+// VIBO_EMIT_CODES=0: later passes re-read the fp32 rows (A/B measurements, tests of both paths)
+static bool emit_codes_wanted() {
+    const char* e = getenv("VIBO_EMIT_CODES");
+    return !(e && e[0] == '0');
+}
 static bool want_msplit(const vibo_desc* d) {
     const char* e = getenv("VIBO_MSPLIT");
     if (e && e[0] == '0') return false;
@@ -227,6 +234,16 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
             off += up((size_t)d->num_person * (2 * A + 1) * 4);
             pl->off_coef = off;
             off += up((size_t)pl->panels * d->num_person * 4 * A * 4);
+        }
+        // fp32 rows of the conditional posterior (three passes, five at ability_dim > 4): cond_pre also writes the rows' 1-byte
+        // cell codes, the later passes read those: 8 instead of 15 B/term of HBM traffic.  (For the two passes of the
+        // unconditional posterior with more than 1024 items the extra write costs more than the cheaper panels win:
+        // 100k x 10k 2.32 vs 2.23 ms, so row_count_kernel's code output stays unused there.)
+        pl->off_codes = 0;
+        pl->codes_stride = ((long long)I + 255) / 256 * 256;      // whole 128-byte lines per wave store (4 B per lane x 64 lanes)
+        if (emit_codes_wanted() && d->mask_dtype != VIBO_MASK_CODES && d->mask_dtype != VIBO_MASK_I64 && is_cond) {
+            pl->off_codes = off;
+            off += up((size_t)d->num_person * pl->codes_stride);
         }
         pl->total_bytes = off + 256;
         pl->general = false;
@@ -338,7 +355,8 @@ __global__ void item_prep_kernel(const float* __restrict__ item, float* __restri
 __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict__ response, const void* __restrict__ mask,
                                                         const int64_t* __restrict__ row_index, int* __restrict__ cnt,
                                                         long long resp_stride, long long mask_stride, int B, int I,
-                                                        int mask_dtype) {
+                                                        int mask_dtype, uint8_t* __restrict__ codes_out = nullptr,
+                                                        long long codes_stride = 0) {
     const int lane = threadIdx.x & 63;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * 4;
@@ -368,6 +386,9 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
             for (int u = 0; u < 4; ++u) {
                 if (cell_codes) (void)pack_cell_codes4(m[u], keep[u], packed);
                 else (void)pack_codes4(x[u], m[u] & keep[u], packed);
+                // fp32 rows, more passes to come: leave the row behind as 1-byte cell codes (minibatch order)
+                if (!cell_codes && codes_out && c0 + 64 * u < n4)
+                    reinterpret_cast<uint32_t*>(codes_out + row * codes_stride)[c0 + 64 * u] = cell_codes4(x[u], m[u] & keep[u]);
             }
         }
         const int tot = lane63(wave_sum63(packed));
@@ -805,7 +826,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
     const int I = d->num_item, A = d->ability_dim;
     // 16-byte row loads need aligned rows
     const bool vec = rows_vec_ok(d, response, mask);
-    const bool codes = d->mask_dtype == VIBO_MASK_CODES;
+    bool codes = d->mask_dtype == VIBO_MASK_CODES;      // (panel mode on fp32 rows: true from the second pass on, see off_codes)
     if (codes && !(vec && !pl.general && (pl.panels > 0 || pl.split_ok))) return codes_unsupported();
     if (pl.given && !vec) return fail(-8, "VIBO_POSTERIOR_GIVEN: rows must be aligned for 4-cell chunks (see vibo_amd.ops.pad_rows)");
 
@@ -871,6 +892,11 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         CondParams cp;
         memset(&cp, 0, sizeof(cp));
         const int cond_blocks = pl.cond_nblk;
+        // fp32 rows + more than one pass: the first pass (cond_pre / row_count) leaves 1-byte cell codes of the minibatch's rows
+        // in the workspace (already gathered), every later pass reads those
+        const bool emit = pl.off_codes != 0 && !pl.given && response != nullptr;
+        uint8_t* code_rows = emit ? reinterpret_cast<uint8_t*>(wsb + pl.off_codes) : nullptr;
+        cp.codes_stride = pl.codes_stride;
         cp.response = response; cp.mask = mask; cp.row_index = row_index; cp.table = table;
         cp.resp_stride = d->response_row_stride; cp.mask_stride = d->mask_row_stride;
         cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;
@@ -889,9 +915,12 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                 cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
-                for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)      // 4 ability dims per launch
+                for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4) {     // 4 ability dims per launch
+                    cp.codes_out = (emit && cp.a0 == 0) ? code_rows : nullptr;
                     e = launch_cond_pre(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);   // own template width (3PL widens the split kernel's)
+                }
             }
+            cp.codes_out = nullptr;
             p.pre_stats = pre;
             p.pre_panels = pl.panels;
         } else {
@@ -899,9 +928,17 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             int cgrid = num_cu * 8;
             if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
             hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
-                               (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype);
+                               (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype,
+                               code_rows, (long long)pl.codes_stride);
             e = hipGetLastError();
             p.row_cnt = cnt;
+        }
+        if (emit) {                   // from here on the rows are the cell codes just written (in minibatch order)
+            codes = true;
+            p.response = nullptr; p.mask = code_rows; p.row_index = nullptr;
+            p.mask_stride = pl.codes_stride; p.mask_dtype = VIBO_MASK_CODES;
+            cp.response = nullptr; cp.mask = code_rows; cp.row_index = nullptr;
+            cp.mask_stride = pl.codes_stride; cp.mask_dtype = VIBO_MASK_CODES;
         }
         for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
             p.item0 = pn * 1024;

@@ -130,6 +130,11 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
         for (int r = 0; r < kCR; ++r) {
             int pk = 0;
             const uint32_t cw = row_codes(rb, r, tail_mask, pk);
+            if constexpr (!CODES) {          // leave the row behind as cell codes for the passes that follow (1 B/cell instead of 5)
+                if (p.codes_out && chunk_ok && row0 + r < p.B)
+                    reinterpret_cast<uint32_t*>(p.codes_out + (row0 + r) * p.codes_stride + p.item0)[chunk] =
+                        cell_codes4(rb.x[r], rb.m[r] & tail_mask);
+            }
             const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, false);
             const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, true);
             const float w[4] = {w01[0], w01[1], w23[0], w23[1]};

@@ -15,6 +15,8 @@ struct CondParams {
     float* partial;            // cond_post: [grid][rec_stride] records of this panel
     long long resp_stride, mask_stride;
     int B, I, I_total, item0, A, mask_dtype, coef_panels, rec_stride;
+    uint8_t* codes_out;        // cond_pre on fp32 rows: if set, the rows' 1-byte cell codes go here ([B][codes_stride], minibatch order)
+    long long codes_stride;
     int a0;                    // first ability dim of this launch (dims a0 .. a0 + AT - 1: more than 4 dims take two launches)
 };
 

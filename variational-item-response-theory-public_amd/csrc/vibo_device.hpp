@@ -98,4 +98,13 @@ __device__ __forceinline__ uint32_t pack_cell_codes4(const uint32_t w, const uin
 }
 constexpr uint32_t kAllMissing4 = 0x02020202u;
 
+// 4 responses (fp32 0.0/1.0) + 4 mask bytes (0/1) -> the 4 Format P cell codes (0 wrong / 1 right / 2 missing): what a first pass
+// over fp32 rows leaves behind for the passes that follow it (1 B instead of 5 B per cell)
+__device__ __forceinline__ uint32_t cell_codes4(const float4 x, const uint32_t m) {
+    const uint32_t x0 = __builtin_bit_cast(uint32_t, x.x), x1 = __builtin_bit_cast(uint32_t, x.y);
+    const uint32_t x2 = __builtin_bit_cast(uint32_t, x.z), x3 = __builtin_bit_cast(uint32_t, x.w);
+    const uint32_t hi = __builtin_amdgcn_perm(x1, x0, 0x0c0c0703u) | __builtin_amdgcn_perm(x3, x2, 0x07030c0cu);
+    return (hi & m & 0x01010101u) | ((m ^ 0x01010101u) << 1);
+}
+
 }  // namespace vibo
