@@ -72,7 +72,8 @@ def parse():
     ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
     ap.add_argument('--rng', choices=['native', 'torch'], default='native', help='reparameterisation noise: vibo_fill_normal (Philox, in the C ABI) or torch.randn')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
-    ap.add_argument('--two-graphs', action='store_true', help='multi-GPU: two hipGraphs around an EAGER all-reduce instead of one graph with the collective captured inside (the default; tests/test_gpu_rccl.py pins both bitwise)')
+    ap.add_argument('--one-graph', action='store_true', help='multi-GPU: capture the RCCL all-reduce inside the step\'s hipGraph (one graph per step, no host round trip) instead of two hipGraphs around an EAGER all-reduce.  Both forms are pinned bitwise on a 1-rank nccl group (tests/test_gpu_rccl.py); the captured collective has not run on a real multi-rank node yet, so the eager collective -- which cannot hang a replay -- stays the default')
+    ap.add_argument('--two-graphs', action='store_true', help='(default for N > 1; kept for compatibility)')
     ap.add_argument('--force-dist', action='store_true', help='create the process group even for one rank (tests the RCCL path)')
     return ap.parse_args()
 
@@ -319,7 +320,7 @@ def main():
 
                 launch_mode = 'hipGraph replay'
                 if dist is not None and trainer is not None:
-                    if args.two_graphs:
+                    if not args.one_graph:
                         step_g, launch_mode = capture_two(), 'two hipGraphs around an eager RCCL all-reduce'
                     else:
                         try:
