@@ -26,7 +26,7 @@ Adds to the contract line:
   elbo_rel_err  |ELBO_hip - ELBO_ref| / |ELBO_ref| on the first 1024 persons of the benchmark matrix, same parameters
                 and noise, in the same run: ref = the CPU restatement of the reference op sequence (fp32, the
                 reference's arithmetic); also against its fp64 evaluation.
-  extra         train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md §8d;
+  extra         decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate); train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md §8d;
                 rows gathered in the kernel, hipGraph replay); the headline is the full shard.
   cpu_baseline  the CPU port of the reference op sequence (per-term MLP -> PoE -> link -> masked log-lik -> autograd ->
                 Adam, oracle/vibo_oracle.py) timed on this host's cores (rank 0, N = 1 only): B = 16 and B = 1024, 3
@@ -451,6 +451,32 @@ def main():
             del tr, gr
         return res
 
+    def decoder_probe():
+        """The per-term MLP decoder kernel (--generative-model deep: csrc/vibo_decoder.hip, the path's one dense contraction):
+        fwd + bwd of 50 000 persons x the benchmark's items, HIP events on the launch stream."""
+        from vibo_amd import decoder as D
+        Bd, H = 50_000, 64
+        g = torch.Generator(device=dev).manual_seed(args.seed + 77)
+        rn = lambda *sh, sc=1.0: torch.randn(*sh, device=dev, generator=g) * sc
+        r = (torch.rand(Bd, I, device=dev, generator=g) < 0.5).float()
+        mk = (torch.rand(Bd, I, device=dev, generator=g) >= args.missing).view(torch.uint8)
+        a = [r, mk, rn(I, H, sc=0.7), rn(Bd, H, sc=0.7), None, None, None, rn(H, H, sc=0.18), rn(H, sc=0.1), rn(H, sc=0.25),
+             rn(1, sc=0.1), 0.0, True]
+        for _ in range(2):
+            D._launch(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            D._launch(*a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        flop = Bd * I * 3 * 2 * H * H
+        return {'workload': f'{Bd} persons x {I} items, per-term 64-64-64-1 decoder (deep), forward + backward, fp32-grade (f16 hi/lo MFMA, 3 passes per product)',
+                'ms': ms, 'terms_per_s': Bd * I / (ms * 1e-3), 'algorithmic_TFLOPs': flop / (ms * 1e-3) / 1e12,
+                'bound': 'mfma + valu', 'peak_fp32_TFLOPs': 157.3, 'frac_of_fp32_peak': flop / (ms * 1e-3) / 1e12 / 157.3,
+                'mfma_issued_TFLOPs': 3 * flop / (ms * 1e-3) / 1e12, 'mfma_util_profile': 'profiles/r02_decoder_pmc.txt (17 %)'}
+
     P, I, A = persons_rank, args.items, args.ability_dim
     m = measure(A, extra=not args.no_extra)
     dt, kern_ms, final_loss = m['dt'], m['kern_ms'], m['final_loss']
@@ -512,7 +538,7 @@ def main():
             line['elbo_rel_err'] = m['rel']['vs_reference_op_sequence_fp32']
             line['elbo_rel_err_detail'] = m['rel']
         if m.get('sweep'):
-            line['extra'] = {'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
+            line['extra'] = {'decoder_kernel': decoder_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
         if also is not None:
             line['also'] = also
         if format_p is not None:
