@@ -90,6 +90,7 @@ def test_fused_trainer_native_rng_trains():
                                    ['--n-norm-flows', '2', '--irt-model', '3pl', '--dataset', '3pl_simulation'],
                                    ['--num-item', '95', '--ability-dim', '3'],
                                    ['--generative-model', 'deep', '--ability-dim', '2'],
+                                   ['--graph-module-step', '--n-norm-flows', '2'],
                                    ['--generative-model', 'link', '--artificial-missing-perc', '0.2'],
                                    ['--generative-model', 'residual', '--irt-model', '3pl', '--dataset', '3pl_simulation',
                                     '--ability-merge', 'mean']])
@@ -269,7 +270,9 @@ def test_graph_replay_survives_a_shorter_eager_minibatch_with_native_noise():
                                     (VIBO_2PL, dict(conditional_posterior=True)),
                                     (VIBO_2PL, dict(conditional_posterior=True, _items=1000)),      # the largest table the CLI captures
                                     (VIBO_2PL, dict(ability_merge='mean')),
-                                    (VIBO_2PL, dict(n_norm_flows=2))])
+                                    (VIBO_2PL, dict(n_norm_flows=2)),
+                                    (VIBO_2PL, dict(n_norm_flows=2, _items=6400)),                  # long item-side flow tensors
+                                    (VIBO_3PL, dict(generative_model='residual', ability_merge='mean'))])
 def test_graphed_module_step_follows_the_eager_module_step(cls, kw):
     """vibo_amd.torch_core.vibo.GraphedModuleStep replays the module-path step (elbo_step, backward, capturable Adam:
     vibo.py:243-268 for --conditional-posterior / --n-norm-flows / --ability-merge mean) from a hipGraph.  Same seed ->

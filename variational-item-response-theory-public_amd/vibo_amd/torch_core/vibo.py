@@ -78,6 +78,9 @@ def build_parser():
     p.add_argument('--rng', choices=['torch', 'native'], default='torch',
                    help="reparameterisation noise of the fused trainer: torch.randn (the stream torch.manual_seed(--seed) governs) or "
                         "the library's Philox generator drawn inside the prologue kernel (two launches fewer per step)")
+    p.add_argument('--graph-module-step', action='store_true', default=False,
+                   help='replay the module + autograd + Adam step of the configurations outside the fused trainer (conditional '
+                        'posterior, flows, mean merge, MLP decoders) from a hipGraph too; verified for small problems only (DESIGN.md 4)')
     p.add_argument('--no-graph', action='store_true', default=False,
                    help='launch every fused train step eagerly instead of replaying a hipGraph (single-GPU runs)')
     p.add_argument('--store-predictive-samples', action='store_true', default=False,
@@ -224,7 +227,6 @@ class GraphedModuleStep:
     `optimizer` must be torch.optim.Adam(capturable=True) (its step counter stays on the device).  Noise comes from the
     default CUDA generator, whose Philox offset torch advances per replay.  Full-size minibatches only."""
     WARMUP = 3
-    MAX_TABLE_ROWS = 2048      # conditional posterior: largest 2 x I-row encoder table the captured step is used for
 
     def __init__(self, model, optimizer, data, batch_size):
         self.model, self.optimizer, self.data, self.batch_size = model, optimizer, data, batch_size
@@ -458,11 +460,12 @@ def main(argv=None):
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)       # same Adam arithmetic, 5-7 launches per step
     graphed = None
-    # (the conditional posterior's 2 x I-row encoder table: captured steps are verified up to 2 000 rows; from 2 048 rows on
-    #  the replayed backward goes wrong on this PyTorch / ROCm stack after a dozen replays -- DESIGN.md section 4 -- so those
-    #  configurations keep the eager module step)
-    module_graph = (trainer is None and args.cuda and world == 1 and not args.no_graph
-                    and not (args.conditional_posterior and 2 * num_item >= GraphedModuleStep.MAX_TABLE_ROWS))
+    # The captured module step is opt-in (--graph-module-step): it is 3-4 x faster at small minibatches and follows the eager
+    # step exactly in every configuration tests/test_gpu_trainer.py replays 60-150 times, but on this PyTorch / ROCm stack a
+    # replayed autograd backward starts returning a wrong 64-float bias gradient after 7-15 replays once a dense PyTorch
+    # layer in the step has a few thousand rows (the conditional posterior's 2 x I-row encoder table from 2 048 rows, the
+    # `deep` decoder's item network at 1 500) -- DESIGN.md section 4.  Until that is understood the default is the eager step.
+    module_graph = trainer is None and args.cuda and world == 1 and not args.no_graph and args.graph_module_step
     # (capturable: Adam's step counter and bias corrections stay on the device -- required inside a captured graph)
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=bool(module_graph))
     if trainer is not None and world == 1 and not args.no_graph:
