@@ -835,6 +835,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // The rows travel in two halves (M-tile 0, M-tile 1), each requested at least four tiles before it is packed; the first
     // goes out right before the sync phase (the texture pipeline digests the workgroup's 128 load instructions while the
     // waves sit in the barriers; issued after them, with all 8 waves in step, every wave stalled ~5000 cycles on it).
+    // (Splitting the bursts by wave group -- the four waves without a slot between the barriers, the slot owners after the
+    // second one, the second half one tile apart -- was measured too: 1.098 vs 1.074 ms.)
     // Nothing loaded is in flight across the loop's back edge: hipcc otherwise parks such registers in a second set and
     // copies them at the back edge behind an s_waitcnt vmcnt(0), which serialises the prefetch.  The sched_barriers keep
     // the loads behind the pack that frees their registers.
