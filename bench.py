@@ -531,7 +531,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
                          'traffic': traffic, 'traffic_note': traffic_note,
-                         'kernel': 'vibo::msplit_kernel (+ item_prep, finalize helpers inside the timed events)',
+                         'kernel': 'vibo::msplit_kernel (+ the finalize helper inside the timed events)',
                          'kernel_ms': kern_ms, 'bytes_per_term': bytes_per_term},
         }
         if m.get('rel') is not None:

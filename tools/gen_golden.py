@@ -104,6 +104,7 @@ CASES = [
     ('3pl_a2_link_flows2',           3, 2, 16, 20, False, 0.0, False, 2, 1.0, False, 'product', 'link'),
     ('1pl_a3_residual_mean_miss_drop', 1, 3, 16, 20, False, 0.2, True, 0, 1.0, True, 'mean', 'residual'),
     ('2pl_a8_deep_nokl',             2, 8, 16, 20, False, 0.0, False, 0, 1.0, False, 'product', 'deep'),
+    ('2pl_a2_cond_residual_miss',    2, 2, 16, 20, True, 0.2, False, 0, 1.0, True, 'product', 'residual'),
 ]
 
 

@@ -60,7 +60,8 @@ struct Plan {
     int row_nblk;
     bool split_ok;            // row-split register kernel (ability_dim 3..8) is applicable (subject to alignment)
     int split_nq, split_nblk;
-    int cond_nblk;            // workgroups of the conditional posterior's cond_pre / cond_post launches
+    int cond_nblk;            // workgroups of the conditional posterior's cond_pre launches (2 per CU)
+    int cond_post_nblk;       // ... of cond_post: 3 per CU when it reads cell codes at template width <= 2 (its launch bound there)
     bool msplit;              // the row-split launches go to the matrix-pipe kernel (vibo_msplit_kernel.hpp): split_nq = waves of
                               // 128 items per workgroup, batches of 32 rows
     int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
@@ -204,6 +205,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         if (pl->split_nblk > (d->num_person + 7) / 8) pl->split_nblk = (d->num_person + 7) / 8;
         pl->cond_nblk = num_cu * 2;      // (4 per CU for one ability dim was tried: the fp32-row variants spill 35-46 registers, 2x slower)
         if (pl->cond_nblk > (d->num_person + 7) / 8) pl->cond_nblk = (d->num_person + 7) / 8;
+        pl->cond_post_nblk = pl->cond_nblk;      // (raised below once it is known whether cond_post reads cell codes)
         if (allow_msplit && want_msplit(d)) {
             pl->msplit = true;
             pl->AT = 8;
@@ -228,7 +230,16 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
             pl->off_coef = off;
             off += up((size_t)pl->panels * d->num_person * 4 * A * 4);
             pl->off_cpart = off;
-            off += up((size_t)pl->panels * pl->cond_nblk * pl->cond_rec * 4);
+            {
+                // cond_post on cell codes (the caller's, or the ones cond_pre leaves behind) has no fp32 row registers: 3 waves per SIMD
+                const bool post_codes = d->mask_dtype == VIBO_MASK_CODES ||
+                                        (emit_codes_wanted() && d->mask_dtype != VIBO_MASK_I64);
+                if (post_codes && A <= 2) {
+                    pl->cond_post_nblk = num_cu * 3;
+                    if (pl->cond_post_nblk > (d->num_person + 7) / 8) pl->cond_post_nblk = (d->num_person + 7) / 8;
+                }
+            }
+            off += up((size_t)pl->panels * pl->cond_post_nblk * pl->cond_rec * 4);
         } else if (is_given) {
             pl->off_pre = off;
             off += up((size_t)d->num_person * (2 * A + 1) * 4);
@@ -953,11 +964,11 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
-                cp.partial = cpart + (size_t)pn * cond_blocks * pl.cond_rec;
+                cp.partial = cpart + (size_t)pn * pl.cond_post_nblk * pl.cond_rec;
                 for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
-                    e = launch_cond_post(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);
+                    e = launch_cond_post(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.cond_post_nblk, s);
             }
-            if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, cond_blocks, pl.cond_rec, s);
+            if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.cond_post_nblk, pl.cond_rec, s);
         }
         if (pl.given && grad && e == hipSuccess) {
             const long long n = (long long)d->num_person * A;

@@ -304,9 +304,6 @@ class VIBO_1PL(nn.Module):
             raise AssertionError('bad response_dist')
         # the fused HIP path covers the 1PL/2PL/3PL logistic link with the product-of-experts
         # encoder on Bernoulli responses (BASELINE.json north_star); nothing else is in scope
-        if generative_model != 'irt' and conditional_posterior:
-            raise NotImplementedError("--generative-model link|deep|residual with --conditional-posterior is not "
-                                      "implemented by the HIP engine")
         if response_dist != 'bernoulli':
             raise NotImplementedError("only --response-dist bernoulli is implemented by the HIP engine")
 
@@ -433,13 +430,7 @@ class VIBO_1PL(nn.Module):
             if counts is None:
                 counts = ops.row_counts(response, mask, row_index)
             return self.ability_encoder.posterior(counts, reducer=self._reducer)
-        if isinstance(response, ops.CellCodes):
-            r, m = (response.rows(row_index) if row_index is not None else response).unpack()
-        else:
-            r = ops.prepare_response(response)
-            m = None if mask is None else ops.prepare_mask(mask)[0]
-            if row_index is not None:
-                r, m = r[row_index], (None if m is None else m[row_index])
+        r, m = self._dense_rows(response, mask, row_index)
         return self.ability_encoder.posterior_conditional(r, m, item_feat, reducer=self._reducer)
 
     def _posterior_from_counts(self, counts):
@@ -457,16 +448,44 @@ class VIBO_1PL(nn.Module):
             lam = lam + (self.num_item - nobs) * (1.0 / (1.0 + 1e-8))
         return smu / lam, torch.log(1.0 / lam)
 
+    def _dense_rows(self, response, mask, row_index):
+        """(response fp32 [B, I], mask u8 [B, I] or None) of the minibatch as dense tensors."""
+        if isinstance(response, ops.CellCodes):
+            return (response.rows(row_index) if row_index is not None else response).unpack()
+        r = ops.prepare_response(response)
+        m = None if mask is None else ops.prepare_mask(mask)[0]
+        if row_index is not None:
+            r, m = r[row_index], (None if m is None else m[row_index])
+        return r, m
+
+    def _conditional_posterior_dense(self, response, mask, row_index, item_feat):
+        """Product of experts of the conditional encoder (models.py:695-710, utils.py:105-113) for the MLP-decoder models,
+        where the ability gradient does not come out of the fused ELBO kernel: the 2 x I-row expert table is gathered by
+        the rows' codes ([B, I, 2A], a minibatch-sized tensor) and reduced with autograd -- plain tensor ops, not a fused path."""
+        A = self.ability_dim
+        r, m = self._dense_rows(response, mask, row_index)
+        table = self.ability_encoder.expert_table(item_feat)                  # [2, I, 2A]
+        sel = table[(r == 1).long(), torch.arange(r.shape[1], device=r.device)]      # [B, I, 2A]
+        mu_set, lv_set = sel[..., :A], sel[..., A:]
+        obs = torch.ones_like(r) if m is None else (m != 0).to(r.dtype)
+        tau = obs.unsqueeze(2) / (torch.exp(lv_set) + 1e-8)
+        lam = tau.sum(1)
+        if self.replace_missing_with_prior:
+            lam = lam + (r.shape[1] - obs.sum(1, keepdim=True)) * (1.0 / (1.0 + 1e-8))
+        return (mu_set * tau).sum(1) / lam, torch.log(1.0 / lam)
+
     def _run_decoder(self, response, mask, *, eps_item=None, eps_ability=None, row_index=None):
         """forward() with a per-term MLP decoder: item sample, posterior from the row counts, sample, flows."""
         if self._reducer is not None:
             raise NotImplementedError('person sharding covers --generative-model irt')
         item_feat, item_mu, item_lv = self._item_side(eps_item)
-        counts = ops.row_counts(response, mask, row_index)
         if self.ability_merge == 'mean':
+            counts = None if self.conditional_posterior else ops.row_counts(response, mask, row_index)
             amu, alv = torch.chunk(self._mean_posterior(response, mask, row_index, item_feat, counts), 2, dim=1)
+        elif self.conditional_posterior:
+            amu, alv = self._conditional_posterior_dense(response, mask, row_index, item_feat)
         else:
-            amu, alv = self._posterior_from_counts(counts)
+            amu, alv = self._posterior_from_counts(ops.row_counts(response, mask, row_index))
         if eps_ability is None:
             eps_ability = self._randn(amu.shape, item_mu, self._ability_gen)
         ctx = DecoderContext(self, response, mask, row_index)

@@ -115,8 +115,6 @@ def check_supported(args):
     problems = []
     if args.ability_merge == 'transformer':
         problems.append("--ability-merge transformer (the reference asserts it away as well, models.py:262)")
-    if args.generative_model != 'irt' and args.conditional_posterior:
-        problems.append(f"--generative-model {args.generative_model} together with --conditional-posterior")
     if args.generative_model != 'irt' and args.hidden_dim != 64:
         problems.append(f"--generative-model {args.generative_model} with --hidden-dim != 64 (the per-term decoder kernel's width)")
     if args.response_dist != 'bernoulli':
