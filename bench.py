@@ -204,6 +204,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # VIBO_BENCH_ONE_DEVICE=1 (test rig, not a measurement): every rank on cuda:0 with the gloo backend -- exercises the N > 1
+    # code path (sharding, barriers, max-over-ranks timing, rank-0 JSON) on a box with a single GPU, where RCCL refuses
+    # two ranks on one device
+    one_device = os.environ.get('VIBO_BENCH_ONE_DEVICE') == '1'
+    if one_device:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
@@ -215,7 +221,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from vibo_amd import ops
     from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL

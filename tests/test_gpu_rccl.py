@@ -90,3 +90,25 @@ def test_one_rank_rccl_group_reproduces_the_unsharded_step_bitwise(tmp_path):
     script.write_text(f'ROOT = {ROOT!r}\n' + SCRIPT)
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'RCCL_1RANK_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_two_ranks_share_one_device_over_gloo(scaling):
+    """bench.py's N > 1 path end to end -- torchrun, person shards per rank, the two-graph step around the collective, barriers,
+    max-over-ranks timing, ONE JSON line from rank 0 -- on a single-GPU box: both ranks on cuda:0 with the gloo backend
+    (VIBO_BENCH_ONE_DEVICE=1; RCCL refuses two ranks on one device).  The rates are meaningless; the contract is checked."""
+    import json
+    env = dict(os.environ, VIBO_BENCH_ONE_DEVICE='1', PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, 'variational-item-response-theory-public_amd')]))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29571', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--scaling', scaling,
+           '--persons', '100000', '--no-cpu-baseline', '--no-extra', '--no-format-p', '--also-ability-dim', '0']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == scaling
+    assert d['config']['global_batch'] == (200000 if scaling == 'weak' else 100000)
+    assert d['value'] > 0 and d['ms_per_step'] > 0 and 'roofline' in d and 'cpu_baseline' not in d
+    assert abs(d['value'] - d['config']['global_batch'] * 1000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
