@@ -714,52 +714,28 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         } else {
-            // 3PL: p = guess + (1 - guess) sigmoid(l)  (models.py:758-765).  P(right) = prb and P(wrong) = qr are formed separately
-            // (no 1 - p cancellation); w = +1 / -1 / 0 selects the observed outcome's probability `arg`:
-            //   ll = log arg,  d ll/d l = w qr sp / arg,  d ll/d guess-logit = w qr guess / arg      (qr = (1 - guess)(1 - sp))
-            // torch clamps the probability to [eps32, 1 - eps32] and passes no gradient outside (utils.py:46-49): that only matters
-            // when prb or qr of some cell falls below eps32 -- a wave-uniform slow path redoes the tile with the clamps.
 #pragma unroll
-            for (int h4 = 0; h4 < 8; h4 += 4) {          // four cells at a time (register pressure)
-                float arg4[4], sp4[4], qr4[4], wl4[4];
-                float qmin = 1.0f;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = h4 + kk;
-                    const float l = lg[k];
-                    const float ee = fast_exp2(-fabsf(l));
-                    const float rr_ = fast_rcp(1.0f + ee);
-                    const float er_ = ee * rr_;
-                    const bool pos = l >= 0.f;
-                    sp4[kk] = pos ? rr_ : er_;
-                    const float sn = pos ? er_ : rr_;
-                    const float prb = fmaf(om[u][t], sp4[kk], gs[u][t]);
-                    qr4[kk] = om[u][t] * sn;
-                    arg4[kk] = (wc[k] > 0.f) ? prb : qr4[kk];
-                    qmin = fminf(qmin, fminf(prb, qr4[kk]));
-                    wl4[kk] = wc[k];
-                }
-                if (__any(!(qmin >= kEps32))) {                // (NaN-safe) some probability reaches the clamp
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const float prb = fmaf(om[u][t], sp4[kk], gs[u][t]);
-                        const float pc = med3(prb, kEps32, 1.0f - kEps32);
-                        arg4[kk] = (wc[h4 + kk] > 0.f) ? pc : med3(qr4[kk], kEps32, 1.0f - kEps32);
-                        wl4[kk] = (prb == pc) ? wc[h4 + kk] : 0.f;        // clamped: no gradient
-                    }
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = h4 + kk;
-                    float& pr = (k & 1) ? pr1 : pr0;
-                    pr *= (wc[k] != 0.f) ? arg4[kk] : 1.0f;
-                    if constexpr (GRAD) {
-                        const float common = wl4[kk] * qr4[kk] * fast_rcp(arg4[kk]);
-                        gl[k] = common * sp4[kk];
-                        acc_g[u][t] = fmaf(common, gs[u][t], acc_g[u][t]);
-                    } else {
-                        gl[k] = 0.f;
-                    }
+            for (int k = 0; k < 8; ++k) {
+                const float w = wc[k];
+                float& pr = (k & 1) ? pr1 : pr0;
+                gl[k] = 0.f;
+                // 3PL: p = guess + (1 - guess) sigmoid(l)  (models.py:758-765), probability clamp on p itself
+                const float l = lg[k];
+                const float ee = fast_exp2(-fabsf(l));
+                const float rr_ = fast_rcp(1.0f + ee);
+                const float er_ = ee * rr_;
+                const float sp = (l >= 0.f) ? rr_ : er_;
+                const float sn = (l >= 0.f) ? er_ : rr_;
+                const float prb = fmaf(om[u][t], sp, gs[u][t]);
+                const float qr = om[u][t] * sn;
+                const float pc = med3(prb, kEps32, 1.0f - kEps32);
+                const float arg = (w > 0.f) ? pc : med3(qr, kEps32, 1.0f - kEps32);
+                pr *= (w != 0.f) ? arg : 1.0f;
+                if constexpr (GRAD) {
+                    const float wlv = (prb == pc) ? w : 0.f;
+                    const float common = wlv * fast_rcp(arg) * om[u][t] * sn;
+                    gl[k] = common * sp;
+                    acc_g[u][t] = fmaf(common, gs[u][t], acc_g[u][t]);
                 }
             }
         }
