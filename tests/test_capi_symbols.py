@@ -46,3 +46,18 @@ def test_desc_struct_matches_header():
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
     fields = re.findall(r'int(?:32|64)_t\s+([a-z_]+)\s*;', body)
     assert fields == [f[0] for f in _lib.ViboDesc._fields_]
+
+
+def test_decoder_desc_struct_matches_header():
+    src = open(os.path.join(ROOT, 'include', 'vibo_hip.h')).read()
+    body = src[src.index('typedef struct vibo_decoder_desc {'):src.index('} vibo_decoder_desc;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for typ, names in re.findall(r'(int32_t|int64_t|float)\s+([a-z_, ]+);', body):
+        fields += [(n.strip(), typ) for n in names.split(',')]
+    ctype = {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float}
+    assert [(n, ctype[t]) for n, t in fields] == list(_lib.ViboDecoderDesc._fields_)
+    lib = _lib.load()
+    assert lib.vibo_decoder_person_chunks(0, 10) == 0 and lib.vibo_decoder_person_chunks(1000, 100) >= 1
+    d = _lib.ViboDecoderDesc(16, 100, 32, 0, 1, 0.0, 100, 100)          # hidden_dim 32: refused before any launch
+    assert lib.vibo_decoder_fwd_bwd(ctypes.byref(d), *([None] * 20)) == -6
