@@ -69,3 +69,30 @@ def test_decoder_kernel_matches_float64_autograd(mode, B, I, missing):
     # fixed-order partial records: bitwise reproducible
     ll2 = D.decoder_log_lik(r32, m8, **args)
     assert torch.equal(ll.detach(), ll2.detach())
+
+
+def test_person_chunking_changes_nothing_but_the_summation_order(monkeypatch):
+    """Calls with more persons than decoder.PERSON_CHUNK go through in several launches (bounded scratch); same sums."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, I, H = 700, 130, 64
+    rn = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).requires_grad_(True)
+    resp = (torch.rand(B, I, device=dev, generator=g) < 0.5).float()
+    mask = torch.rand(B, I, device=dev, generator=g) >= 0.2
+    t = dict(U=rn(I, H, sc=0.7), V=rn(B, H, sc=0.7), W2=rn(H, H, sc=0.18), b2=rn(H, sc=0.1), w3=rn(H, sc=0.25), b3=rn(1, sc=0.1),
+             logit=rn(B, I, sc=1.5), guess=torch.sigmoid(torch.randn(I, device=dev, generator=g)).requires_grad_(True), resid=1.0)
+    res = []
+    for chunk in (1 << 20, 256):
+        monkeypatch.setattr(D, 'PERSON_CHUNK', chunk)
+        for v in t.values():
+            if torch.is_tensor(v):
+                v.grad = None
+        ll = D.decoder_log_lik(resp, mask, **t)
+        ll.backward()
+        p = D.decoder_probs(B, I, **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in t.items()})
+        res.append((ll.detach().clone(), {k: v.grad.clone() for k, v in t.items() if torch.is_tensor(v)}, p))
+    (l0, g0, p0), (l1, g1, p1) = res
+    assert abs(float(l0) - float(l1)) < 1e-6 * abs(float(l0)) and torch.equal(p0, p1)
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-6 * float(g0[k].abs().max()), k
+    assert torch.equal(g0['V'], g1['V']) and torch.equal(g0['logit'], g1['logit'])       # per-person outputs: bitwise

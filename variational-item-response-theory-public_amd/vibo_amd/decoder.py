@@ -59,30 +59,59 @@ def _prep(t):
     return None if t is None else t.detach().contiguous().float()
 
 
+PERSON_CHUNK = 65536      # persons per launch: bounds the per-wave d V records ([4 ceil(I / 64)][persons][64] floats) to ~1 GB at 1 000 items
+
+
 class _DecoderLogLik(torch.autograd.Function):
-    """sum of the masked Bernoulli log-likelihood; every gradient is produced by the forward launch."""
+    """sum of the masked Bernoulli log-likelihood; every gradient is produced by the forward launch(es) -- the persons go
+    through in chunks of PERSON_CHUNK, the per-chunk partial records are summed here (fixed order)."""
 
     @staticmethod
     def forward(ctx, response, mask, resid, U, V, L, guess, w1, W2, b2, w3, b3):
         want_grad = any(t is not None and t.requires_grad for t in (U, V, L, guess, w1, W2, b2, w3, b3))
-        out = ops._BACKEND['decoder'](response, mask, _prep(U), _prep(V), _prep(L), _prep(guess), _prep(w1), _prep(W2), _prep(b2),
-                                      _prep(w3), _prep(b3), resid, want_grad)
-        ctx.out = out if want_grad else None
+        Up, Vp, Lp, gp, w1p, W2p, b2p, w3p, b3p = (_prep(t) for t in (U, V, L, guess, w1, W2, b2, w3, b3))
+        B = response.shape[0]
+        ll = None
+        acc = {}
+        for s in range(0, B, PERSON_CHUNK):
+            e = min(B, s + PERSON_CHUNK)
+            whole = s == 0 and e == B
+            out = ops._BACKEND['decoder'](response if whole else response[s:e], mask if (mask is None or whole) else mask[s:e], Up,
+                                          Vp if whole else Vp[s:e], Lp if (Lp is None or whole) else Lp[s:e], gp, w1p, W2p, b2p, w3p, b3p,
+                                          resid, want_grad)
+            part = out['ll_part'].sum()
+            ll = part if ll is None else ll + part
+            if want_grad:
+                red = {'dW2': out['dW2'].sum(0), 'dvec': out['dvec'].sum(0)}
+                if 'dU' in out:
+                    red['dU'] = out['dU'].sum(0)
+                if 'dguess' in out:
+                    red['dguess'] = out['dguess'].sum(0)
+                for k, v in red.items():
+                    acc[k] = v if k not in acc else acc[k] + v
+                acc.setdefault('dV', []).append(out['dV'].sum(0))
+                if 'dL' in out:
+                    acc.setdefault('dL', []).append(out['dL'])
+        if want_grad:
+            acc['dV'] = acc['dV'][0] if len(acc['dV']) == 1 else torch.cat(acc['dV'], 0)
+            if 'dL' in acc:
+                acc['dL'] = acc['dL'][0] if len(acc['dL']) == 1 else torch.cat(acc['dL'], 0)
+        ctx.out = acc if want_grad else None
         ctx.has = (U is not None, L is not None, guess is not None, w1 is not None)
-        return out['ll_part'].sum()
+        return ll
 
     @staticmethod
     def backward(ctx, g):
         o = ctx.out
         has_u, has_l, has_g, has_w1 = ctx.has
-        dvec = o['dvec'].sum(0)
+        dvec = o['dvec']
         return (None, None, None,
-                g * o['dU'].sum(0) if has_u else None,
-                g * o['dV'].sum(0),
+                g * o['dU'] if has_u else None,
+                g * o['dV'],
                 g * o['dL'] if has_l else None,
-                g * o['dguess'].sum(0) if has_g else None,
+                g * o['dguess'] if has_g else None,
                 g * dvec[2] if has_w1 else None,
-                g * o['dW2'].sum(0), g * dvec[0], g * dvec[1], g * dvec[3, :1])
+                g * o['dW2'], g * dvec[0], g * dvec[1], g * dvec[3, :1])
 
 
 def _rows(response, mask):
@@ -104,10 +133,15 @@ def decoder_log_lik(response, mask, *, U, V, W2, b2, w3, b3, logit=None, w1=None
 @torch.no_grad()
 def decoder_probs(B, I, *, U, V, W2, b2, w3, b3, logit=None, w1=None, guess=None, resid=0.0):
     """P(response = 1) [B, I] of the per-term network (decode(): models.py:373-378 with a non-IRT generative model)."""
-    dummy = torch.zeros(B, I, device=V.device)
-    out = ops._BACKEND['decoder'](dummy, None, _prep(U), _prep(V), _prep(logit), _prep(guess), _prep(w1), _prep(W2), _prep(b2),
-                                  _prep(w3), _prep(b3), resid, False, want_prob=True)
-    return out['prob']
+    Up, Vp, Lp, gp, w1p, W2p, b2p, w3p, b3p = (_prep(t) for t in (U, V, logit, guess, w1, W2, b2, w3, b3))
+    outs = []
+    for s in range(0, B, PERSON_CHUNK):
+        e = min(B, s + PERSON_CHUNK)
+        dummy = torch.zeros(e - s, I, device=V.device)
+        out = ops._BACKEND['decoder'](dummy, None, Up, Vp[s:e], None if Lp is None else Lp[s:e], gp, w1p, W2p, b2p, w3p, b3p,
+                                      resid, False, want_prob=True)
+        outs.append(out['prob'])
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 def irt_logit(irt_model, ability, item_feat):
