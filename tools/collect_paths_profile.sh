@@ -32,3 +32,16 @@ run --persons 100000 --items 10000 --ability-dim 1 --irt 3 --cond --flows 4 --co
 run --persons 1000000 --items 1000 --ability-dim 8 --given
 rm -rf /tmp/kt
 echo "wrote $S"
+run --persons 1000000 --items 1000 --ability-dim 8 --cond
+run --persons 1000000 --items 1000 --ability-dim 8 --flows 4
+run --persons 1000000 --items 1000 --ability-dim 8 --irt 3
+run --persons 200000 --items 10000 --ability-dim 1 --irt 3 --cond --flows 4
+# the per-term MLP decoder kernel (tools/profile_decoder.py)
+for m in deep link; do
+  rm -rf /tmp/kt
+  echo "# rocprofv3 --kernel-trace --stats -- python tools/profile_decoder.py --mode $m" >> $S
+  rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/tools/profile_decoder.py --mode $m > /tmp/kt.log 2>&1
+  grep "terms/s" /tmp/kt.log >> $S
+  python $R/tools/rocpd_summary.py /tmp/kt/kt_results.db vibo | cut -c1-150 >> $S
+  echo >> $S
+done

@@ -155,7 +155,13 @@ static bool want_msplit(const vibo_desc* d) {
     // small minibatches (the reference CLI's default is 16 persons): the matrix kernel's fixed cost -- operand images, 512-thread
     // workgroups, one batch of 32 rows per workgroup -- loses to the VALU kernel's 8-row batches below ~3 000 rows
     // (tools/batch_sweep.py at ability_dim 8: 42 vs 50 us per step at 16 rows, 46 vs 52 at 1 024, 59 vs 54 at 4 096)
-    return d->num_person > 2048;
+    if (d->num_person <= 2048) return false;
+    // narrow matrices: a workgroup of the matrix kernel is ceil(I / 128) waves on one CU, so with few items the chip holds few
+    // waves; the VALU kernel's 256-item waves and 2 workgroups per CU do better there (50 M cells per call: 96 items
+    // 0.143 vs 0.278 ms at ability_dim 1 -- CritLangAcq's shape -- 256 items 0.072 vs 0.142, 768 items 0.081 vs 0.100; at
+    // ability_dim 8 the contractions tip it earlier: 256 items 0.116 vs 0.151, 384 items 0.139 vs 0.121)
+    const int width = d->num_item < 1024 ? d->num_item : 1024;
+    return d->ability_dim > 4 ? width >= 320 : width >= 896;
 }
 static int msplit_blocks(int num_cu, int items, long long persons) {
     const int nw = (items + 127) / 128;
