@@ -26,7 +26,7 @@ Adds to the contract line:
   elbo_rel_err  |ELBO_hip - ELBO_ref| / |ELBO_ref| on the first 1024 persons of the benchmark matrix, same parameters
                 and noise, in the same run: ref = the CPU restatement of the reference op sequence (fp32, the
                 reference's arithmetic); also against its fp64 evaluation.
-  extra         decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate); train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md §8d;
+  extra         config5_path: BASELINE configs[4]'s path (3PL, 10 000 items, conditional, 4 flows) on 100 000 persons; decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate); train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md §8d;
                 rows gathered in the kernel, hipGraph replay); the headline is the full shard.
   cpu_baseline  the CPU port of the reference op sequence (per-term MLP -> PoE -> link -> masked log-lik -> autograd ->
                 Adam, oracle/vibo_oracle.py) timed on this host's cores (rank 0, N = 1 only): B = 16 and B = 1024, 3
@@ -486,6 +486,38 @@ def main():
                 'bound': 'mfma + valu', 'peak_fp32_TFLOPs': 157.3, 'frac_of_fp32_peak': flop / (ms * 1e-3) / 1e12 / 157.3,
                 'mfma_issued_TFLOPs': 3 * flop / (ms * 1e-3) / 1e12, 'mfma_util_profile': 'profiles/r02_decoder_pmc.txt (17 %)'}
 
+    def config5_probe():
+        """BASELINE configs[4]'s path on a slice of its shape (3PL, 10 000 items, conditional posterior, 4 planar flows, fp32 rows):
+        one forward + backward call of 100 000 persons; three passes (cond_pre, matrix kernel per 1024-item panel, cond_post)."""
+        from vibo_amd import _lib
+        from vibo_amd.ops import ElboSpec
+        Pc, Ic = 100_000, 10_000
+        g = torch.Generator(device=dev).manual_seed(args.seed + 5)
+        r = (torch.rand(Pc, Ic, device=dev, generator=g) < 0.5).float()
+        mk = torch.rand(Pc, Ic, device=dev, generator=g) >= args.missing
+        spec = ElboSpec(irt_model=3, ability_dim=1, conditional=True, n_flows=4)
+        table = torch.randn(2, Ic, 2, device=dev, generator=g) * 0.5
+        item = torch.randn(Ic, 3, device=dev, generator=g)
+        eps = torch.randn(Pc, 1, device=dev, generator=g)
+        flow = torch.randn(4, 3, device=dev, generator=g) * 0.5
+        m8, code = ops.prepare_mask(mk)
+        call = lambda: ops._hip_launch_elbo(spec, r, m8, code, None, table, item, eps, flow, _lib.REG_SAMPLED, True, Pc)
+        for _ in range(2):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        bpt = 5.0 + 12.0 / Ic
+        return {'workload': f'3PL, {Pc} persons x {Ic} items, ability_dim 1, conditional posterior, 4 planar flows, fp32 rows: one forward + backward call',
+                'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3), 'bytes_per_term': bpt,
+                'roofline_frac': bpt * Pc * Ic / (ms * 1e-3) / 8e12,
+                'hbm_bytes_per_term_by_construction': 8.0,
+                'note': 'cond_pre reads 5 B and writes 1 B of cell codes per term, the matrix kernel and cond_post read 1 B each'}
+
     P, I, A = persons_rank, args.items, args.ability_dim
     m = measure(A, extra=not args.no_extra)
     dt, kern_ms, final_loss = m['dt'], m['kern_ms'], m['final_loss']
@@ -547,7 +579,7 @@ def main():
             line['elbo_rel_err'] = m['rel']['vs_reference_op_sequence_fp32']
             line['elbo_rel_err_detail'] = m['rel']
         if m.get('sweep'):
-            line['extra'] = {'decoder_kernel': decoder_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
+            line['extra'] = {'decoder_kernel': decoder_probe(), 'config5_path': config5_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
         if also is not None:
             line['also'] = also
         if format_p is not None:
