@@ -306,6 +306,20 @@ int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* re
  * want_grad = 0: only ll_part and, when prob_out != NULL, prob_out [B][I] = P(response = 1) (decode()).
  * person_chunks: vibo_decoder_person_chunks(B, I), or any value in 1..B.
  */
+/*
+ * A stack of planar flows on the rows of z [n_rows][dim] (PlanarFlow.forward / NormalizingFlows.forward, flows.py:21-41,
+ * 58-66; the item-side stack of models.py:342-348 and the ability-side stack of the MLP-decoder models):
+ *     z <- z + uhat_k tanh(w_k . z + b_k),   ladj[row] = sum_k log(|1 + (1 - tanh^2)(w_k . uhat_k)| + 1e-8)
+ * packed [n_flows][2 dim + 1] = uhat | w | b per flow (uhat from (u, w) by the caller, flows.py:24-26); dim <= 10,
+ * n_flows <= VIBO_MAX_FLOWS.  forward: z_out [n_rows][dim], ladj [n_rows], tanh_out [n_rows][n_flows] (kept for backward).
+ * backward: given d/d z_out and d/d ladj, writes d/d z [n_rows][dim] and ceil(n_rows / 256) partial records
+ * [n_flows][2 dim + 1] = d/d uhat | d/d w | d/d b that the caller sums (fixed order).
+ */
+int vibo_flow_stack_forward(int n_rows, int dim, int n_flows, const float* z, const float* packed, float* z_out, float* ladj,
+                            float* tanh_out, void* stream);
+int vibo_flow_stack_backward(int n_rows, int dim, int n_flows, const float* z_out, const float* packed, const float* tanh_saved,
+                             const float* g_zout, const float* g_ladj, float* g_z, float* partials, void* stream);
+
 typedef struct vibo_decoder_desc {
     int32_t num_person, num_item, hidden_dim, want_grad, person_chunks;
     float resid;

@@ -151,7 +151,18 @@ def install(ops):
                 out['dguess'] = z('guess', guess).unsqueeze(0)
         return out
 
-    ops._BACKEND.update(decoder=decoder, elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts, mean_fwd=mean_fwd,
+    def flow_stack(z, packed):
+        """vibo_flow_stack_forward/backward as plain autograd ops (flows.py:21-41, 58-66)."""
+        D = z.shape[1]
+        total = 0.0
+        for k in range(packed.shape[0]):
+            uhat, w, b = packed[k, :D], packed[k, D:2 * D], packed[k, 2 * D]
+            t = torch.tanh(z @ w + b)
+            z = z + uhat.unsqueeze(0) * t.unsqueeze(1)
+            total = total + torch.log(torch.abs(1.0 + (1.0 - t * t) * torch.dot(w, uhat)) + 1e-8)
+        return z, total
+
+    ops._BACKEND.update(decoder=decoder, flow_stack=flow_stack, elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts, mean_fwd=mean_fwd,
                         mean_bwd=mean_bwd)
 
     def restore():

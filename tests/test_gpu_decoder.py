@@ -96,3 +96,34 @@ def test_person_chunking_changes_nothing_but_the_summation_order(monkeypatch):
     for k in g0:
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-6 * float(g0[k].abs().max()), k
     assert torch.equal(g0['V'], g1['V']) and torch.equal(g0['logit'], g1['logit'])       # per-person outputs: bitwise
+
+
+@pytest.mark.parametrize('N,Dm,K', [(1000, 3, 4), (37, 10, 8), (10000, 2, 1), (257, 1, 2)])
+def test_flow_stack_kernels_match_autograd(N, Dm, K):
+    """vibo_flow_stack_forward / _backward (the item-side planar-flow stack, flows.py:21-66) vs float64 autograd."""
+    from vibo_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(N + Dm + K)
+    z = torch.randn(N, Dm, generator=g).double().requires_grad_(True)
+    u, w = torch.randn(K, Dm, generator=g).double(), torch.randn(K, Dm, generator=g).double()
+    uw = (u * w).sum(1, keepdim=True)          # uhat as the flow builds it (flows.py:24-26): w . uhat >= -1, so psi stays away from 0
+    uhat = u + (torch.nn.functional.softplus(uw) - 1.0 - uw) * w / (w * w).sum(1, keepdim=True)
+    packed = torch.cat([uhat, w, torch.randn(K, 1, generator=g).double()], 1).requires_grad_(True)
+    zz, total = z, 0.0
+    for k in range(K):
+        uhat, w, b = packed[k, :Dm], packed[k, Dm:2 * Dm], packed[k, 2 * Dm]
+        t = torch.tanh(zz @ w + b)
+        zz = zz + uhat.unsqueeze(0) * t.unsqueeze(1)
+        total = total + torch.log(torch.abs(1.0 + (1.0 - t * t) * torch.dot(w, uhat)) + 1e-8)
+    cz, cl = torch.randn(N, Dm, generator=g).double(), torch.randn(N, generator=g).double()
+    ((zz * cz).sum() + (total * cl).sum()).backward()
+    z32 = z.detach().float().to(dev).requires_grad_(True)
+    p32 = packed.detach().float().to(dev).requires_grad_(True)
+    zo, la = ops.FlowStackFn.apply(z32, p32)
+    ((zo * cz.float().to(dev)).sum() + (la * cl.float().to(dev)).sum()).backward()
+    assert (zo.detach().double().cpu() - zz.detach()).abs().max() < 2e-6 * max(1.0, float(zz.abs().max()))
+    assert (la.detach().double().cpu() - total.detach()).abs().max() < 2e-5
+    assert rel(z32.grad.double().cpu(), z.grad) < 1e-4
+    assert rel(p32.grad.double().cpu(), packed.grad) < 1e-4
+    zo2, la2 = ops.FlowStackFn.apply(z32, p32)
+    assert torch.equal(zo, zo2) and torch.equal(la, la2)

@@ -61,7 +61,7 @@ EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_by
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
                     'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise',
-                    'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd')
+                    'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd', 'vibo_flow_stack_forward', 'vibo_flow_stack_backward')
 
 _lib = None
 
@@ -126,6 +126,10 @@ def load():
     lib.vibo_decoder_person_chunks.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.vibo_decoder_fwd_bwd.restype = ctypes.c_int
     lib.vibo_decoder_fwd_bwd.argtypes = [ctypes.POINTER(ViboDecoderDesc)] + [vp] * 19 + [vp]
+    lib.vibo_flow_stack_forward.restype = ctypes.c_int
+    lib.vibo_flow_stack_forward.argtypes = [ctypes.c_int] * 3 + [vp] * 5 + [vp]
+    lib.vibo_flow_stack_backward.restype = ctypes.c_int
+    lib.vibo_flow_stack_backward.argtypes = [ctypes.c_int] * 3 + [vp] * 7 + [vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

@@ -423,6 +423,44 @@ class MeanEncoderFn(torch.autograd.Function):
         return gu, gv, gw2, gb2, None
 
 
+class FlowStackFn(torch.autograd.Function):
+    """(z [N, D], packed [K, 2D+1] = uhat | w | b) -> (z_K [N, D], ladj [N]): a stack of planar flows in two launches
+    (vibo_flow_stack_forward / _backward) instead of ~35 small PyTorch kernels per flow and direction."""
+
+    @staticmethod
+    def forward(ctx, z, packed):
+        lib = _lib.load()
+        z, packed = z.detach().contiguous().float(), packed.detach().contiguous().float()
+        _require_device(z, packed)
+        N, D = z.shape
+        K = packed.shape[0]
+        z_out, ladj, th = torch.empty_like(z), torch.empty(N, dtype=torch.float32, device=z.device), torch.empty(N, K, dtype=torch.float32, device=z.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        _lib.check(lib.vibo_flow_stack_forward(N, D, K, _ptr(z), _ptr(packed), _ptr(z_out), _ptr(ladj), _ptr(th), stream),
+                   'vibo_flow_stack_forward')
+        ctx.save_for_backward(z_out, packed, th)
+        return z_out, ladj
+
+    @staticmethod
+    def backward(ctx, g_z, g_l):
+        lib = _lib.load()
+        z_out, packed, th = ctx.saved_tensors
+        N, D = z_out.shape
+        K = packed.shape[0]
+        g_z = torch.zeros_like(z_out) if g_z is None else g_z.contiguous().float()
+        g_l = torch.zeros(N, dtype=torch.float32, device=z_out.device) if g_l is None else g_l.contiguous().float()
+        g_in = torch.empty_like(z_out)
+        parts = torch.empty((N + 255) // 256, K, 2 * D + 1, dtype=torch.float32, device=z_out.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(z_out.device).cuda_stream)
+        _lib.check(lib.vibo_flow_stack_backward(N, D, K, _ptr(z_out), _ptr(packed), _ptr(th), _ptr(g_z), _ptr(g_l), _ptr(g_in),
+                                                _ptr(parts), stream), 'vibo_flow_stack_backward')
+        return g_in, parts.sum(0)
+
+
+def _hip_flow_stack(z, packed):
+    return FlowStackFn.apply(z, packed)
+
+
 def _hip_decode_mean(spec, abilities, items):
     """vibo_decode_mean: abilities [S,B,A], items [S,I,D] -> mean over S of P(response = 1) [B,I]."""
     lib = _lib.load()
@@ -440,7 +478,7 @@ def _hip_decode_mean(spec, abilities, items):
 # oracle to exercise the host logic without a GPU (never done by product code).
 _BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward,
             'decode_mean': _hip_decode_mean, 'counts': _hip_row_counts, 'mean_fwd': _hip_mean_encoder_fwd,
-            'mean_bwd': _hip_mean_encoder_bwd}
+            'mean_bwd': _hip_mean_encoder_bwd, 'flow_stack': _hip_flow_stack}
 
 
 class FusedELBO(torch.autograd.Function):

@@ -221,15 +221,17 @@ class FlowStack(nn.Module):
         self.flows = nn.ModuleList([PlanarFlowParams(dim) for _ in range(n_flows)])
 
     def forward(self, z):
-        total = None
-        for f in self.flows:
-            z, ladj = f(z)
-            total = ladj if total is None else total + ladj
-        return z, total
+        """(z_K, sum of log|det J|) of the rows of z: one native forward launch (and one backward launch) for the whole stack."""
+        return ops._BACKEND['flow_stack'](z, self.packed())
 
     def packed(self):
-        """[n_flows, 2*dim+1] = (uhat | w | b) rows for the kernel."""
-        return torch.stack([torch.cat([f.uhat(), f.w, f.b]) for f in self.flows])
+        """[n_flows, 2*dim+1] = (uhat | w | b) rows for the kernels; uhat (flows.py:24-26) for all flows at once."""
+        U = torch.stack([f.u for f in self.flows])
+        W = torch.stack([f.w for f in self.flows])
+        b = torch.cat([f.b for f in self.flows]).unsqueeze(1)
+        uw = (U * W).sum(1, keepdim=True)
+        uhat = U + (F.softplus(uw) - 1.0 - uw) * W / (W * W).sum(1, keepdim=True)
+        return torch.cat([uhat, W, b], dim=1)
 
 
 # ---------------------------------------------------------------------------
