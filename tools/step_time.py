@@ -41,7 +41,7 @@ cls = {1: M.VIBO_1PL, 2: M.VIBO_2PL, 3: M.VIBO_3PL}[a.irt]
 for mode in ('eager', 'graph'):
     torch.manual_seed(0)
     model = cls(A, I, ability_merge=a.merge, conditional_posterior=a.cond, n_norm_flows=a.flows).to(d)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=mode == 'graph')
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=mode == 'graph', fused=True)      # (as the CLI builds it)
     step = GraphedModuleStep(model, opt, data, B)
     if mode == 'eager':
         step.WARMUP = 1 << 30
