@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, DEC_MIN_WG) void decoder_kernel(const DecParam
             const float sg = o >= 0.f ? big : small, sq = o >= 0.f ? small : big;       // sigmoid(o), 1 - sigmoid(o)
             const float pr_ = has_guess ? guess + (1.0f - guess) * sg : sg;
             const float qr_ = has_guess ? (1.0f - guess) * sq : sq;
-            const bool inside = pr_ > kEps32 && pr_ < 1.0f - kEps32;
+            const bool inside = pr_ >= kEps32 && pr_ <= 1.0f - kEps32;      // (torch's clamp passes the gradient at the bounds themselves)
             const float pc = inside ? pr_ : fminf(fmaxf(pr_, kEps32), 1.0f - kEps32);
             const float qc = inside ? qr_ : 1.0f - pc;
             float ll = 0.f, dldp = 0.f;
