@@ -127,3 +127,30 @@ def test_flow_stack_kernels_match_autograd(N, Dm, K):
     assert rel(p32.grad.double().cpu(), packed.grad) < 1e-4
     zo2, la2 = ops.FlowStackFn.apply(z32, p32)
     assert torch.equal(zo, zo2) and torch.equal(la, la2)
+
+
+def test_decoder_kernel_on_the_references_saturation_probe():
+    """The Bernoulli probability clamp of the reference (utils.py:46-49 -> torch: value capped, gradient exactly zero outside the
+    clamp and passed AT its bounds) through the decoder kernel: residual mode with a zero network makes the output equal the
+    supplied logit, and tests/golden/saturation.npz holds the REAL reference's ll and d ll / d logit on a grid over [-30, 30]."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'saturation.npz'))
+    dev = torch.device('cuda:0')
+    logit = torch.from_numpy(z['logit'])[::3].to(dev)
+    I, H = logit.numel(), 64
+    zeros = lambda *s: torch.zeros(*s, device=dev)
+    for x in (0, 1):
+        L = logit.unsqueeze(0).clone().requires_grad_(True)
+        ll = D.decoder_log_lik(torch.full((1, I), float(x), device=dev), None, U=zeros(I, H), V=zeros(1, H).requires_grad_(True),
+                               W2=zeros(H, H), b2=zeros(H), w3=zeros(H), b3=zeros(1), logit=L, resid=1.0)
+        ll.backward()
+        ref_ll = torch.from_numpy(z[f'll_x{x}'])[::3].double()
+        ref_g = torch.from_numpy(z[f'dll_dlogit_x{x}'])[::3]
+        g = L.grad[0].cpu()
+        assert torch.equal(g == 0, ref_g == 0)                      # the same cells are clamped
+        assert (g - ref_g).abs().max() < 2e-6
+        # (the reference's own fp32 value is quantised through 1 - P for logits of 12..16 -- up to 5e-4 per cell; the kernel forms
+        #  1 - P without that cancellation, so the sums agree to 1e-4, not to rounding)
+        assert abs(float(ll.detach()) - float(ref_ll.sum())) < 1e-4 * abs(float(ref_ll.sum()))

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256, DEC_MIN_WG) void decoder_kernel(const DecParam
             float ll = 0.f, dldp = 0.f;
             if (obs) {
                 const bool one = x > 0.5f;
-                ll = logf(one ? pc : qc);
+                // (value floor: the reference's fp32 1 - P is quantised at eps32, so its log-likelihood of a confidently wrong cell
+                //  stops at log eps32 = -15.94 while its gradient lives on until P rounds to 1: tests/golden/saturation.npz)
+                ll = logf(fmaxf(one ? pc : qc, kEps32));
                 if (inside) dldp = one ? 1.0f / pc : -1.0f / qc;
             }
             if (g == 0) llsum += ll;
