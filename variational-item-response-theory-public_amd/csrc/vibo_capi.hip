@@ -934,7 +934,12 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
                 for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4) {     // 4 ability dims per launch
                     cp.codes_out = (emit && cp.a0 == 0) ? code_rows : nullptr;
-                    e = launch_cond_pre(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);   // own template width (3PL widens the split kernel's)
+                    CondParams cq = cp;
+                    if (emit && cp.a0 > 0) {      // dims 4..7: the rows' cell codes are there already (written by the first launch)
+                        cq.response = nullptr; cq.mask = code_rows; cq.row_index = nullptr;
+                        cq.mask_stride = pl.codes_stride; cq.mask_dtype = VIBO_MASK_CODES;
+                    }
+                    e = launch_cond_pre(cq, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);   // own template width (3PL widens the split kernel's)
                 }
             }
             cp.codes_out = nullptr;
