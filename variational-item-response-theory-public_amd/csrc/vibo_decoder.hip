@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, DEC_MIN_WG) void decoder_kernel(const DecParam
         }
         {
             const float t = wave_total(db3);
-            if (lane == 0) dv[3 * kH] = t;
+            dv[3 * kH + lane] = lane == 0 ? t : 0.f;          // (the rest of the row is zero: outputs are fully overwritten)
         }
         if (item_ok) {
             if (p.dU_part) {
