@@ -397,9 +397,9 @@ def main():
         achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         ops._BACKEND['elbo'] = native
         rel, sweep = None, None
-        if extra and not codes and rank == 0:
+        if extra and not codes and rank == 0 and dist is None:      # (one rank only: these steps would issue collectives of their own)
             rel = elbo_rel_err(model, resp, mask, A)
-            if trainer is not None and dist is None:
+            if trainer is not None:
                 sweep = batch_sweep(model, resp, mask, A)
         del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()

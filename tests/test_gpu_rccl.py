@@ -102,7 +102,7 @@ def test_bench_two_ranks_share_one_device_over_gloo(scaling):
     env = dict(os.environ, VIBO_BENCH_ONE_DEVICE='1', PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, 'variational-item-response-theory-public_amd')]))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29571', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--scaling', scaling,
-           '--persons', '100000', '--no-cpu-baseline', '--no-extra', '--no-format-p', '--also-ability-dim', '0']
+           '--persons', '100000']          # (otherwise the flags the driver passes: extras, `also` and Format P legs must not deadlock)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
@@ -110,5 +110,6 @@ def test_bench_two_ranks_share_one_device_over_gloo(scaling):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == scaling
     assert d['config']['global_batch'] == (200000 if scaling == 'weak' else 100000)
-    assert d['value'] > 0 and d['ms_per_step'] > 0 and 'roofline' in d and 'cpu_baseline' not in d
+    assert d['value'] > 0 and d['ms_per_step'] > 0 and 'roofline' in d and 'cpu_baseline' not in d and 'extra' not in d
+    assert 'also' in d and 'format_p' in d
     assert abs(d['value'] - d['config']['global_batch'] * 1000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
