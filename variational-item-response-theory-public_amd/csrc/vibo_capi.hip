@@ -418,6 +418,16 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
 // conditional pipeline: precision lam = exp(-logvar), s = mu lam, nobs = I (no prior experts are added); the kernel's
 // per-person coefficients P1 = g_mu / lam, P2 = -(g_mu mu + g_lv) / lam come back as d / d (mu, logvar)
 // ---------------------------------------------------------------------------
+// conditional posterior, more than one 1024-item panel: the panels' row statistics summed once (fixed order) into panel 0's
+// block, so the matrix kernel's per-person forward reads 3 values instead of 3 per panel inside its barrier phase
+__global__ __launch_bounds__(256) void panel_sum_kernel(float* __restrict__ pre, long long n, int panels) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float t = pre[e];
+    for (int pn = 1; pn < panels; ++pn) t += pre[(size_t)pn * n + e];
+    pre[e] = t;
+}
+
 __global__ __launch_bounds__(256) void given_pre_kernel(const float* __restrict__ post, float* __restrict__ pre, long long B, int A,
                                                         int I) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -945,6 +955,12 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             cp.codes_out = nullptr;
             p.pre_stats = pre;
             p.pre_panels = pl.panels;
+            if (pl.panels > 1 && e == hipSuccess) {
+                const long long n = (long long)d->num_person * (2 * A + 1);
+                hipLaunchKernelGGL(panel_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, n, pl.panels);
+                e = hipGetLastError();
+                p.pre_panels = 1;
+            }
         } else {
             int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
             int cgrid = num_cu * 8;
@@ -972,6 +988,12 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s, pl.msplit);
         }
         if (pl.cond && grad) {
+            if (pl.panels > 1 && e == hipSuccess) {       // the panels' backward coefficients summed once (cond_post reads 1 block, not `panels`)
+                const long long n = (long long)d->num_person * 4 * A;
+                hipLaunchKernelGGL(panel_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coef, n, pl.panels);
+                e = hipGetLastError();
+                cp.coef_panels = 1;
+            }
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
                 cp.item0 = pn * 1024;
                 cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
