@@ -381,6 +381,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // EXT: the variant that reads global memory in the sync phase (whole-row counts of the panel mode, the conditional /
     // given posterior's statistics).  The plain variant issues no load at all: a load destination shared with it would make
     // hipcc guard the register with an s_waitcnt vmcnt(0) -- behind the row loads that are in flight across the sync phase.
+    // (on cell codes, RM == 2, the single-panel statistics of the conditional / given posterior come a batch ahead with
+    //  eps -- prs -- and the plain variant serves them: the conditional posterior's matrix pass runs on emitted codes)
+#ifdef VIBO_MS_NO_PRS
+    constexpr bool kPrs = false;
+#else
+    constexpr bool kPrs = RM == 2;
+#endif
+    float prs0 = 0.f, prs1 = 0.f, prs2 = 0.f;
     auto forward_slot = [&](auto extc, const long long bt, const int par, const int s, const float eps_c) {
         constexpr bool EXT = decltype(extc)::value;
         const long long row0 = bt * R;
@@ -408,7 +416,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const float n0 = nobs - n1;
         const float tau0 = cl.ctab[(0 * 2 + 0) * 8 + ed], tau1 = cl.ctab[(0 * 2 + 1) * 8 + ed];
         const float mt0 = cl.ctab[(1 * 2 + 0) * 8 + ed], mt1 = cl.ctab[(1 * 2 + 1) * 8 + ed];
-        float lam = n0 * tau0 + n1 * tau1, smu = n0 * mt0 + n1 * mt1;
+        // (written as one fma each: the contraction hipcc picks for a sum of two products depends on the surrounding code,
+        //  and the variants of this kernel have to agree bit for bit)
+        float lam = fmaf(n0, tau0, n1 * tau1), smu = fmaf(n0, mt0, n1 * mt1);
         if constexpr (EXT) {
             if (p.pre_stats) {
                 lam = 0.f; smu = 0.f; nobs = 0.f;
@@ -419,6 +429,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     }
                 }
             }
+        }
+        if constexpr (!EXT && kPrs) {
+            if (p.pre_stats) { lam = prs0; smu = prs1; nobs = prs2; }
         }
         const float nmiss = (float)p.I_total - nobs;
         if (p.missing_mode == 0) lam += nmiss * (1.0f / (1.0f + kPoeEps));
@@ -597,12 +610,19 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if (s0 < s1) {
             const long long row = bt * R + ((64 * s0 + lane) >> 3);
             epn = (ed < A && row < p.B) ? p.eps[row * A + ed] : 0.f;
+            if constexpr (kPrs) {
+                if (p.pre_stats && p.pre_panels == 1) {
+                    const bool lv = ed < A && row < p.B;
+                    const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
+                    prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
+                }
+            }
         }
     };
     auto person_forward = [&](const long long bt, const int par) {
         int s0, s1, step;
         my_slots(par, s0, s1, step);
-        if (nw < 4 || p.row_cnt || p.pre_stats) {          // (wave-uniform)
+        if (nw < 4 || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1))) {          // (wave-uniform)
 #pragma unroll 1
             for (int s = s0; s < s1; s += step) {
                 float eps_c = epn;
@@ -824,6 +844,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         put_counts(pk, true);
         fetch_eps(bt, 0);
         asm volatile("" : "+v"(epn));                 // (in before the loop: no wait on it behind the loop's own loads)
+        if constexpr (kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
     }
     int par = 0;                                      // parity of the workgroup's batch counter: LDS double buffers, slot owners
 #ifdef VIBO_MS_TIMING
@@ -893,6 +914,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) pack_quarter(nxt, 1, j, cwB0, cwB1, pk);
         asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
+        if constexpr (kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
         MS_T(3)
         put_counts(pk, nxt < n_batches);
         if constexpr (GRAD) put_gtheta(par);
