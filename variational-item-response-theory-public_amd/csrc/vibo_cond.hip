@@ -79,11 +79,46 @@ __device__ __forceinline__ void load_rows(const CondParams& p, const long long b
         }
     }
 }
-// fp8 codes of row r of the batch (either row format)
+// The word a pass keeps per row and lane: the 4 cell codes as they are (CODES) or the 4 fp8 codes of an fp32 row.
 template <bool CODES>
-__device__ __forceinline__ uint32_t row_codes(const RowBatch<CODES>& rb, const int r, const uint32_t tail_mask, int& pk) {
-    if constexpr (CODES) return pack_cell_codes4(rb.m[r], tail_mask, pk);
-    else return pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
+__device__ __forceinline__ uint32_t row_word(const RowBatch<CODES>& rb, const int r, const uint32_t tail_mask, int& nobs) {
+    if constexpr (CODES) {
+        return rb.m[r];
+    } else {
+        int pk = 0;
+        const uint32_t cw = pack_codes4(rb.x[r], rb.m[r] & tail_mask, pk);
+        nobs = pk & 0xffff;
+        return cw;
+    }
+}
+// [correct] / [wrong] indicators (exactly 0.0 / 1.0) of the word's 4 cells.  On cell codes they come straight from the code
+// bits (observed = !bit 1, correct = bit 0: one v_cvt_f32_ubyte per value); from fp8 codes (+1 / -1 / 0) through a clamp --
+// v_med3, which unlike fmaxf() needs no canonicalising v_max in front of it (that doubled the instruction count here).
+template <bool CODES>
+__device__ __forceinline__ void word_indicators(const uint32_t wd, const uint32_t tail_mask, float (&wp)[4], float (&wn)[4], int& nobs) {
+    if constexpr (CODES) {
+        const uint32_t ob = ~(wd >> 1) & (tail_mask & 0x01010101u);
+        const uint32_t p1 = wd & ob, p0 = ob ^ p1;
+        // (spelled out: hipcc shifts the word first and converts byte 0 otherwise)
+        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(wp[0]) : "v"(p1));
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(wp[1]) : "v"(p1));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(wp[2]) : "v"(p1));
+        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(wp[3]) : "v"(p1));
+        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(wn[0]) : "v"(p0));
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(wn[1]) : "v"(p0));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(wn[2]) : "v"(p0));
+        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(wn[3]) : "v"(p0));
+        nobs = __builtin_popcount(ob);
+    } else {
+        const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wd, false);
+        const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)wd, true);
+        const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wp[j] = __builtin_amdgcn_fmed3f(w[j], 0.f, 1.f);
+            wn[j] = __builtin_amdgcn_fmed3f(-w[j], 0.f, 1.f);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -128,28 +163,26 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
         float v[NV][kCR];
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
-            int pk = 0;
-            const uint32_t cw = row_codes(rb, r, tail_mask, pk);
+            int nobs = 0;
+            const uint32_t cw = row_word(rb, r, tail_mask, nobs);
             if constexpr (!CODES) {          // leave the row behind as cell codes for the passes that follow (1 B/cell instead of 5)
                 if (p.codes_out && chunk_ok && row0 + r < p.B)
                     reinterpret_cast<uint32_t*>(p.codes_out + (row0 + r) * p.codes_stride + p.item0)[chunk] =
                         cell_codes4(rb.x[r], rb.m[r] & tail_mask);
             }
-            const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, false);
-            const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw, true);
-            const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
+            float wp[4], wn[4];                                              // [correct], [wrong]
+            word_indicators<CODES>(cw, tail_mask, wp, wn, nobs);
 #pragma unroll
             for (int a = 0; a < AT; ++a) { v[a][r] = 0.f; v[AT + a][r] = 0.f; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float wp = fmaxf(w[j], 0.f), wn = fmaxf(-w[j], 0.f);      // [correct], [wrong]
 #pragma unroll
                 for (int a = 0; a < AT; ++a) {
-                    v[a][r] = fmaf(wp, tau[j][1][a], fmaf(wn, tau[j][0][a], v[a][r]));
-                    v[AT + a][r] = fmaf(wp, mt[j][1][a], fmaf(wn, mt[j][0][a], v[AT + a][r]));
+                    v[a][r] = fmaf(wp[j], tau[j][1][a], fmaf(wn[j], tau[j][0][a], v[a][r]));
+                    v[AT + a][r] = fmaf(wp[j], mt[j][1][a], fmaf(wn[j], mt[j][0][a], v[AT + a][r]));
                 }
             }
-            v[2 * AT][r] = (float)(pk & 0xffff);
+            v[2 * AT][r] = (float)nobs;
         }
         if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
 #pragma unroll
@@ -201,8 +234,8 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
         uint32_t cw[kCR];
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
-            int pk = 0;
-            cw[r] = row_codes(rb, r, tail_mask, pk);
+            int nobs = 0;
+            cw[r] = row_word(rb, r, tail_mask, nobs);
         }
         if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
         // this batch's coefficients (sum over the panels' shares), wave-private copy
@@ -216,9 +249,9 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
         }
 #pragma unroll
         for (int r = 0; r < kCR; ++r) {
-            const float2v w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw[r], false);
-            const float2v w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)cw[r], true);
-            const float w[4] = {w01[0], w01[1], w23[0], w23[1]};
+            float wp[4], wn[4];
+            int nobs = 0;
+            word_indicators<CODES>(cw[r], tail_mask, wp, wn, nobs);
             float C[NC];
 #pragma unroll
             for (int k = 0; k < NC; k += 4) {
@@ -227,11 +260,10 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float wp = fmaxf(w[j], 0.f), wn = fmaxf(-w[j], 0.f);
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
-                    S[j][1][k] = fmaf(wp, C[k], S[j][1][k]);
-                    S[j][0][k] = fmaf(wn, C[k], S[j][0][k]);
+                    S[j][1][k] = fmaf(wp[j], C[k], S[j][1][k]);
+                    S[j][0][k] = fmaf(wn[j], C[k], S[j][0][k]);
                 }
             }
         }
