@@ -21,11 +21,14 @@ Adds to the contract line:
                 the same step right after the timed region when the step is graph-replayed); peak 8000 GB/s
                 (MI355X_MICROARCH.md), also as a fraction of the 6290 GB/s measured copy ceiling; traffic = the
                 2*FETCH_SIZE + WRITE_SIZE of the kernel PARSED from the committed rocprofv3 summary of this command
-                (profiles/r02_bench_profile.txt, written by tools/collect_profile.sh; null when the file or the kernel's
+                (profiles/r03_bench_profile.txt, written by tools/collect_profile.sh; null when the file or the kernel's
                 line is missing -- nothing is hard-coded here).
-  elbo_rel_err  |ELBO_hip - ELBO_ref| / |ELBO_ref| on the first 1024 persons of the benchmark matrix, same parameters
+  elbo_rel_err  |ELBO_hip - ELBO_ref| / |ELBO_ref| on the first 4 096 persons of the benchmark matrix, same parameters
                 and noise, in the same run: ref = the CPU restatement of the reference op sequence (fp32, the
-                reference's arithmetic); also against its fp64 evaluation.
+                reference's arithmetic); also against its fp64 evaluation.  4 096 persons is above the planner's
+                2 048-person threshold: the call runs on the kernel the timed step runs on, and the line says so
+                (elbo_rel_err_detail.kernel = vibo_plan_kernel's answer).  `also` and `format_p` carry their own.
+  roofline.frac_step  the same algorithmic bytes over the whole timed step (ms_per_step), next to the kernel-only frac.
   extra         config5_path: BASELINE configs[4]'s path (3PL, 10 000 items, conditional, 4 flows) on 100 000 persons; decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate); train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md §8d;
                 rows gathered in the kernel, hipGraph replay); the headline is the full shard.
   cpu_baseline  the CPU port of the reference op sequence (per-term MLP -> PoE -> link -> masked log-lik -> autograd ->
@@ -178,10 +181,13 @@ def cpu_baseline(args, irt):
     }
 
 
+PROFILE_FILE = 'r03_bench_profile.txt'      # rocprofv3 summary of this command on this round's build (tools/collect_profile.sh)
+
+
 def parse_traffic(kernel_tag):
     """2 * FETCH_SIZE + WRITE_SIZE (KiB counters -> bytes, gfx950 correction of MI355X_MICROARCH.md) of the kernel whose
     mangled name contains `kernel_tag`, from the committed rocprofv3 summary of this command; None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'r02_bench_profile.txt')
+    path = os.path.join(ROOT, 'profiles', PROFILE_FILE)
     vals = {}
     try:
         for ln in open(path):
@@ -189,11 +195,11 @@ def parse_traffic(kernel_tag):
             if len(t) >= 3 and kernel_tag in t[0] and t[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
                 vals.setdefault(t[1], float(t[2]))
     except OSError:
-        return None, 'profiles/r02_bench_profile.txt not found'
+        return None, 'profiles/r03_bench_profile.txt not found'
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
-        return None, f'no FETCH_SIZE / WRITE_SIZE line for {kernel_tag} in profiles/r02_bench_profile.txt'
+        return None, f'no FETCH_SIZE / WRITE_SIZE line for {kernel_tag} in profiles/r03_bench_profile.txt'
     return (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, \
-        f'parsed from profiles/r02_bench_profile.txt: 2*FETCH_SIZE + WRITE_SIZE of {kernel_tag} (KiB counters, separate --pmc passes)'
+        f'parsed from profiles/r03_bench_profile.txt: 2*FETCH_SIZE + WRITE_SIZE of {kernel_tag} (KiB counters, separate --pmc passes)'
 
 
 def main():
@@ -397,26 +403,38 @@ def main():
         achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         ops._BACKEND['elbo'] = native
         rel, sweep = None, None
-        if extra and not codes and rank == 0 and dist is None:      # (one rank only: these steps would issue collectives of their own)
+        if not args.no_extra and rank == 0 and dist is None:        # (one rank only: these steps would issue collectives of their own)
             rel = elbo_rel_err(model, resp, mask, A)
-            if trainer is not None:
+            if extra and not codes and trainer is not None:
                 sweep = batch_sweep(model, resp, mask, A)
         del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()
         return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None, rel=rel, sweep=sweep,
                     launch=launch_mode if graph is not None else 'eager')
 
-    def elbo_rel_err(model, resp, mask, A, n=1024):
-        """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64)."""
+    def elbo_rel_err(model, resp, mask, A, n=4096):
+        """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64).
+        4 096 persons: above the planner's 2 048-person threshold, i.e. on the SAME kernel the timed step runs
+        (`kernel` = vibo_plan_kernel's answer for this call, checked against the timed call's)."""
         from oracle import vibo_oracle as O
+        from vibo_amd import _lib
         I = args.items
         n = min(n, resp.shape[0])
         g = torch.Generator(device=dev).manual_seed(args.seed + 7)
         eps_i = torch.randn(I, O.item_feat_dim(irt, A), device=dev, generator=g)
         eps_a = torch.randn(n, A, device=dev, generator=g)
-        r, m = resp[:n].contiguous(), mask[:n].contiguous()
+        codes = isinstance(resp, ops.CellCodes)
+        if codes:
+            hip_rows, hip_mask = resp.rows(slice(0, n)), None
+            r, m = hip_rows.unpack()
+        else:
+            r, m = resp[:n].contiguous(), mask[:n].contiguous()
+            hip_rows, hip_mask = r, m
+        mcode = _lib.MASK_CODES if codes else _lib.MASK_U8
+        kernel = ops.plan_kernel(model.spec, n, I, mcode, False)
+        kernel_timed = ops.plan_kernel(model.spec, resp.shape[0], I, mcode, not args.eval_only)
         with torch.no_grad():
-            hip = float(model.elbo(*model(r, m, eps_item=eps_i, eps_ability=eps_a)))
+            hip = float(model.elbo(*model(hip_rows, hip_mask, eps_item=eps_i, eps_ability=eps_a)))
         out = {}
         for name, dt_ in (('fp32', torch.float32), ('fp64', torch.float64)):
             params = {k: v.detach().cpu().to(dt_) for k, v in model.state_dict().items()}
@@ -424,7 +442,8 @@ def main():
                 ref = float(O.elbo_forward(params, r.cpu().to(dt_), m.cpu(), eps_i.cpu().to(dt_), eps_a.cpu().to(dt_),
                                            irt_model=irt, ability_dim=A)['loss'])
             out[name] = abs(hip - ref) / abs(ref)
-        return {'persons': n, 'vs_reference_op_sequence_fp32': out['fp32'], 'vs_same_in_fp64': out['fp64'], 'elbo_hip': hip}
+        return {'persons': n, 'kernel': kernel, 'kernel_of_the_timed_step': kernel_timed, 'same_kernel': kernel == kernel_timed,
+                'vs_reference_op_sequence_fp32': out['fp32'], 'vs_same_in_fp64': out['fp64'], 'elbo_hip': hip}
 
     def batch_sweep(model, resp, mask, A):
         """Train-step rate at the minibatch sizes SURVEY.md §8d names (rows gathered in the kernel, hipGraph replay)."""
@@ -533,7 +552,10 @@ def main():
                 'value': total_persons * I * args.steps / m2['dt'], 'ms_per_step': m2['dt'] / args.steps * 1e3,
                 'kernel_ms': m2['kern_ms'], 'roofline_achieved_GBps': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9,
                 'roofline_frac': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 8000.0,
-                'roofline_frac_of_measured_copy_peak': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 6290.0}
+                'roofline_frac_step': b2 * total_persons * I * args.steps / m2['dt'] / 1e9 / 8000.0 / world,
+                'roofline_frac_of_measured_copy_peak': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 6290.0,
+                'elbo_rel_err': m2['rel']['vs_reference_op_sequence_fp32'] if m2.get('rel') else None,
+                'elbo_rel_err_kernel': m2['rel']['kernel'] if m2.get('rel') else None}
 
     format_p = None
     if not args.no_format_p:
@@ -545,7 +567,9 @@ def main():
                     'kernel_ms': m3['kern_ms'], 'bytes_per_term': b3,
                     'roofline_achieved_GBps': b3 * P * I / (m3['kern_ms'] * 1e-3) / 1e9,
                     'roofline_frac': b3 * P * I / (m3['kern_ms'] * 1e-3) / 1e9 / 8000.0,
-                    'bound': 'valu (latency / issue), not hbm', 'final_loss_per_term': m3['final_loss'] / (total_persons * I)}
+                    'bound': 'valu (latency / issue), not hbm', 'final_loss_per_term': m3['final_loss'] / (total_persons * I),
+                    'elbo_rel_err': m3['rel']['vs_reference_op_sequence_fp32'] if m3.get('rel') else None,
+                    'elbo_rel_err_kernel': m3['rel']['kernel'] if m3.get('rel') else None}
 
     # HBM bytes per launch: parsed from the committed rocprofv3 summary of this command (tools/collect_profile.sh); only
     # meaningful for the workload that summary was taken on (the default one)
@@ -561,7 +585,9 @@ def main():
                       if not args.eval_only else 'person x item ELBO terms/sec (forward ELBO only)',
             'value': terms / dt, 'unit': 'terms/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f32 (the three ability-wide contractions of the matrix kernel: 3-pass f16 hi/lo MFMA products, ~22-bit, fp32 accumulate; everything else fp32)',
+            'data': 'synthetic',
             'config': {'workload': f'{args.irt_model.upper()} simulation, {P} persons x {I} items per GPU{" (" + str(args.persons) + " in total, strong scaling)" if args.scaling == "strong" else ""}, '
                                    f'ability_dim={A}, {args.missing:.0%} missing, {"product-of-experts" if args.ability_merge == "product" else "mean-merge"} encoder, '
                                    f'unconditional posterior, full-shard minibatch',
@@ -571,6 +597,11 @@ def main():
                        'final_loss_per_term': final_loss / (total_persons * I)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
+                         # the same bytes over the whole timed step (noise, prologue, kernel, finalize, [all-reduce], epilogue + Adam)
+                         'frac_step': bytes_per_term * P * I / (dt / args.steps) / 1e9 / 8000.0,
+                         'frac_note': 'frac = algorithmic bytes / mean duration of the fused call by HIP events on its stream (10 back-to-back '
+                                      'calls after the timed region); frac_step = the same bytes / ms_per_step; the rocprofv3 kernel-trace '
+                                      f'average of the same command is in profiles/{PROFILE_FILE}',
                          'traffic': traffic, 'traffic_note': traffic_note,
                          'kernel': 'vibo::msplit_kernel (+ the finalize helper inside the timed events)',
                          'kernel_ms': kern_ms, 'bytes_per_term': bytes_per_term},

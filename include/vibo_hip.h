@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VIBO_ABI_VERSION 1
+#define VIBO_ABI_VERSION 2
 
 enum { VIBO_IRT_1PL = 1, VIBO_IRT_2PL = 2, VIBO_IRT_3PL = 3 };
 enum { VIBO_POSTERIOR_UNCONDITIONAL = 0, VIBO_POSTERIOR_CONDITIONAL = 1,
@@ -84,7 +84,24 @@ typedef struct vibo_desc {
     int32_t deterministic;    /* 1: fixed-order reductions (bitwise reproducible)    */
     int64_t response_row_stride; /* elements between consecutive rows of `response`  */
     int64_t mask_row_stride;     /* elements between consecutive rows of `mask`      */
+    int32_t flags;            /* VIBO_FLAG_* (0 = let the planner choose)            */
+    int32_t reserved;         /* 0                                                   */
 } vibo_desc;
+
+/* vibo_desc.flags: planner overrides (A/B measurements, tests that pin one kernel).  The planner reads nothing but the
+ * descriptor -- no environment variables, no state between calls. */
+enum { VIBO_FLAG_KERNEL_VALU = 1,     /* row-split work goes to the VALU kernel (vibo_split_kernel.hpp)              */
+       VIBO_FLAG_KERNEL_MATRIX = 2,   /* ... to the matrix-pipe kernel (vibo_msplit_kernel.hpp) whatever the size    */
+       VIBO_FLAG_NO_EMIT_CODES = 4 }; /* multi-pass paths re-read the fp32 rows instead of the first pass's cell codes */
+
+/* Which fused kernel vibo_elbo_fwd_bwd would launch for `d` (pointers assumed aligned): VIBO_KERNEL_*, or <0 on a bad
+ * descriptor.  Lets a benchmark state which kernel its numbers belong to. */
+enum { VIBO_KERNEL_MATRIX = 1,        /* msplit_kernel: contractions as f16 hi/lo MFMAs (default above 2 048 persons) */
+       VIBO_KERNEL_VALU = 2,          /* split_kernel: VALU row-split kernel                                          */
+       VIBO_KERNEL_ROW = 3,           /* wave-per-row kernel (int64 masks)                                            */
+       VIBO_KERNEL_TILED = 4,         /* tiled fp32-MFMA fallback (ragged rows)                                       */
+       VIBO_KERNEL_GENERAL = 5 };     /* wave-per-person fallback                                                     */
+int vibo_plan_kernel(const vibo_desc* d);
 
 /* Library / ABI version (VIBO_ABI_VERSION of the build). */
 int vibo_version(void);

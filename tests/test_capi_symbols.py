@@ -39,6 +39,34 @@ def test_version_and_descriptor_validation():
     assert lib.vibo_workspace_bytes(ctypes.byref(d)) > 0
 
 
+def test_planner_reports_its_kernel_and_honours_the_flags():
+    """vibo_plan_kernel (no launch, no GPU needed): the benchmark's shape goes to the matrix row-split kernel, the
+    reference's default minibatch (16 persons) to the VALU one, and vibo_desc.flags pins either -- the planner reads the
+    descriptor only (no environment variables)."""
+    lib = _lib.load()
+
+    def plan(B, I, A, flags=0, mask=_lib.MASK_U8):
+        d = _lib.ViboDesc()
+        d.abi_version = _lib.ABI_VERSION
+        d.num_person, d.num_item, d.ability_dim, d.irt_model = B, I, A, 2
+        d.mask_dtype, d.want_grad, d.flags = mask, 1, flags
+        d.response_row_stride = d.mask_row_stride = (I + 3) & ~3
+        return lib.vibo_plan_kernel(ctypes.byref(d))
+
+    assert plan(1_000_000, 1000, 8) == 1 and plan(1_000_000, 1000, 1) == 1          # bench.py's two shapes
+    assert plan(4096, 1000, 8) == 1                                                  # ... and its elbo_rel_err sample
+    assert plan(16, 1000, 8) == 2 and plan(535_598, 96, 1) == 2
+    assert plan(16, 1000, 8, _lib.FLAG_KERNEL_MATRIX) == 1 and plan(1_000_000, 1000, 8, _lib.FLAG_KERNEL_VALU) == 2
+    assert plan(1000, 1000, 2, 0, _lib.MASK_I64) == 3
+    assert plan(16, 1000, 8, 3) < 0 and plan(16, 1000, 8, 64) < 0                    # contradictory / unknown flags
+    import os
+    os.environ['VIBO_MSPLIT'] = '0'                                                  # (round 2's switch: ignored now)
+    try:
+        assert plan(1_000_000, 1000, 8) == 1
+    finally:
+        del os.environ['VIBO_MSPLIT']
+
+
 def test_desc_struct_matches_header():
     """ctypes mirror has the header's field order."""
     src = open(os.path.join(ROOT, 'include', 'vibo_hip.h')).read()

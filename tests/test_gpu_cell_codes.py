@@ -15,14 +15,15 @@ from vibo_amd.trainer import FusedTrainer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[('1', '1'), ('0', '1'), ('1', '0')], ids=['matrix-kernel', 'valu-kernel', 'matrix-kernel-fp32-passes'])
+@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES],
+                ids=['matrix-kernel', 'valu-kernel', 'matrix-kernel-fp32-passes'])
 def row_split_kernel_choice(request, monkeypatch):
     """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
-    above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; VIBO_MSPLIT pins one for the whole test.
-    Third run: the multi-pass paths (conditional posterior, more than 1024 items) re-read the fp32 rows in every pass instead
-    of the 1-byte cell codes their first pass leaves behind (VIBO_EMIT_CODES=0)."""
-    monkeypatch.setenv('VIBO_MSPLIT', request.param[0])
-    monkeypatch.setenv('VIBO_EMIT_CODES', request.param[1])
+    above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; vibo_desc.flags pins one for the whole test
+    (ops.DESC_FLAGS: the library reads no environment variable).  Third run: the multi-pass paths (conditional posterior, more
+    than 1024 items) re-read the fp32 rows in every pass instead of the 1-byte cell codes their first pass leaves behind
+    (VIBO_FLAG_NO_EMIT_CODES)."""
+    monkeypatch.setattr(ops, 'DESC_FLAGS', request.param)
 dev = torch.device('cuda:0')
 
 

@@ -21,14 +21,15 @@ from vibo_amd.ops import ElboSpec
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[('1', '1'), ('0', '1'), ('1', '0')], ids=['matrix-kernel', 'valu-kernel', 'matrix-kernel-fp32-passes'])
+@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES],
+                ids=['matrix-kernel', 'valu-kernel', 'matrix-kernel-fp32-passes'])
 def row_split_kernel_choice(request, monkeypatch):
     """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
-    above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; VIBO_MSPLIT pins one for the whole test.
-    Third run: the multi-pass paths (conditional posterior, more than 1024 items) re-read the fp32 rows in every pass instead
-    of the 1-byte cell codes their first pass leaves behind (VIBO_EMIT_CODES=0)."""
-    monkeypatch.setenv('VIBO_MSPLIT', request.param[0])
-    monkeypatch.setenv('VIBO_EMIT_CODES', request.param[1])
+    above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; vibo_desc.flags pins one for the whole test
+    (ops.DESC_FLAGS: the library reads no environment variable).  Third run: the multi-pass paths (conditional posterior, more
+    than 1024 items) re-read the fp32 rows in every pass instead of the 1-byte cell codes their first pass leaves behind
+    (VIBO_FLAG_NO_EMIT_CODES)."""
+    monkeypatch.setattr(ops, 'DESC_FLAGS', request.param)
 
 TOL_ELBO = 1e-4
 
@@ -326,6 +327,45 @@ def test_all_missing_rows_and_saturated_logits():
     assert float((ref['logit'].abs() > 17).float().mean()) > 0.02      # the clamp really is exercised
     raw = run_kernel(spec, resp, mask, table, item, eps)
     compare_raw(raw, ref, (I, spec.item_dim), tol=1e-3)
+
+
+@pytest.mark.parametrize('irt', [2, 3])
+@pytest.mark.parametrize('A', [1, 8])
+@pytest.mark.parametrize('scale', [1e-4, 1e3, 1e5, 3e6])
+def test_item_scales_far_outside_the_f16_range(scale, A, irt):
+    """The matrix kernel's contractions run on f16 hi/lo pieces (vibo_msplit_kernel.hpp): item parameters far below and far
+    above the f16 range (max 65 504) must still give the fp32 reference's numbers -- the kernel rescales its operands by a
+    power of two per launch (up to 2^8, exact).  Discriminations / difficulties of 1e-4 ... 3e6: beyond ~1e3 every logit
+    is past the Bernoulli clamp (log-lik capped, likelihood gradients exactly zero), which the oracle reproduces
+    (exact_saturation).  Runs on both row-split kernels (fixture)."""
+    B, I = 96, 384
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.2, seed=31 + A)
+    item[:, :A + 1] *= scale                   # discriminations and difficulties (the 3PL guess logit stays O(1))
+    ref = T.fused_elbo_ref(table, item, resp, mask, eps, irt_model=irt, ability_dim=A, mode='kl', exact_saturation=True)
+    raw = run_kernel(spec, resp, mask, table, item, eps)
+    assert torch.isfinite(raw.scalars).all()
+    if irt == 3 and scale >= 1e3:
+        # 3PL clamps the mixture probability itself (models.py:758-765): with |logit| in the thousands the clamp decision of a
+        # cell at p = guess + (1 - guess) sigmoid(l) is settled, but g_item's guess column keeps O(1) entries -- same bar
+        compare_raw(raw, ref, (I, spec.item_dim), tol=1e-3)
+    else:
+        compare_raw(raw, ref, (I, spec.item_dim), tol=3e-4 if scale < 1e3 else 1e-3)
+
+
+def test_operands_beyond_the_rescaling_range_fail_loudly():
+    """|a log2 e| above 2^23 (or an ability sample beyond 65 504) cannot be represented by the matrix kernel's scaled f16
+    pieces: the result is NaN, never a silently wrong number; the fp32 VALU kernel (VIBO_FLAG_KERNEL_VALU) still evaluates it."""
+    irt, A, B, I = 2, 2, 64, 256
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.1, seed=5)
+    item[3, 0] = 3e7
+    raw = run_kernel(spec, resp, mask, table, item, eps)
+    if ops.DESC_FLAGS & _lib.FLAG_KERNEL_VALU:
+        ref = T.fused_elbo_ref(table, item, resp, mask, eps, irt_model=irt, ability_dim=A, mode='kl', exact_saturation=True)
+        assert rel_err(raw.scalars.cpu()[_lib.S_LL], ref['ll']) < 2e-5
+    else:
+        assert torch.isnan(raw.scalars[_lib.S_LL])
 
 
 def test_saturation_golden_through_kernel():

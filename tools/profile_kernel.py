@@ -25,8 +25,10 @@ ap.add_argument('--missing', type=float, default=0.1)
 ap.add_argument('--gather', action='store_true', help='rows through a random row_index permutation (shuffled minibatch)')
 ap.add_argument('--given', action='store_true', help='caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN, the --ability-merge mean path)')
 ap.add_argument('--codes', action='store_true', help='rows as 1-byte cell codes (VIBO_MASK_CODES, Format P) instead of fp32 + mask')
+ap.add_argument('--kernel', choices=['auto', 'matrix', 'valu'], default='auto', help='pin a row-split kernel (vibo_desc.flags)')
 ap.add_argument('--cached-rows', type=int, default=0, help='gather rows from the first N rows only (L2-resident): compute-only timing')
 a = ap.parse_args()
+ops.DESC_FLAGS = {'auto': 0, 'matrix': _lib.FLAG_KERNEL_MATRIX, 'valu': _lib.FLAG_KERNEL_VALU}[a.kernel]
 d = torch.device('cuda:0')
 g = torch.Generator(device=d).manual_seed(0)
 P, I, A = a.persons, a.items, a.ability_dim

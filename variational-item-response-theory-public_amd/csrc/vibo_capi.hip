@@ -51,6 +51,8 @@ static int check_desc(const vibo_desc* d) {
     if (d->reg_mode != VIBO_REG_KL && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "bad reg_mode");
     if (d->n_flows < 0 || d->n_flows > VIBO_MAX_FLOWS) return fail(-3, "n_flows outside 0..%d", VIBO_MAX_FLOWS);
     if (d->n_flows > 0 && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "flows need reg_mode SAMPLED");
+    if (d->flags & ~(VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX | VIBO_FLAG_NO_EMIT_CODES)) return fail(-3, "unknown flags");
+    if ((d->flags & VIBO_FLAG_KERNEL_VALU) && (d->flags & VIBO_FLAG_KERNEL_MATRIX)) return fail(-3, "flags pin two kernels");
     return 0;
 }
 
@@ -141,17 +143,14 @@ static bool codes_three_waves(const vibo_desc* d, int AT) {
     return d->mask_dtype == VIBO_MASK_CODES && (AT <= 2 || (AT == 4 && d->irt_model <= 2));
 }
 
-// Which row-split kernel: the matrix-pipe kernel (contractions as f16 hi/lo MFMAs) or the VALU kernel.  VIBO_MSPLIT=0/1 in the
-// environment forces one of them (A/B measurements, tests of both paths).
-// VIBO_EMIT_CODES=0: later passes re-read the fp32 rows (A/B measurements, tests of both paths)
-static bool emit_codes_wanted() {
-    const char* e = getenv("VIBO_EMIT_CODES");
-    return !(e && e[0] == '0');
-}
+// Which row-split kernel: the matrix-pipe kernel (contractions as f16 hi/lo MFMAs) or the VALU kernel.  The descriptor's
+// flags pin one of them (A/B measurements, tests of both paths); VIBO_FLAG_NO_EMIT_CODES: later passes re-read the fp32 rows.
+static bool emit_codes_wanted(const vibo_desc* d) { return !(d->flags & VIBO_FLAG_NO_EMIT_CODES); }
 static bool want_msplit(const vibo_desc* d) {
-    const char* e = getenv("VIBO_MSPLIT");
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
+    if (d->flags & VIBO_FLAG_KERNEL_VALU) return false;
+    // (32-bit row numbers and batch counters in the matrix kernel)
+    if (d->num_person > 0x7fffffff - 0x10000) return false;
+    if (d->flags & VIBO_FLAG_KERNEL_MATRIX) return true;
     // small minibatches (the reference CLI's default is 16 persons): the matrix kernel's fixed cost -- operand images, 512-thread
     // workgroups, one batch of 32 rows per workgroup -- loses to the VALU kernel's 8-row batches below ~3 000 rows
     // (tools/batch_sweep.py at ability_dim 8: 42 vs 50 us per step at 16 rows, 46 vs 52 at 1 024, 59 vs 54 at 4 096)
@@ -239,7 +238,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
             {
                 // cond_post on cell codes (the caller's, or the ones cond_pre leaves behind) has no fp32 row registers: 3 waves per SIMD
                 const bool post_codes = d->mask_dtype == VIBO_MASK_CODES ||
-                                        (emit_codes_wanted() && d->mask_dtype != VIBO_MASK_I64);
+                                        (emit_codes_wanted(d) && d->mask_dtype != VIBO_MASK_I64);
                 if (post_codes && A <= 2) {
                     pl->cond_post_nblk = num_cu * 3;
                     if (pl->cond_post_nblk > (d->num_person + 7) / 8) pl->cond_post_nblk = (d->num_person + 7) / 8;
@@ -258,7 +257,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         // 100k x 10k 2.32 vs 2.23 ms, so row_count_kernel's code output stays unused there.)
         pl->off_codes = 0;
         pl->codes_stride = ((long long)I + 255) / 256 * 256;      // whole 128-byte lines per wave store (4 B per lane x 64 lanes)
-        if (emit_codes_wanted() && d->mask_dtype != VIBO_MASK_CODES && d->mask_dtype != VIBO_MASK_I64 && is_cond) {
+        if (emit_codes_wanted(d) && d->mask_dtype != VIBO_MASK_CODES && d->mask_dtype != VIBO_MASK_I64 && is_cond) {
             pl->off_codes = off;
             off += up((size_t)d->num_person * pl->codes_stride);
         }
@@ -818,6 +817,18 @@ using namespace vibo;
 extern "C" {
 
 int vibo_version(void) { return VIBO_ABI_VERSION; }
+
+int vibo_plan_kernel(const vibo_desc* d) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    Plan pl;
+    rc = make_plan(d, &pl);
+    if (rc < 0) return rc;
+    if (pl.general) return VIBO_KERNEL_GENERAL;
+    if (pl.panels > 0 || pl.split_ok) return pl.msplit ? VIBO_KERNEL_MATRIX : VIBO_KERNEL_VALU;
+    if (pl.row_ok && d->num_item % 4 == 0 && pl.AT == d->ability_dim) return VIBO_KERNEL_ROW;
+    return VIBO_KERNEL_TILED;
+}
 
 const char* vibo_last_error_string(void) { return g_err; }
 

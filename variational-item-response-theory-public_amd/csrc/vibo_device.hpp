@@ -96,6 +96,28 @@ __device__ __forceinline__ uint32_t pack_cell_codes4(const uint32_t w, const uin
     packed += __builtin_popcount(m) + (__builtin_popcount(xb & m) << 16);
     return code;
 }
+// The same two packs for the matrix row-split kernel, as byte look-ups (v_perm_b32) with the counts in two plain
+// accumulators: no `m * 0xFF` -- hipcc turns the shift-and-subtract form above back into a quarter-rate v_mul_lo_u32.
+//   fp32 rows: selector byte = 2 [correct] + [observed] in {0..3} -> {0, code(wrong), 0, code(right)}
+// `lut`: bytes {missing, wrong, -, right} as fp8 (e4m3) values, e.g. 0xB8003800 = {0, +1, 0, -1}
+__device__ __forceinline__ uint32_t pack_codes4_lut(const float4 x, const uint32_t m, const uint32_t lut, int& nobs, int& n1) {
+    const uint32_t x0 = __builtin_bit_cast(uint32_t, x.x), x1 = __builtin_bit_cast(uint32_t, x.y);
+    const uint32_t x2 = __builtin_bit_cast(uint32_t, x.z), x3 = __builtin_bit_cast(uint32_t, x.w);
+    // (the mask bytes are 0 / 1, so the "& m" also isolates bit 0 of the high bytes)
+    const uint32_t xm = (__builtin_amdgcn_perm(x1, x0, 0x0c0c0703u) | __builtin_amdgcn_perm(x3, x2, 0x07030c0cu)) & m;
+    const uint32_t sel = (xm << 1) + m;          // 0 missing | 1 wrong | 3 right
+    nobs += __builtin_popcount(m);
+    n1 += __builtin_popcount(xm);
+    return __builtin_amdgcn_perm(0u, lut, sel);
+}
+//   cell codes: selector byte = the code itself (0 wrong / 1 right / 2 missing), bytes outside `keep` forced to 2
+__device__ __forceinline__ uint32_t pack_cell_codes4_lut(const uint32_t w, const uint32_t keep, const uint32_t lut, int& nobs, int& n1) {
+    const uint32_t sel = (w & keep) | (0x02020202u & ~keep);
+    const uint32_t ob = ~(sel >> 1) & 0x01010101u;
+    nobs += __builtin_popcount(ob);
+    n1 += __builtin_popcount(sel & ob);
+    return __builtin_amdgcn_perm(0u, lut, sel);
+}
 constexpr uint32_t kAllMissing4 = 0x02020202u;
 
 // 4 responses (fp32 0.0/1.0) + 4 mask bytes (0/1) -> the 4 Format P cell codes (0 wrong / 1 right / 2 missing): what a first pass

@@ -100,11 +100,6 @@ __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
     hi = h[0];
     lo = pkrtz(x - (float)h[0], 0.f)[0];
 }
-// buffer resource over `bytes` bytes from `base` (wave-uniform); loads past the end return zeros
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ms_rsrc(const void* base, long long bytes) {
-    const unsigned n = bytes <= 0 ? 0u : bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)n, 0x00020000);
-}
 // running sum in LDS, one owner lane per address: plain read-modify-write (measured: 12 ds_add_f32 per batch and owner
 // lane instead cost the whole kernel 0.29 ms of 1.46 -- the LDS serialises its float atomics)
 __device__ __forceinline__ void lds_add(float* p, float v) { *p += v; }
@@ -124,8 +119,14 @@ __device__ __forceinline__ half8 cat8(const half2v a, const half2v b, const half
 // IRT: 1/2/3PL.  GRAD: also gradients.  RM (row mode): 0 = fp32 responses + mask bytes, rows in order; 1 = the same
 // through p.row_index; 2 = 1-byte cell codes (VIBO_MASK_CODES, through p.mask), with or without p.row_index.
 // FLOWS: planar flows on the ability sample (flows.py:21-66, models.py:342-348) in the (person, dim) lanes.
+// NW8: the workgroup has exactly 8 waves (897..1024 items, the benchmark's width): slot ownership and the sums over the
+// waves' LDS records are compile-time.  EXTRA: the launch uses one of the panel / conditional / given hooks (p.row_cnt,
+// p.pre_stats, p.post_coef, p.primary == 0); without it those branches do not exist in the code.
 // blockDim.x = 64 nw, dynamic LDS = msplit_lds_bytes(nw, FLOWS).
-template <int IRT, bool GRAD, int RM, bool FLOWS>
+// The kernel runs at 2 waves per SIMD, where a wave issues at most one instruction per ~5 cycles whatever its type: every
+// scalar instruction, branch and spill reload in the batch loop costs as much as a vector instruction (round 3: the loop
+// lost ~500 of its ~2 300 executed instructions per wave and batch this way).
+template <int IRT, bool GRAD, int RM, bool FLOWS, bool NW8, bool EXTRA>
 __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     constexpr bool CODES = RM == 2;
     constexpr int R = kMsRows;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = (int)(blockDim.x >> 6);
+    const int nw = NW8 ? 8 : (int)(blockDim.x >> 6);
     MsWaveLds& wl = wls[q];
     MsFlowLds& fl = *reinterpret_cast<MsFlowLds*>(ms_smem + sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds));   // (FLOWS only)
     const int I = p.I, A = p.A;
@@ -183,24 +184,71 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     //   logit MFMA, tile (u, t): lane (item 4 (32 q + 16 u + i16) + t, g) reads 16 B: g 0/2 = na hi, 1 = na lo, 3 = bias pieces
     //   d LL/d theta MFMA, (u, kt): lane (col i16, g) gets k = 8 g + kk <-> item (chunk 4 g + (kk & 3), t = 2 kt + (kk >> 2)) by two
     //   transposed reads of the [na_hi | na_lo] rows
+    //
+    // Range of the f16 pieces: an operand above 65 504 would saturate its hi piece.  The launch's largest |na|, |nb| decides
+    // a power of two 2^ksh (ksh = 0 whenever everything is below 2^15, i.e. for any sane item parameters; up to 8): the image
+    // holds the operands times 2^-ksh (exact), the MFMA returns logit x 2^-ksh, and the cells' fp8 codes carry -w 2^ksh
+    // instead of -w (the byte look-up of the pack: free), so the exponent -w l is exact and the hot path has not one
+    // instruction more.  What changes with ksh > 0: d ll/d l comes out times 2^ksh -- d LL/d theta = sum g a is then
+    // already right, d LL/d a, d b, d guess are scaled back once in the epilogue -- and the clamp thresholds on the raw
+    // MFMA output scale with it.  Operands beyond 2^23 (or a sample |theta| > 65 504) turn the results into NaN rather
+    // than into silently wrong numbers; VIBO_FLAG_KERNEL_VALU runs such inputs on the fp32 VALU kernel.
     float gs[2][4], om[2][4];           // 3PL: guess, 1 - guess of the lane's items
+    float na_raw[2][8], nb_raw[2];
+    float amax = 0.f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int xl = 64 * h + lane;                                   // item of the wave, one per lane and pass
         const int il = kMsSpan * q + xl;
         const bool ok = il < I;
         const float* ir = p.item_raw + (size_t)(p.item0 + (ok ? il : 0)) * p.D;
-        _Float16* dst = &wl.img[h][0] + ((xl & 63) >> 2) * kMsItemLane + (xl & 3) * kMsItemRow;
-        half8 hi8, lo8;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float na = 0.f;
             if (ok && kk < A) na = IRT == 1 ? kLog2e : -ir[kk] * kLog2e;      // models.py:731 / 744,759
+            na_raw[h][kk] = na;
+            amax = fmaxf(amax, fabsf(na));
+        }
+        nb_raw[h] = ok ? ir[IRT == 1 ? 0 : A] * kLog2e : 0.f;
+        amax = fmaxf(amax, fabsf(nb_raw[h]));
+    }
+    {
+        // workgroup maximum (NaN / Inf operands count as "too large": the results become NaN below)
+        float mx = (amax <= 3.0e38f) ? amax : 3.0e38f;
+        mx = fmaxf(mx, dpp_f<0xb1>(mx)); mx = fmaxf(mx, dpp_f<0x4e>(mx));
+        mx = fmaxf(mx, dpp_f<0x124>(mx)); mx = fmaxf(mx, dpp_f<0x128>(mx));
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (lane == 0) wl.red[1] = mx;
+    }
+    __syncthreads();
+    float wg_max = 0.f;
+    for (int w = 0; w < nw; ++w) wg_max = fmaxf(wg_max, wls[w].red[1]);
+    // 2^ksh: the smallest power of two that brings the maximum below 2^15 (frexp exponent e: max < 2^e)
+    int ksh = 0;
+    {
+        const int e = (int)((__builtin_bit_cast(uint32_t, wg_max) >> 23) & 0xff) - 126;
+        ksh = __builtin_amdgcn_readfirstlane(e > 15 ? e - 15 : 0);
+    }
+    const bool range_fault = ksh > 8;                 // (wave-uniform) operands beyond 2^23: poison the outputs
+    if (range_fault) ksh = 8;
+    const float sc_dn = __builtin_bit_cast(float, (uint32_t)(127 - ksh) << 23);        // 2^-ksh
+    const float sc_up = __builtin_bit_cast(float, (uint32_t)(127 + ksh) << 23);        // 2^ksh
+    // fp8 (e4m3) look-up table of the pack: {missing, wrong, -, right} -> {0, +-2^ksh, 0, -+2^ksh}
+    const uint32_t cb = (uint32_t)(ksh + 7) << 3;
+    const uint32_t lut_fp32 = (IRT != 3) ? ((cb | 0x80u) << 24) | (cb << 8) : (cb << 24) | ((cb | 0x80u) << 8);
+    const uint32_t lut_code = (IRT != 3) ? ((cb | 0x80u) << 8) | cb : (cb << 8) | (cb | 0x80u);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int xl = 64 * h + lane;
+        _Float16* dst = &wl.img[h][0] + ((xl & 63) >> 2) * kMsItemLane + (xl & 3) * kMsItemRow;
+        half8 hi8, lo8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
             _Float16 hi, lo;
-            split16(na, hi, lo);
+            split16(na_raw[h][kk] * sc_dn, hi, lo);
             hi8[kk] = hi; lo8[kk] = lo;
         }
-        const float nb = ok ? ir[IRT == 1 ? 0 : A] * kLog2e : 0.f;
+        const float nb = range_fault ? __builtin_nanf("") : nb_raw[h] * sc_dn;
         _Float16 b0, b1, b2, b3;
         split16(nb, b0, b1);
         split16(nb - (float)b0 - (float)b1, b2, b3);
@@ -243,18 +291,19 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int wofs = 16 * i16 + 4 * (g ^ (i16 >> 2));
     const int rofs = 64 * g + 16 * (i16 >> 2) + 4 * ((i16 & 3) ^ g);
 
-    const long long n_batches = ((long long)p.B + R - 1) / R;
+    // (the planner keeps num_person <= 2^31 - 2^16: row numbers and batch counters are 32-bit)
+    const int n_batches = (int)(((long long)p.B + R - 1) / R);
     float4 x[CODES ? 1 : 8];                        // [2 j + u]: person j of the half, chunk u
     uint32_t m[8];
     int ridx[8];
-    auto fetch_idx = [&](const long long bt) {
+    auto fetch_idx = [&](const int bt) {
         if constexpr (RM != 0) {
             if (!p.row_index) return;
-            const long long row0 = bt * R;
+            const int row0 = bt * R;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const long long row = row0 + 4 * g + (k & 3) + 16 * (k >> 2);
-                const long long rc = min(row, (long long)p.B - 1);
+                const int row = row0 + 4 * g + (k & 3) + 16 * (k >> 2);
+                const int rc = min(row, p.B - 1);
                 ridx[k] = bt < n_batches ? (int)p.row_index[rc] : 0;
             }
         }
@@ -265,48 +314,41 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // to be re-fetched half a batch later: 1.34x the algorithmic HBM traffic).
     // In-order rows go through buffer loads: one resource per batch (scalar registers) whose record limit ends at the last
     // row of the matrix (rows past the end read as zeros), per-lane offsets shared by all rows of the lane and the row step
-    // as a scalar offset -- no per-row address registers.  Gathered rows compute their addresses at the load.  Chunks
-    // past the row's end read its last chunk; both cases are masked when the cells are packed.
+    // as a scalar offset -- no per-row address registers, and no branch in the load sequence: without a mask the mask
+    // resource has no records (its loads return zeros) and the cells are switched on when they are packed (`fillw`).
+    // Gathered rows compute their addresses at the load.  Chunks past the row's end read its last chunk; both cases are
+    // masked when the cells are packed.
     const int cc0 = min(32 * q + i16, n4 - 1), cc1 = min(32 * q + 16 + i16, n4 - 1);
-    const unsigned mvo0 = (unsigned)(4 * g * (int)p.mask_stride + 4 * cc0), mvo1 = (unsigned)(4 * g * (int)p.mask_stride + 4 * cc1);
-    const unsigned rvo0 = (unsigned)(16 * g * (int)p.resp_stride + 16 * cc0), rvo1 = (unsigned)(16 * g * (int)p.resp_stride + 16 * cc1);
-    // per-batch source of the in-order rows (scalar registers): past the last batch the record count is 0 and every load
-    // returns zeros, so no load sits behind a branch
+    const unsigned rstride4 = (unsigned)p.resp_stride * 4u, mstride = (unsigned)p.mask_stride;      // bytes per row
+    const unsigned mvo0 = 4u * g * mstride + 4u * cc0, mvo1 = 4u * g * mstride + 4u * cc1;
+    const unsigned rvo0 = 4u * g * rstride4 + 16u * cc0, rvo1 = 4u * g * rstride4 + 16u * cc1;
+    const bool have_mask = CODES || p.mask_dtype == 0;        // (wave-uniform)
+    const uint32_t fillw = have_mask ? 0u : 0x01010101u;
     struct RowSrc { __amdgpu_buffer_rsrc_t r, m; };
-    const long long full_r = (31ll * p.resp_stride + 4 * n4) * 4, full_m = 31ll * p.mask_stride + 4 * n4;
-    auto row_src = [&](const long long bt) {
-        const long long row0 = bt * R;
-        const long long left = (long long)p.B - row0;
-        long long br = full_r, bm = full_m;
-        if (left < R) {                      // (wave-uniform; the last batch of the matrix, or past it)
-            br = left > 0 ? ((left - 1) * p.resp_stride + 4 * n4) * 4 : 0;
-            bm = left > 0 ? (left - 1) * p.mask_stride + 4 * n4 : 0;
-        }
+    auto row_src = [&](const int bt) {
+        const int rows = min(p.B - bt * R, R);                // rows of this batch (<= 0 past the last batch: no records)
+        const unsigned br = rows > 0 ? (unsigned)(rows - 1) * rstride4 + 16u * n4 : 0u;
+        const unsigned bm = (rows > 0 && have_mask) ? (unsigned)(rows - 1) * mstride + 4u * n4 : 0u;
         RowSrc rs;
-        rs.m = ms_rsrc(static_cast<const uint8_t*>(p.mask) + row0 * p.mask_stride + p.item0, p.mask ? bm : 0);
-        if constexpr (!CODES) rs.r = ms_rsrc(p.response + row0 * p.resp_stride + p.item0, br);
+        rs.m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(static_cast<const uint8_t*>(p.mask) + (size_t)bt * R * p.mask_stride + p.item0),
+                                                 (short)0, (int)bm, 0x00020000);
+        if constexpr (!CODES) rs.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.response + (size_t)bt * R * p.resp_stride + p.item0),
+                                                                       (short)0, (int)br, 0x00020000);
         else rs.r = rs.m;
         return rs;
     };
     // quarter (h, j) = person 4 h + j of the lane (row 4 g + j + 16 h of the batch), both chunks: 2 x 16 B + 2 x 4 B
-    auto load_quarter = [&](const long long bt, const RowSrc& rs, const int h, const int j) {
+    auto load_quarter = [&](const int bt, const RowSrc& rs, const int h, const int j) {
         bool linear = RM == 0;
         if constexpr (RM == 2) linear = p.row_index == nullptr;
         if (linear) {
-            const int mso = (j + 16 * h) * (int)p.mask_stride;
-            if constexpr (CODES) {
-                m[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo0, mso, 0);
-                m[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo1, mso, 0);
-            } else {
-                const int so = (j + 16 * h) * 4 * (int)p.resp_stride;
+            const int mso = (j + 16 * h) * (int)mstride;
+            m[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo0, mso, 0);
+            m[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo1, mso, 0);
+            if constexpr (!CODES) {
+                const int so = (j + 16 * h) * (int)rstride4;
                 x[2 * j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo0, so, 0));
                 x[2 * j + 1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo1, so, 0));
-                if (p.mask_dtype == 0) {
-                    m[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo0, mso, 0);
-                    m[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo1, mso, 0);
-                } else {
-                    m[2 * j] = m[2 * j + 1] = 0x01010101u;
-                }
             }
         } else {
             if (bt >= n_batches) return;
@@ -324,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     m[2 * j] = mp[cc0];
                     m[2 * j + 1] = mp[cc1];
                 } else {
-                    m[2 * j] = m[2 * j + 1] = 0x01010101u;
+                    m[2 * j] = m[2 * j + 1] = 0u;
                 }
             }
         }
@@ -333,23 +375,41 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const uint32_t tm_tail = (I & 3) ? ((1u << (8 * (I & 3))) - 1u) : 0xFFFFFFFFu;
     const uint32_t tm0 = (32 * q + i16) >= n4 ? 0u : ((I & 3) && (32 * q + i16) == (I >> 2)) ? tm_tail : 0xFFFFFFFFu;
     const uint32_t tm1 = (32 * q + 16 + i16) >= n4 ? 0u : ((I & 3) && (32 * q + 16 + i16) == (I >> 2)) ? tm_tail : 0xFFFFFFFFu;
+    // Rows past the matrix' end (last batch only): in-order rows with a mask read zeros there (the resource's record
+    // limit) and need nothing; gathered rows, rows without a mask and cell codes (0 = an answer) are masked per lane -- in
+    // a variant of the pack of its own, so that the common case carries no selects.
+    bool need_in = RM != 0 || !have_mask;
+    if constexpr (RM == 2) need_in = true;
     // pk[j]: 8-bit fields nobs | nobs of M-tile 1 | n1 | n1 of M-tile 1 of persons j and 4 + j (each <= 8 per lane)
-    auto pack_quarter = [&](const long long bt, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4]) {
-        int pc = 0;
-        const long long left = (long long)p.B - bt * R;          // (wave-uniform) only the last batch has rows past the end
-        const bool in = left >= R || 4 * g + j + 16 * h < (int)left;
-        const uint32_t k0 = in ? tm0 : 0u, k1 = in ? tm1 : 0u;
-        // 1PL/2PL carry -w in the codes (the exponent is -w x logit: one VOP2 multiply)
-        if constexpr (CODES) {
-            cw0[4 * h + j] = pack_cell_codes4<IRT != 3>(m[2 * j], k0, pc);
-            cw1[4 * h + j] = pack_cell_codes4<IRT != 3>(m[2 * j + 1], k1, pc);
-        } else {
-            cw0[4 * h + j] = pack_codes4<IRT != 3>(x[2 * j], m[2 * j] & k0, pc);
-            cw1[4 * h + j] = pack_codes4<IRT != 3>(x[2 * j + 1], m[2 * j + 1] & k1, pc);
+    auto pack_quarter = [&](auto inc, const int left, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4]) {
+        constexpr bool IN = decltype(inc)::value;
+        uint32_t k0 = tm0, k1 = tm1;
+        if constexpr (IN) {
+            const bool in = 4 * g + j + 16 * h < left;
+            k0 = in ? tm0 : 0u; k1 = in ? tm1 : 0u;
         }
-        pk[j] += h ? (pc << 8) : pc;
+        // 1PL/2PL carry -w in the codes (the exponent is -w x logit: one VOP2 multiply)
+        int nobs = 0, n1 = 0;
+        if constexpr (CODES) {
+            cw0[4 * h + j] = pack_cell_codes4_lut(m[2 * j], k0, lut_code, nobs, n1);
+            cw1[4 * h + j] = pack_cell_codes4_lut(m[2 * j + 1], k1, lut_code, nobs, n1);
+        } else {
+            cw0[4 * h + j] = pack_codes4_lut(x[2 * j], (m[2 * j] | fillw) & k0, lut_fp32, nobs, n1);
+            cw1[4 * h + j] = pack_codes4_lut(x[2 * j + 1], (m[2 * j + 1] | fillw) & k1, lut_fp32, nobs, n1);
+        }
+        pk[j] += (nobs | (n1 << 16)) << (8 * h);
         // (pinned here: hipcc otherwise sinks the whole pack to the end of the batch, and the next loads take new registers)
         asm volatile("" : "+v"(cw0[4 * h + j]), "+v"(cw1[4 * h + j]), "+v"(pk[j]));
+    };
+    auto pack_half = [&](const int bt, const int h, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4]) {
+        const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
+        if (need_in && left < R) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk);
+        }
     };
     // packed counts of the lane's 8 persons (both u-steps) -> 16-lane sums -> wl.cnt
     auto put_counts = [&](const int (&pk)[4], const bool real) {
@@ -389,9 +449,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     constexpr bool kPrs = RM == 2;
 #endif
     float prs0 = 0.f, prs1 = 0.f, prs2 = 0.f;
-    auto forward_slot = [&](auto extc, const long long bt, const int par, const int s, const float eps_c) {
+    // prior experts of the missing cells (models.py:613-620): weight 1 / (1 + eps) each, or dropped
+    const float prior_w = p.missing_mode == 0 ? 1.0f / (1.0f + kPoeEps) : 0.f;
+    const bool primary = EXTRA ? p.primary != 0 : true;
+    const float t_lo = kLoS * sc_dn, t_hi = kHiS * sc_dn;         // clamp bounds on the raw MFMA output (logit x 2^-ksh)
+    auto forward_slot = [&](auto extc, const int bt, const int par, const int s, const float eps_c) {
         constexpr bool EXT = decltype(extc)::value;
-        const long long row0 = bt * R;
+        static_assert(EXTRA || !EXT, "the global-memory variant belongs to the EXTRA instantiations");
+        const int row0 = bt * R;
         const int e = 64 * s + lane, pp = e >> 3;
         const bool live = ed < A && (row0 + pp) < p.B;
         int cnt = 0;
@@ -403,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
         if (!have_cnt) {
-            if (nw == 8) {
+            if constexpr (NW8) {
 #pragma unroll
                 for (int w = 0; w < 8; ++w) cnt += wls[w].cnt[pp];
             } else {
@@ -430,11 +495,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         }
-        if constexpr (!EXT && kPrs) {
+        if constexpr (EXTRA && !EXT && kPrs) {
             if (p.pre_stats) { lam = prs0; smu = prs1; nobs = prs2; }
         }
         const float nmiss = (float)p.I_total - nobs;
-        if (p.missing_mode == 0) lam += nmiss * (1.0f / (1.0f + kPoeEps));
+        lam = fmaf(nmiss, prior_w, lam);
         if (!live) lam = 1.0f;
         const float inv_lam = 1.0f / lam;
         const float amu = smu * inv_lam;
@@ -460,8 +525,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         }
-        if (live && p.primary) {
-            const long long o = (row0 + pp) * A + ed;
+        if (live && primary) {
+            const long long o = (long long)(row0 + pp) * A + ed;
             const float alv = -kLn2 * fast_log2(lam);
             p.ability_mu[o] = amu;
             p.ability_logvar[o] = alv;
@@ -483,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             cl.st[par][4][e] = __builtin_bit_cast(float, cnt);
         }
         _Float16 hi, lo;
-        split16(thv, hi, lo);
+        split16(fabsf(thv) <= 65504.f ? thv : __builtin_nanf(""), hi, lo);      // (beyond the f16 range: NaN, not a saturated piece)
         const int slot = 8 * ((pp & 15) >> 2) + 4 * (pp >> 4) + (pp & 3);
         cl.thA[0][pp][ed] = hi;
         cl.thA[1][pp][ed] = lo;
@@ -492,12 +557,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     };
     // backward of one slot through the sample and the product of experts; the 8 table-gradient sums of the wave's lanes
     // go to the wave's LDS record (fixed order: bitwise reproducible)
-    auto backward_slot = [&](const long long bt, const int par, const int s) {
-        const long long row0 = bt * R;
+    auto backward_slot = [&](const int bt, const int par, const int s) {
+        const int row0 = bt * R;
         const int e = 64 * s + lane, pp = e >> 3;
         const bool live = ed < A && (row0 + pp) < p.B;
         float g0 = 0.f;
-        if (nw == 8) {
+        if constexpr (NW8) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) g0 += wls[w].gth[par][pp][ed];
         } else {
@@ -509,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int cnt = __builtin_bit_cast(int, cl.st[par][4][e]);
         const float n1 = (float)(cnt >> 16), n0 = (float)(cnt & 0xffff) - n1;
         float thv = live ? amu + sig * eps_c : 0.f;
-        const bool reg_on = live && p.primary;
+        const bool reg_on = live && primary;
         float gz1 = 0.f;
         if constexpr (!FLOWS) {
             gz1 = (reg_on && p.reg_mode != 0) ? thv : 0.f;        // d REG / d theta_K (-log p)
@@ -566,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             glv[1] = gz1 * h - 0.5f;
         }
         if (!reg_on) { gmu[1] = 0.f; glv[1] = 0.f; }
-        if (p.post_coef) {
+        if (EXTRA && p.post_coef) {
             if (live) {
                 float* pc = p.post_coef + (size_t)(row0 + pp) * 4 * A;
 #pragma unroll
@@ -595,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     };
     // slots of this wave for a batch: [s0, s1) in steps of `step` (one slot at most with 4 or more waves)
     auto my_slots = [&](const int par, int& s0, int& s1, int& step) {
-        if (nw == 8) {
+        if (NW8 || nw == 8) {
             s0 = q - 4 * par; s1 = s0 + 1; step = 1;
             if (s0 < 0 || s0 > 3) s1 = s0 = 0;
         } else {
@@ -603,14 +668,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
     };
     float epn = 0.f;                                  // eps of this wave's slot of the next batch (4 or more waves), loaded a batch ahead
-    auto fetch_eps = [&](const long long bt, const int par) {
-        if (nw < 4 || bt >= n_batches) return;
+    auto fetch_eps = [&](const int bt, const int par) {
+        if ((!NW8 && nw < 4) || bt >= n_batches) return;
         int s0, s1, step;
         my_slots(par, s0, s1, step);
         if (s0 < s1) {
-            const long long row = bt * R + ((64 * s0 + lane) >> 3);
-            epn = (ed < A && row < p.B) ? p.eps[row * A + ed] : 0.f;
-            if constexpr (kPrs) {
+            const int row = bt * R + ((64 * s0 + lane) >> 3);
+            epn = (ed < A && row < p.B) ? p.eps[(long long)row * A + ed] : 0.f;
+            if constexpr (EXTRA && kPrs) {
                 if (p.pre_stats && p.pre_panels == 1) {
                     const bool lv = ed < A && row < p.B;
                     const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
@@ -619,24 +684,29 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
     };
-    auto person_forward = [&](const long long bt, const int par) {
+    auto person_forward = [&](const int bt, const int par) {
         int s0, s1, step;
         my_slots(par, s0, s1, step);
-        if (nw < 4 || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1))) {          // (wave-uniform)
+        if constexpr (EXTRA || !NW8) {
+            bool ext = nw < 4;                                   // (wave-uniform)
+            if constexpr (EXTRA) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));
+            if (ext) {
+                // (without the EXTRA hooks the plain variant serves the narrow workgroups too: eps is loaded here)
 #pragma unroll 1
-            for (int s = s0; s < s1; s += step) {
-                float eps_c = epn;
-                if (nw < 4) {
-                    const long long row = bt * R + ((64 * s + lane) >> 3);
-                    eps_c = (ed < A && row < p.B) ? p.eps[row * A + ed] : 0.f;
+                for (int s = s0; s < s1; s += step) {
+                    float eps_c = epn;
+                    if (nw < 4) {
+                        const int row = bt * R + ((64 * s + lane) >> 3);
+                        eps_c = (ed < A && row < p.B) ? p.eps[(long long)row * A + ed] : 0.f;
+                    }
+                    forward_slot(std::integral_constant<bool, EXTRA>{}, bt, par, s, eps_c);
                 }
-                forward_slot(std::true_type{}, bt, par, s, eps_c);
+                return;
             }
-        } else if (s0 < s1) {
-            forward_slot(std::false_type{}, bt, par, s0, epn);
         }
+        if (s0 < s1) forward_slot(std::false_type{}, bt, par, s0, epn);
     };
-    auto person_backward = [&](const long long bt, const int par) {
+    auto person_backward = [&](const int bt, const int par) {
         int s0, s1, step;
         my_slots(par, s0, s1, step);
 #pragma unroll 1
@@ -650,9 +720,13 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     half8 A1[2], B2;
     float wev[8], wod[8];                // code values of the even tile / of the odd tile that follows it
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto logits = [&](auto uc, auto tc, f32x4& d0, f32x4& d1) {
+    // item operand of the logit MFMAs of tile (u, t): read two tiles before its use (the LDS latency used to sit between
+    // the read and the MFMA at the top of every tile)
+    auto item_op = [&](auto uc, auto tc) {
         constexpr int u = decltype(uc)::value, t = decltype(tc)::value;
-        const half8 b1 = *reinterpret_cast<const half8*>(&wl.img[u][0] + b1ofs + t * kMsItemRow);
+        return *reinterpret_cast<const half8*>(&wl.img[u][0] + b1ofs + t * kMsItemRow);
+    };
+    auto logits = [&](const half8 b1, f32x4& d0, f32x4& d1) {
         d0 = mfma16(A1[0], b1, zero4);
         d1 = mfma16(A1[1], b1, zero4);
     };
@@ -677,7 +751,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             for (int mt = 0; mt < 2; ++mt) acc_gt[mt] = mfma16(ko.a3[hl][mt], ko.b3, acc_gt[mt]);
     };
     // tile (u, t) on the logits d0 | d1; n0 | n1 receive the next tile's logits
-    auto tile = [&](auto uc, auto tc, const f32x4 d0, const f32x4 d1, f32x4& n0, f32x4& n1, const uint32_t (&cw)[8]) {
+    // bop: item operand of the NEXT tile's logits (read earlier); bnx receives the operand of the tile after that
+    auto tile = [&](auto uc, auto tc, const f32x4 d0, const f32x4 d1, f32x4& n0, f32x4& n1, const uint32_t (&cw)[8],
+                    const half8 bop, half8& bnx) {
         constexpr int u = decltype(uc)::value, t = decltype(tc)::value;
         constexpr bool last = u == 1 && t == 3;
 #ifndef VIBO_MS_NO_PRIO
@@ -685,10 +761,22 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         // batch's barrier ~4 000 cycles early while the other finishes alone at a single wave's issue rate (phase timing:
         // 12.4 k vs 16.2 k cycles per batch).  Swapping the leader every tile keeps the pair within a tile of each other.
         // (A/B on one box, ability_dim 8: 1.053 ms against 1.076 without; swapping every half tile 1.071, every two tiles 1.065)
-        if ((((u * 4 + t) & 1) != 0) == ((q & 4) != 0)) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
+        // (s_setprio takes an immediate: set one value, skip the other for half of the waves -- one short forward branch)
+#ifdef VIBO_MS_PRIO_SWAP
+        if constexpr (((u * 4 + t) & 1) == 0)
+#else
+        if constexpr (((u * 4 + t) & 1) != 0)
 #endif
-        if constexpr (!last) logits(std::integral_constant<int, (t < 3 ? u : 1)>{}, std::integral_constant<int, (t < 3 ? t + 1 : 0)>{}, n0, n1);
+            asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio 0\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio 1\n.Lmsprio%=:" :: "s"(q) : "scc");
+        else
+            asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio 1\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio 0\n.Lmsprio%=:" :: "s"(q) : "scc");
+#endif
+        if constexpr (!last) logits(bop, n0, n1);
+        // (tile (u, t) reads the operand of tile + 2; the batch's last two tiles read those of the next batch's first two)
+        {
+            constexpr int lin = (u * 4 + t + 2) & 7;
+            bnx = item_op(std::integral_constant<int, (lin >> 2)>{}, std::integral_constant<int, (lin & 3)>{});
+        }
         // K-tile whose pieces were completed by the previous tile: (u, 0) at t = 2, (0, 1) at (1, 0)
         constexpr bool pend = GRAD && (t == 2 || (u == 1 && t == 0));
         const float lg[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
@@ -709,17 +797,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             // The reference's probability clamp (utils.py:46-49 -> torch) only matters for |logit| > 15.94: value capped at
             // +-kLogitLo, gradient exactly zero outside [-kLogitLo, kLogitHi] -- a wave-uniform slow path; everywhere else the
             // plain formula is the reference's.
-            float tt[8];
+            // The tile's largest |logit| by four 3-input maxima (hipcc's own lowering of the fmaxf chain took six instructions),
+            // the plain formula for all cells first, and ONE branch to the slow path that overrides it.
+            // (the maxima read the exponents u = -w l, not the logits: the MFMA -> VALU wait states are the compiler's business
+            //  -- it knows nothing about registers read inside an asm statement -- and a missing cell, u = 0, never triggers)
+            float tt[8], uu[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) tt[k] = 1.0f + fast_exp2(wc[k] * lg[k]);
-            float lmax = fmaxf(fmaxf(fabsf(lg[0]), fabsf(lg[1])), fabsf(lg[2]));
-            lmax = fmaxf(fmaxf(lmax, fabsf(lg[3])), fabsf(lg[4]));
-            lmax = fmaxf(fmaxf(lmax, fabsf(lg[5])), fabsf(lg[6]));
-            lmax = fmaxf(lmax, fabsf(lg[7]));
-            const bool rare = __any(!(lmax <= kLoS));                   // (NaN-safe)
-            if (rare) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) tt[k] = 1.0f + fast_exp2(wc[k] * med3(lg[k], -kLoS, kLoS));
+            for (int k = 0; k < 8; ++k) {
+                uu[k] = wc[k] * lg[k];
+                tt[k] = 1.0f + fast_exp2(uu[k]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -727,10 +813,25 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 pr *= tt[k];                                          // <= (1 + 2^23)^4: one log2 per 4 terms
                 if constexpr (GRAD) gl[k] = fmaf(wc[k], fast_rcp(tt[k]), -wc[k]);
             }
-            if constexpr (GRAD) {
-                if (rare) {
+#ifdef VIBO_MS_PRODCHK
+            // (A/B only: "some e > 2^23" from the products -- misses the likely-side band where the reference's gradient is an exact 0)
+            float lmax = fmaxf(pr0, pr1) < 8388608.0f ? 0.f : 1e30f;
+#else
+            float lmax;
+            asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(lmax) : "v"(uu[0]), "v"(uu[1]), "v"(uu[2]));
+            asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(lmax) : "v"(lmax), "v"(uu[3]), "v"(uu[4]));
+            asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(lmax) : "v"(lmax), "v"(uu[5]), "v"(uu[6]));
+            asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(lmax) : "v"(lmax), "v"(uu[7]));
+#endif
+            if (__any(!(lmax <= kLoS))) {                              // (wave-uniform, rare)
+                pr0 = pr1 = 1.0f;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) gl[k] = (lg[k] < -kLoS || lg[k] > kHiS) ? 0.f : gl[k];
+                for (int k = 0; k < 8; ++k) {
+                    float& pr = (k & 1) ? pr1 : pr0;
+                    // (lg = logit x 2^-ksh, wc = -w 2^ksh: the clamp bounds on lg scale with it)
+                    const float tk = 1.0f + fast_exp2(wc[k] * med3(lg[k], -t_lo, t_lo));
+                    pr *= tk;
+                    if constexpr (GRAD) gl[k] = (lg[k] < -t_lo || lg[k] > t_hi) ? 0.f : fmaf(wc[k], fast_rcp(tk), -wc[k]);
                 }
             }
         } else {
@@ -740,7 +841,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 float& pr = (k & 1) ? pr1 : pr0;
                 gl[k] = 0.f;
                 // 3PL: p = guess + (1 - guess) sigmoid(l)  (models.py:758-765), probability clamp on p itself
-                const float l = lg[k];
+                const float l = lg[k] * sc_up;
                 const float ee = fast_exp2(-fabsf(l));
                 const float rr_ = fast_rcp(1.0f + ee);
                 const float er_ = ee * rr_;
@@ -823,10 +924,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     };
 
     // ================= prologue: first batch =================
-    long long bt = blockIdx.x;
+    int bt = (int)blockIdx.x;
     uint32_t cwA0[8], cwA1[8], cwB0[8], cwB1[8];
     int pk[4];
-    const long long G = gridDim.x;
+    const int G = (int)gridDim.x;
     if (bt < n_batches) {
         fetch_idx(bt);
 #pragma unroll
@@ -837,22 +938,25 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) load_quarter(bt, s0, h, j);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pack_quarter(bt, h, j, cwA0, cwA1, pk);
+                pack_half(bt, h, cwA0, cwA1, pk);
             }
         }
         put_counts(pk, true);
         fetch_eps(bt, 0);
         asm volatile("" : "+v"(epn));                 // (in before the loop: no wait on it behind the loop's own loads)
-        if constexpr (kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
+        if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
     }
     int par = 0;                                      // parity of the workgroup's batch counter: LDS double buffers, slot owners
+    // item operands of the first two tiles' logits (every batch reads the same image: carried across the back edge)
+    half8 bopA = item_op(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    half8 bopB = item_op(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
 #ifdef VIBO_MS_TIMING
     long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (long long)__builtin_readcyclecounter();
 #endif
-    // One iteration = [request the first half of the next batch's rows] [sync phase of this batch: counts -> theta]
-    // [backward of the previous batch] [math of this batch, with the next batch's rows packed / requested under it].
+    // One iteration = [request the first half of the next batch's rows] [sync phase of this batch: counts -> theta, with the
+    // backward of the previous batch in the waves that have no forward slot] [math of this batch, with the next batch's rows
+    // packed / requested under it].
     // The rows travel in two halves (M-tile 0, M-tile 1), each requested at least four tiles before it is packed; the first
     // goes out right before the sync phase (the texture pipeline digests the workgroup's 128 load instructions while the
     // waves sit in the barriers; issued after them, with all 8 waves in step, every wave stalled ~5000 cycles on it).
@@ -862,22 +966,20 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // copies them at the back edge behind an s_waitcnt vmcnt(0), which serialises the prefetch.  The sched_barriers keep
     // the loads behind the pack that frees their registers.
     for (; bt < n_batches; bt += G, par ^= 1) {
-        const long long nxt = bt + G;
+        const int nxt = bt + G;
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = 0;
         fetch_idx(nxt);
+        const RowSrc sn = row_src(nxt);
         auto burst_a = [&]() {
-            const RowSrc sn = row_src(nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 0, j);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto pack_a_burst_b = [&]() {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(nxt, 0, j, cwB0, cwB1, pk);
+            pack_half(nxt, 0, cwB0, cwB1, pk);
             fetch_eps(nxt, par ^ 1);                  // (complete by the second pack: free to carry across the back edge)
-            const RowSrc sn = row_src(nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 1, j);
@@ -889,32 +991,40 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         MS_T(5)
         person_forward(bt, par);                      // short: counts -> theta operands (eps came a batch ahead)
         MS_T(6)
+        if constexpr (GRAD && NW8) {
+            // 8 waves: the four waves without a forward slot in this batch own the backward slots of the previous one -- they
+            // run it here, while the others compute theta, instead of after the second barrier (where it delayed their math
+            // by ~1 000 cycles and the whole workgroup at the next barrier)
+            if (bt >= G + (int)blockIdx.x) person_backward(bt - G, par ^ 1);
+        }
+        MS_T(9)
         __syncthreads();
         MS_T(7)
         read_theta_ops();
         MS_T(8)
-        if constexpr (GRAD) {
-            if (bt >= G + (long long)blockIdx.x) person_backward(bt - G, par ^ 1);   // nobody waits for this
+        if constexpr (GRAD && !NW8) {
+            if (bt >= G + (int)blockIdx.x) person_backward(bt - G, par ^ 1);   // nobody waits for this
         }
-        MS_T(9)
         f32x4 da0, da1, db0, db1;
-        logits(IC0{}, IC0{}, da0, da1);
-        tile(IC0{}, IC0{}, da0, da1, db0, db1, cwA0);
-        tile(IC0{}, IC1{}, db0, db1, da0, da1, cwA0);
-        tile(IC0{}, IC2{}, da0, da1, db0, db1, cwA0);
-        tile(IC0{}, IC3{}, db0, db1, da0, da1, cwA0);
+        logits(bopA, da0, da1);
+        tile(IC0{}, IC0{}, da0, da1, db0, db1, cwA0, bopB, bopA);     // (reads the operand of (0, 2) into bopA, ...)
+        tile(IC0{}, IC1{}, db0, db1, da0, da1, cwA0, bopA, bopB);
+        tile(IC0{}, IC2{}, da0, da1, db0, db1, cwA0, bopB, bopA);
+        tile(IC0{}, IC3{}, db0, db1, da0, da1, cwA0, bopA, bopB);
         MS_T(0)
         pack_a_burst_b();
         MS_T(1)
-        tile(IC1{}, IC0{}, da0, da1, db0, db1, cwA1);
-        tile(IC1{}, IC1{}, db0, db1, da0, da1, cwA1);
-        tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1);
-        tile(IC1{}, IC3{}, db0, db1, da0, da1, cwA1);
+        tile(IC1{}, IC0{}, da0, da1, db0, db1, cwA1, bopB, bopA);
+        tile(IC1{}, IC1{}, db0, db1, da0, da1, cwA1, bopA, bopB);
+        tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1, bopB, bopA);     // (... of the next batch's (0, 0) into bopA)
+        tile(IC1{}, IC3{}, db0, db1, da0, da1, cwA1, bopA, bopB);     // (not used: last; reads (0, 1) into bopB)
         MS_T(2)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pack_quarter(nxt, 1, j, cwB0, cwB1, pk);
+#ifdef VIBO_MS_PRIO_RESET
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        pack_half(nxt, 1, cwB0, cwB1, pk);
         asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
-        if constexpr (kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
+        if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
         MS_T(3)
         put_counts(pk, nxt < n_batches);
         if constexpr (GRAD) put_gtheta(par);
@@ -924,7 +1034,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     if constexpr (GRAD) {
         // backward of the workgroup's last batch
         __syncthreads();
-        if (bt >= G + (long long)blockIdx.x) person_backward(bt - G, par ^ 1);
+        if (bt >= G + (int)blockIdx.x) person_backward(bt - G, par ^ 1);
     }
 
 #ifdef VIBO_MS_TIMING
@@ -987,7 +1097,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 if constexpr (IRT != 1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = acc_ga[u][t][j] + dpp_f<0x128>(acc_ga[u][t][j]);
+                        const float v = (acc_ga[u][t][j] + dpp_f<0x128>(acc_ga[u][t][j])) * sc_dn;
                         const int il = kMsSpan * q + 64 * u + 4 * (4 * g + j) + t;
                         if (i16 < A && il < I) out[p.lay.off_item + (size_t)i16 * p.lay.i_pad + il] = -v;
                     }
@@ -998,29 +1108,38 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 b += __shfl_xor(b, 32);
                 const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
                 const int brow = IRT == 1 ? 0 : A;
-                if (g == 0 && il < I) out[p.lay.off_item + (size_t)brow * p.lay.i_pad + il] = b;
+                if (g == 0 && il < I) out[p.lay.off_item + (size_t)brow * p.lay.i_pad + il] = b * sc_dn;
                 if constexpr (IRT == 3) {
                     float gg = acc_g[u][t];
                     gg += __shfl_xor(gg, 16);
                     gg += __shfl_xor(gg, 32);
-                    if (g == 0 && il < I) out[p.lay.off_item + (size_t)(A + 1) * p.lay.i_pad + il] = gg;
+                    if (g == 0 && il < I) out[p.lay.off_item + (size_t)(A + 1) * p.lay.i_pad + il] = gg * sc_dn;
                 }
             }
     }
 }
 
-template <int IRT, bool GRAD, int RM, bool FLOWS>
-static hipError_t launch_msplit_one(const ElboParams& p, int nw, int grid, hipStream_t s) {
+template <int IRT, bool GRAD, int RM, bool FLOWS, bool NW8, bool EXTRA>
+static hipError_t launch_msplit_inst(const ElboParams& p, int nw, int grid, hipStream_t s) {
     // more than 64 KB of dynamic LDS has to be opted into (once per kernel; gfx950 has 160 KB per CU)
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msplit_kernel<IRT, GRAD, RM, FLOWS>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msplit_kernel<IRT, GRAD, RM, FLOWS, NW8, EXTRA>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)msplit_lds_bytes(8, FLOWS));
         if (e != hipSuccess) return e;
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM, FLOWS>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw, FLOWS), s, p);
+    hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM, FLOWS, NW8, EXTRA>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw, FLOWS), s, p);
     return hipGetLastError();
+}
+template <int IRT, bool GRAD, int RM, bool FLOWS>
+static hipError_t launch_msplit_one(const ElboParams& p, int nw, int grid, hipStream_t s) {
+    // EXTRA: the panel / conditional / given hooks (see the kernel); NW8: exactly 8 waves per workgroup
+    const bool extra = p.row_cnt || p.pre_stats || p.post_coef || !p.primary;
+    if (nw == 8) return extra ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, true>(p, nw, grid, s)
+                              : launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, false>(p, nw, grid, s);
+    return extra ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, true>(p, nw, grid, s)
+                 : launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, false>(p, nw, grid, s);
 }
 template <int RM, bool FLOWS>
 static hipError_t launch_msplit_rm(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s) {

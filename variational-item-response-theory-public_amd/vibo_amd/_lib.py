@@ -6,7 +6,7 @@ missing or a call fails, this module raises.
 import ctypes
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_SCALARS = 8
 S_LL, S_REG, S_KL, S_LOGQ0, S_LOGP, S_LADJ, S_NOBS = 0, 1, 2, 3, 4, 5, 6
 
@@ -15,6 +15,9 @@ POSTERIOR_UNCONDITIONAL, POSTERIOR_CONDITIONAL, POSTERIOR_GIVEN = 0, 1, 2
 MISSING_PRIOR, MISSING_DROP = 0, 1
 MASK_U8, MASK_I64, MASK_NONE, MASK_CODES = 0, 1, 2, 3
 REG_KL, REG_SAMPLED = 0, 1
+FLAG_KERNEL_VALU, FLAG_KERNEL_MATRIX, FLAG_NO_EMIT_CODES = 1, 2, 4
+KERNEL_NAMES = {1: 'matrix row-split (msplit_kernel)', 2: 'VALU row-split (split_kernel)', 3: 'wave-per-row', 4: 'tiled',
+                5: 'wave-per-person'}
 MAX_ABILITY_DIM = 8
 MAX_FLOWS = 8
 
@@ -40,6 +43,8 @@ class ViboDesc(ctypes.Structure):
         ('deterministic', ctypes.c_int32),
         ('response_row_stride', ctypes.c_int64),
         ('mask_row_stride', ctypes.c_int64),
+        ('flags', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
     ]
 
 
@@ -57,7 +62,7 @@ class ViboDecoderDesc(ctypes.Structure):
     ]
 
 
-EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes',
+EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes', 'vibo_plan_kernel',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
                     'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise',
@@ -89,6 +94,8 @@ def load():
     lib.vibo_last_error_string.argtypes = []
     lib.vibo_workspace_bytes.restype = ctypes.c_size_t
     lib.vibo_workspace_bytes.argtypes = [dp]
+    lib.vibo_plan_kernel.restype = ctypes.c_int
+    lib.vibo_plan_kernel.argtypes = [dp]
     lib.vibo_elbo_fwd_bwd.restype = ctypes.c_int
     lib.vibo_elbo_fwd_bwd.argtypes = [dp, fp, vp, i64p, fp, fp, fp, fp,      # inputs
                                       fp, fp, fp, fp, fp, fp,                # scalars + posterior outputs

@@ -211,8 +211,24 @@ def prepare_response(response):
     return response
 
 
+# vibo_desc.flags of every descriptor this module builds (_lib.FLAG_*): 0 = the planner chooses.  Tests and A/B tools
+# pin one row-split kernel here; the library itself reads no environment variable.
+DESC_FLAGS = 0
+
+
+def plan_kernel(spec, num_person, num_item, mask_code=_lib.MASK_U8, want_grad=True):
+    """Name of the fused kernel the planner picks for a call of this shape (vibo_plan_kernel)."""
+    d = _make_desc(spec, num_person, num_item, mask_code, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, want_grad,
+                   (num_item + 3) & ~3, (num_item + 3) & ~3)
+    k = _lib.load().vibo_plan_kernel(ctypes.byref(d))
+    if k < 0:
+        _lib.check(k, 'vibo_plan_kernel')
+    return _lib.KERNEL_NAMES[k]
+
+
 def _make_desc(spec, B, I, mask_code, reg_mode, want_grad, resp_stride, mask_stride):
     d = _lib.ViboDesc()
+    d.flags = DESC_FLAGS
     d.abi_version = _lib.ABI_VERSION
     d.num_person = B
     d.num_item = I
