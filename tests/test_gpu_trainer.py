@@ -337,3 +337,153 @@ def test_graphed_module_step_follows_the_eager_module_step(cls, kw):
     assert step3.graph is not None
     for (k, a), (_, b) in zip(m3.state_dict().items(), m4.state_dict().items()):
         assert (a - b).abs().max() < 1e-4 * max(1.0, float(b.abs().max())), k
+
+
+@pytest.mark.gpu
+def test_graphed_module_step_survives_the_epochs_short_last_minibatch():
+    """num_person % batch_size != 0: the epoch's last, shorter minibatch runs eagerly between the replays.  Its zero_grad
+    must not free the gradient buffers the captured graph was recorded with (set_to_none=True there was a
+    use-after-free -- later replays wrote their gradients into memory the allocator had handed to someone else)."""
+    import copy
+    from vibo_amd.torch_core.vibo import GraphedModuleStep
+
+    class Data:
+        pass
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    P, I, A, B = 672, 120, 2, 64                       # 10 full minibatches + one of 32 rows
+    resp, mask = O.simulate_responses(2, P, I, A, generator=g, missing_frac=0.1)
+    data = Data()
+    data.response, data.mask, data.device = resp.to(dev), mask.bool().to(dev), dev
+    torch.manual_seed(2)
+    m1 = VIBO_2PL(A, I, ability_merge='product', conditional_posterior=True).to(dev)
+    m2 = copy.deepcopy(m1)
+    o1 = torch.optim.Adam(m1.parameters(), lr=5e-3, capturable=True)
+    o2 = torch.optim.Adam(m2.parameters(), lr=5e-3)
+    step = GraphedModuleStep(m1, o1, data, B)
+    order = torch.arange(P, device=dev)
+    it = 0
+    for epoch in range(3):
+        for s0 in range(0, P, B):
+            rows = order[s0:s0 + B]
+            with torch.no_grad():
+                for p1, p2 in zip(m1.parameters(), m2.parameters()):
+                    p1.copy_(p2)
+            torch.manual_seed(90 + it)
+            l1 = step(rows, 1.0)
+            if rows.numel() != B:
+                assert step.graph is not None
+                grads = [p.grad.data_ptr() for p in m1.parameters()]
+                junk = [torch.randn(64, device=dev) for _ in range(64)]      # would land in freed gradient buffers
+            torch.manual_seed(90 + it)
+            o2.zero_grad()
+            l2 = m2.elbo_step(data.response, data.mask, annealing_factor=1.0, row_index=rows)
+            l2.backward()
+            assert abs(float(l1.detach()) - float(l2.detach())) < 1e-5 * abs(float(l2.detach())), it
+            for (k, p1), p2 in zip(m1.named_parameters(), m2.parameters()):
+                assert float((p1.grad - p2.grad).abs().max()) <= 1e-4 * float(p2.grad.abs().max()) + 1e-6, (it, k)
+            o2.step()
+            it += 1
+    assert [p.grad.data_ptr() for p in m1.parameters()] == grads
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cls,A,I,B,beta,kw', [
+    (VIBO_2PL, 1, 200, 130, 0.7, dict(conditional_posterior=True)),
+    (VIBO_2PL, 2, 1000, 64, 1.0, dict(conditional_posterior=True)),
+    (VIBO_3PL, 1, 120, 77, 1.0, dict(conditional_posterior=True, n_norm_flows=4)),          # BASELINE configs[4]'s flag set
+    (VIBO_2PL, 3, 95, 50, 1.0, dict(n_norm_flows=2)),
+    (VIBO_1PL, 2, 64, 40, 0.5, dict(conditional_posterior=True)),
+    # (wide ability + flows: 2PL.  With 3PL at ability_dim 8 a few cells sit exactly on 3PL's probability clamp (models.py:758-765
+    #  -> utils.py:46-49) and flip with the last bit of the expert table -- a few % of the encoder gradient in the reference's
+    #  own arithmetic, tools/scratch/dbg_ct.py; 3PL is covered at ability_dim 1 and 2)
+    (VIBO_2PL, 8, 1100, 48, 1.0, dict(conditional_posterior=True, n_norm_flows=2)),          # panels + wide ability
+    (VIBO_2PL, 8, 200, 48, 1.0, dict(conditional_posterior=True, n_norm_flows=2)),
+    (VIBO_3PL, 2, 200, 48, 1.0, dict(conditional_posterior=True, n_norm_flows=2)),
+    (VIBO_2PL, 2, 1100, 48, 1.0, dict(conditional_posterior=True)),
+    (VIBO_2PL, 8, 300, 48, 1.0, dict(conditional_posterior=True)),
+    (VIBO_2PL, 8, 300, 48, 1.0, dict(n_norm_flows=3)),
+    (VIBO_2PL, 2, 130, 60, 1.0, dict(conditional_posterior=True, hidden_dim=32)),
+])
+def test_fused_cond_flow_trainer_matches_torch_adam(cls, A, I, B, beta, kw):
+    """FusedTrainer on --conditional-posterior / --n-norm-flows models (FusedCondFlowTrainer: vibo_ctrain_prologue, the ELBO
+    kernel, vibo_ctrain_epilogue -- no autograd) follows module + autograd + torch.optim.Adam: same seeds -> the same noise
+    (rng='torch'), so losses and every parameter must agree after several steps.  Reference loop: vibo.py:243-268."""
+    dev = torch.device('cuda:0')
+    irt = cls.IRT
+    g = torch.Generator().manual_seed(A * 100 + I)
+    resp, mask = O.simulate_responses(irt, B, I, A, generator=g, missing_frac=0.15)
+    resp, mask = resp.to(dev), mask.bool().to(dev)
+    kw = dict(kw)
+    torch.manual_seed(kw.pop('_seed', 3))
+    ref = cls(A, I, ability_merge='product', **kw).to(dev)
+    fus = copy.deepcopy(ref)
+    opt = torch.optim.Adam(ref.parameters(), lr=5e-3)
+    trainer = FusedTrainer(fus, lr=5e-3)
+    assert type(trainer).__name__ == 'FusedCondFlowTrainer'
+    assert list(fus.state_dict().keys()) == list(ref.state_dict().keys())
+    for step in range(4):
+        torch.manual_seed(100 + step)
+        opt.zero_grad()
+        loss_ref = ref.elbo_step(resp, mask, annealing_factor=beta)
+        loss_ref.backward()
+        if step == 0:
+            g_ref = {k: p.grad.clone() for k, p in ref.named_parameters()}
+            p_before = {k: p.detach().clone() for k, p in ref.named_parameters()}
+        opt.step()
+        torch.manual_seed(100 + step)
+        loss_fus = trainer.step(resp, mask, beta=beta)
+        assert abs(float(loss_fus) - float(loss_ref.detach())) < 3e-5 * abs(float(loss_ref.detach())), step
+        if step == 0:
+            # Adam's first step moves every parameter by lr * sign(g) (up to eps / |g|): a wrong gradient SIGN anywhere shows
+            # as a 2 lr difference -- checked per tensor so that a failure names the parameter
+            # (entries whose gradient is below 1e-3 of the tensor's largest are left out: their sign is the summation order's)
+            for (k, a), (_, b) in zip(ref.named_parameters(), fus.named_parameters()):
+                big = g_ref[k].abs() > 1e-3 * g_ref[k].abs().max()
+                diff = (a.detach() - b.detach()).abs()
+                assert (diff[big] < 1e-4).all(), (k, float(diff.max()), int((diff[big] >= 1e-4).sum()), int(big.sum()))
+                assert float((diff >= 1e-4).float().mean()) < 0.02, (k, 'more than 2 % of the entries moved the other way')
+    for (k, a), (_, b) in zip(ref.state_dict().items(), fus.state_dict().items()):
+        assert (a - b).abs().max() < 2e-4, (k, float((a - b).abs().max()))
+    assert int(trainer.step_count) == 4
+
+
+@pytest.mark.gpu
+def test_fused_cond_flow_trainer_replays_bitwise_from_a_hipgraph():
+    """The conditional + flows step (BASELINE configs[4]'s flag set) captured once and replayed: bitwise the parameters of the
+    same steps launched eagerly (native noise: the counters live on the device), 200 replays -- the captured autograd step
+    this replaces went wrong after a dozen replays on the same stack."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    P, I, A, B = 512, 1000, 1, 16
+    resp, mask = O.simulate_responses(3, P, I, A, generator=g, missing_frac=0.1)
+    resp, mask = resp.to(dev), mask.bool().to(dev)
+    torch.manual_seed(4)
+    m1 = VIBO_3PL(A, I, ability_merge='product', conditional_posterior=True, n_norm_flows=4).to(dev)
+    m2 = copy.deepcopy(m1)
+    t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=9)
+    t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=9)
+    rows = torch.zeros(B, dtype=torch.int64, device=dev)
+    perm = torch.randperm(P, generator=g).to(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for it in range(3):
+            rows.copy_(perm[it * B:(it + 1) * B])
+            t1.step(resp, mask, row_index=rows)
+            t2.step(resp, mask, row_index=rows)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        t1.step(resp, mask, row_index=rows)
+    t2.step(resp, mask, row_index=rows)                    # (the capture ran step 4 once for t1 as well? no: capture records only)
+    gr.replay()
+    for it in range(4, 204):
+        rows.copy_(perm[(it * B) % P:(it * B) % P + B])
+        gr.replay()
+        t2.step(resp, mask, row_index=rows)
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.isfinite(a).all(), k
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))

@@ -11,7 +11,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 for p in (ROOT, os.path.join(ROOT, 'variational-item-response-theory-public_amd')):
     sys.path.insert(0, p)
 import torch
-from vibo_amd.torch_core.models import VIBO_2PL
+from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
 from vibo_amd.trainer import FusedTrainer
 
 ap = argparse.ArgumentParser()
@@ -20,6 +20,9 @@ ap.add_argument('--batch', type=int, default=16)
 ap.add_argument('--items', type=int, default=100)
 ap.add_argument('--ability-dim', type=int, default=1)
 ap.add_argument('--persons', type=int, default=8000)
+ap.add_argument('--irt', type=int, default=2)
+ap.add_argument('--cond', action='store_true', help='--conditional-posterior (FusedCondFlowTrainer)')
+ap.add_argument('--flows', type=int, default=0, help='--n-norm-flows')
 a = ap.parse_args()
 d = torch.device('cuda:0')
 g = torch.Generator(device=d).manual_seed(0)
@@ -27,7 +30,7 @@ P, I, A, B = a.persons, a.items, a.ability_dim, a.batch
 resp = (torch.rand(P, I, device=d, generator=g) < 0.5).float()
 mask = torch.rand(P, I, device=d, generator=g) >= 0.1
 torch.manual_seed(1)
-m1 = VIBO_2PL(A, I, ability_merge='product').to(d)
+m1 = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[a.irt](A, I, ability_merge='product', conditional_posterior=a.cond, n_norm_flows=a.flows).to(d)
 m2 = copy.deepcopy(m1)
 t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=7)
 t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=7)

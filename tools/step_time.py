@@ -56,3 +56,33 @@ for mode in ('eager', 'graph'):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f'irt={a.irt} I={I} A={A} B={B} cond={a.cond} flows={a.flows} merge={a.merge} {mode:6s}: {dt * 1e6:9.1f} us/step  loss {float(loss):.1f}')
+
+# the same configuration through the fused trainer (FusedTrainer / FusedCondFlowTrainer), eager and replayed
+from vibo_amd.trainer import FusedTrainer, fused_trainer_covers
+torch.manual_seed(0)
+model = cls(A, I, ability_merge=a.merge, conditional_posterior=a.cond, n_norm_flows=a.flows).to(d)
+if fused_trainer_covers(model):
+    tr = FusedTrainer(model, lr=5e-3, rng='native', seed=3)
+    rbuf = torch.zeros(B, dtype=torch.int64, device=d)
+    rows = [torch.randperm(P, device=d)[:B].contiguous() for _ in range(8)]
+    for k in range(4):
+        rbuf.copy_(rows[k]); tr.step(data.response, data.mask, row_index=rbuf)
+    torch.cuda.synchronize()
+    n = 200
+    t0 = time.perf_counter()
+    for k in range(n):
+        rbuf.copy_(rows[k % 8]); loss = tr.step(data.response, data.mask, row_index=rbuf)
+    torch.cuda.synchronize()
+    print(f'fused trainer ({type(tr).__name__}) eager : {(time.perf_counter() - t0) / n * 1e6:9.1f} us/step  loss {float(loss):.1f}')
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        loss = tr.step(data.response, data.mask, row_index=rbuf)
+    for k in range(5):
+        gr.replay()
+    torch.cuda.synchronize()
+    n = 1000
+    t0 = time.perf_counter()
+    for k in range(n):
+        rbuf.copy_(rows[k % 8]); gr.replay()
+    torch.cuda.synchronize()
+    print(f'fused trainer ({type(tr).__name__}) graph : {(time.perf_counter() - t0) / n * 1e6:9.1f} us/step  loss {float(loss):.1f}')

@@ -131,6 +131,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     constexpr bool CODES = RM == 2;
     constexpr int R = kMsRows;
     constexpr float kLoS = kLogitLo * kLog2e, kHiS = kLogitHi * kLog2e;
+    // fp8 (e4m3) look-up tables of the pack.  fp32 rows: selector {missing, wrong, -, right}; cell codes: {wrong, right, missing}.
+    // 1PL/2PL carry -w (the exponent is -w x logit: one VOP2 multiply), 3PL +w.
+    constexpr uint32_t kLutFp32 = IRT != 3 ? 0xB8003800u : 0x3800B800u;
+    constexpr uint32_t kLutCode = IRT != 3 ? 0x0000B838u : 0x000038B8u;
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_smem[];
     MsCommonLds& cl = *reinterpret_cast<MsCommonLds*>(ms_smem);
     MsWaveLds* wls = reinterpret_cast<MsWaveLds*>(ms_smem + sizeof(MsCommonLds));
@@ -185,17 +189,20 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     //   d LL/d theta MFMA, (u, kt): lane (col i16, g) gets k = 8 g + kk <-> item (chunk 4 g + (kk & 3), t = 2 kt + (kk >> 2)) by two
     //   transposed reads of the [na_hi | na_lo] rows
     //
-    // Range of the f16 pieces: an operand above 65 504 would saturate its hi piece.  The launch's largest |na|, |nb| decides
-    // a power of two 2^ksh (ksh = 0 whenever everything is below 2^15, i.e. for any sane item parameters; up to 8): the image
-    // holds the operands times 2^-ksh (exact), the MFMA returns logit x 2^-ksh, and the cells' fp8 codes carry -w 2^ksh
-    // instead of -w (the byte look-up of the pack: free), so the exponent -w l is exact and the hot path has not one
-    // instruction more.  What changes with ksh > 0: d ll/d l comes out times 2^ksh -- d LL/d theta = sum g a is then
-    // already right, d LL/d a, d b, d guess are scaled back once in the epilogue -- and the clamp thresholds on the raw
-    // MFMA output scale with it.  Operands beyond 2^23 (or a sample |theta| > 65 504) turn the results into NaN rather
-    // than into silently wrong numbers; VIBO_FLAG_KERNEL_VALU runs such inputs on the fp32 VALU kernel.
+    // Range of the f16 pieces.  A two-piece f16 value carries an ABSOLUTE error of ~2^-24 once its lo piece is subnormal
+    // (|x| < 2^-3), and saturates above 65 504.  Two per-launch powers of two keep the operands where the split is good
+    // for any item parameters -- at no cost in the hot path (the cells' codes stay +-1, the logits come out unscaled):
+    //   * theta <-> a balance 2^jsh: the image holds a 2^jsh, the (person, dim) lanes hand over theta 2^-jsh; jsh =
+    //     -floor(exponent(max |a|) / 2), i.e. both sides near sqrt(|a theta|) (discriminations of 1e-4 or 1e6 alike).
+    //     d LL/d theta = sum g a comes out times 2^jsh, d LL/d a = sum g theta times 2^-jsh: undone for free in the
+    //     backward's existing scale factor and once in the epilogue;
+    //   * difficulties: the three bias pieces hold b 2^-bsh and the "1" entries of the logit MFMA's A operand 2^bsh
+    //     (bsh = 0 below 2^15).
+    // Beyond that (|b| > 2^30, or a sample with |theta 2^-jsh| > 65 504) the results turn into NaN rather than into
+    // silently wrong numbers; VIBO_FLAG_KERNEL_VALU runs such inputs on the fp32 VALU kernel.
     float gs[2][4], om[2][4];           // 3PL: guess, 1 - guess of the lane's items
     float na_raw[2][8], nb_raw[2];
-    float amax = 0.f;
+    float amax = 0.f, bmax = 0.f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int xl = 64 * h + lane;                                   // item of the wave, one per lane and pass
@@ -207,36 +214,37 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             float na = 0.f;
             if (ok && kk < A) na = IRT == 1 ? kLog2e : -ir[kk] * kLog2e;      // models.py:731 / 744,759
             na_raw[h][kk] = na;
-            amax = fmaxf(amax, fabsf(na));
+            amax = !(fabsf(na) <= 3.0e38f) ? 3.0e38f : fmaxf(amax, fabsf(na));       // (NaN / Inf: "too large", sticky)
         }
         nb_raw[h] = ok ? ir[IRT == 1 ? 0 : A] * kLog2e : 0.f;
-        amax = fmaxf(amax, fabsf(nb_raw[h]));
+        bmax = !(fabsf(nb_raw[h]) <= 3.0e38f) ? 3.0e38f : fmaxf(bmax, fabsf(nb_raw[h]));
     }
     {
-        // workgroup maximum (NaN / Inf operands count as "too large": the results become NaN below)
-        float mx = (amax <= 3.0e38f) ? amax : 3.0e38f;
-        mx = fmaxf(mx, dpp_f<0xb1>(mx)); mx = fmaxf(mx, dpp_f<0x4e>(mx));
-        mx = fmaxf(mx, dpp_f<0x124>(mx)); mx = fmaxf(mx, dpp_f<0x128>(mx));
-        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (lane == 0) wl.red[1] = mx;
+        // workgroup maxima
+        float ma = amax, mb = bmax;
+        ma = fmaxf(ma, dpp_f<0xb1>(ma)); ma = fmaxf(ma, dpp_f<0x4e>(ma));
+        ma = fmaxf(ma, dpp_f<0x124>(ma)); ma = fmaxf(ma, dpp_f<0x128>(ma));
+        ma = fmaxf(ma, __shfl_xor(ma, 16)); ma = fmaxf(ma, __shfl_xor(ma, 32));
+        mb = fmaxf(mb, dpp_f<0xb1>(mb)); mb = fmaxf(mb, dpp_f<0x4e>(mb));
+        mb = fmaxf(mb, dpp_f<0x124>(mb)); mb = fmaxf(mb, dpp_f<0x128>(mb));
+        mb = fmaxf(mb, __shfl_xor(mb, 16)); mb = fmaxf(mb, __shfl_xor(mb, 32));
+        if (lane == 0) { wl.red[1] = ma; wl.red[2] = mb; }
     }
     __syncthreads();
-    float wg_max = 0.f;
-    for (int w = 0; w < nw; ++w) wg_max = fmaxf(wg_max, wls[w].red[1]);
-    // 2^ksh: the smallest power of two that brings the maximum below 2^15 (frexp exponent e: max < 2^e)
-    int ksh = 0;
-    {
-        const int e = (int)((__builtin_bit_cast(uint32_t, wg_max) >> 23) & 0xff) - 126;
-        ksh = __builtin_amdgcn_readfirstlane(e > 15 ? e - 15 : 0);
-    }
-    const bool range_fault = ksh > 8;                 // (wave-uniform) operands beyond 2^23: poison the outputs
-    if (range_fault) ksh = 8;
-    const float sc_dn = __builtin_bit_cast(float, (uint32_t)(127 - ksh) << 23);        // 2^-ksh
-    const float sc_up = __builtin_bit_cast(float, (uint32_t)(127 + ksh) << 23);        // 2^ksh
-    // fp8 (e4m3) look-up table of the pack: {missing, wrong, -, right} -> {0, +-2^ksh, 0, -+2^ksh}
-    const uint32_t cb = (uint32_t)(ksh + 7) << 3;
-    const uint32_t lut_fp32 = (IRT != 3) ? ((cb | 0x80u) << 24) | (cb << 8) : (cb << 24) | ((cb | 0x80u) << 8);
-    const uint32_t lut_code = (IRT != 3) ? ((cb | 0x80u) << 8) | cb : (cb << 8) | (cb | 0x80u);
+    float wg_amax = 0.f, wg_bmax = 0.f;
+    for (int w = 0; w < nw; ++w) { wg_amax = fmaxf(wg_amax, wls[w].red[1]); wg_bmax = fmaxf(wg_bmax, wls[w].red[2]); }
+    // frexp exponents e: max < 2^e
+    const int e_a = __builtin_amdgcn_readfirstlane((int)((__builtin_bit_cast(uint32_t, wg_amax) >> 23) & 0xff) - 126);
+    const int e_b = __builtin_amdgcn_readfirstlane((int)((__builtin_bit_cast(uint32_t, wg_bmax) >> 23) & 0xff) - 126);
+    int jsh = -(e_a >> 1);
+    jsh = jsh < -14 ? -14 : jsh > 12 ? 12 : jsh;
+    int bsh = e_b > 15 ? e_b - 15 : 0;
+    const bool range_fault = bsh > 15 || e_a + jsh > 15;      // (wave-uniform) not representable: poison the outputs
+    if (bsh > 15) bsh = 15;
+    const float sc_a = __builtin_bit_cast(float, (uint32_t)(127 + jsh) << 23);         // 2^jsh: image = a 2^jsh
+    const float sc_t = __builtin_bit_cast(float, (uint32_t)(127 - jsh) << 23);         // 2^-jsh: operands = theta 2^-jsh
+    const float sc_b = __builtin_bit_cast(float, (uint32_t)(127 - bsh) << 23);         // 2^-bsh: bias pieces
+    const _Float16 one_b = (_Float16)__builtin_bit_cast(float, (uint32_t)(127 + bsh) << 23);   // 2^bsh: their A-operand entries
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int xl = 64 * h + lane;
@@ -245,10 +253,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             _Float16 hi, lo;
-            split16(na_raw[h][kk] * sc_dn, hi, lo);
+            split16(na_raw[h][kk] * sc_a, hi, lo);
             hi8[kk] = hi; lo8[kk] = lo;
         }
-        const float nb = range_fault ? __builtin_nanf("") : nb_raw[h] * sc_dn;
+        const float nb = range_fault ? __builtin_nanf("") : nb_raw[h] * sc_b;
         _Float16 b0, b1, b2, b3;
         split16(nb, b0, b1);
         split16(nb - (float)b0 - (float)b1, b2, b3);
@@ -391,11 +399,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         // 1PL/2PL carry -w in the codes (the exponent is -w x logit: one VOP2 multiply)
         int nobs = 0, n1 = 0;
         if constexpr (CODES) {
-            cw0[4 * h + j] = pack_cell_codes4_lut(m[2 * j], k0, lut_code, nobs, n1);
-            cw1[4 * h + j] = pack_cell_codes4_lut(m[2 * j + 1], k1, lut_code, nobs, n1);
+            cw0[4 * h + j] = pack_cell_codes4_lut(m[2 * j], k0, kLutCode, nobs, n1);
+            cw1[4 * h + j] = pack_cell_codes4_lut(m[2 * j + 1], k1, kLutCode, nobs, n1);
         } else {
-            cw0[4 * h + j] = pack_codes4_lut(x[2 * j], (m[2 * j] | fillw) & k0, lut_fp32, nobs, n1);
-            cw1[4 * h + j] = pack_codes4_lut(x[2 * j + 1], (m[2 * j + 1] | fillw) & k1, lut_fp32, nobs, n1);
+            cw0[4 * h + j] = pack_codes4_lut(x[2 * j], (m[2 * j] | fillw) & k0, kLutFp32, nobs, n1);
+            cw1[4 * h + j] = pack_codes4_lut(x[2 * j + 1], (m[2 * j + 1] | fillw) & k1, kLutFp32, nobs, n1);
         }
         pk[j] += (nobs | (n1 << 16)) << (8 * h);
         // (pinned here: hipcc otherwise sinks the whole pack to the end of the batch, and the next loads take new registers)
@@ -452,7 +460,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // prior experts of the missing cells (models.py:613-620): weight 1 / (1 + eps) each, or dropped
     const float prior_w = p.missing_mode == 0 ? 1.0f / (1.0f + kPoeEps) : 0.f;
     const bool primary = EXTRA ? p.primary != 0 : true;
-    const float t_lo = kLoS * sc_dn, t_hi = kHiS * sc_dn;         // clamp bounds on the raw MFMA output (logit x 2^-ksh)
     auto forward_slot = [&](auto extc, const int bt, const int par, const int s, const float eps_c) {
         constexpr bool EXT = decltype(extc)::value;
         static_assert(EXTRA || !EXT, "the global-memory variant belongs to the EXTRA instantiations");
@@ -525,6 +532,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         }
+        const float ths = thv * sc_t;                   // operands carry theta 2^-jsh (see the operand image)
         if (live && primary) {
             const long long o = (long long)(row0 + pp) * A + ed;
             const float alv = -kLn2 * fast_log2(lam);
@@ -538,7 +546,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     lds_add(&fl.lacc[par][pp], ladj);
                 }
             }
-            lds_add(&cl.tacc[par][8][e], -0.5f * (1.0f + alv - amu * amu - inv_lam));
+            // a sample beyond the f16 range (or NaN): the regulariser sum -- and with it the loss -- becomes NaN.  (A NaN logit
+            // alone would not do: the clamp's v_med3 returns a finite bound for it.)
+            const float kl_term = -0.5f * (1.0f + alv - amu * amu - inv_lam);
+            lds_add(&cl.tacc[par][8][e], fabsf(ths) <= 65504.f ? kl_term : __builtin_nanf(""));
             lds_add(&cl.tacc[par][9][e], -0.5f * kLog2Pi - 0.5f * alv - 0.5f * eps_c * eps_c);
             lds_add(&cl.tacc[par][10][e], -0.5f * kLog2Pi - 0.5f * thv * thv);
             if (ed == 0) lds_add(&cl.tacc[par][11][e], nobs);
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             cl.st[par][4][e] = __builtin_bit_cast(float, cnt);
         }
         _Float16 hi, lo;
-        split16(fabsf(thv) <= 65504.f ? thv : __builtin_nanf(""), hi, lo);      // (beyond the f16 range: NaN, not a saturated piece)
+        split16(ths, hi, lo);
         const int slot = 8 * ((pp & 15) >> 2) + 4 * (pp >> 4) + (pp & 3);
         cl.thA[0][pp][ed] = hi;
         cl.thA[1][pp][ed] = lo;
@@ -569,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll 1
             for (int w = 0; w < nw; ++w) g0 += wls[w].gth[par][pp][ed];
         }
-        float gz0 = live ? g0 * kLn2 : 0.f;
+        float gz0 = live ? g0 * (kLn2 * sc_t) : 0.f;          // (log2 units -> nats; sum g a' = 2^jsh sum g a)
         const float amu = cl.st[par][0][e], sig = cl.st[par][1][e], inv_lam = cl.st[par][2][e], eps_c = cl.st[par][3][e];
         const int cnt = __builtin_bit_cast(int, cl.st[par][4][e]);
         const float n1 = (float)(cnt >> 16), n0 = (float)(cnt & 0xffff) - n1;
@@ -828,10 +839,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float& pr = (k & 1) ? pr1 : pr0;
-                    // (lg = logit x 2^-ksh, wc = -w 2^ksh: the clamp bounds on lg scale with it)
-                    const float tk = 1.0f + fast_exp2(wc[k] * med3(lg[k], -t_lo, t_lo));
+                    const float tk = 1.0f + fast_exp2(wc[k] * med3(lg[k], -kLoS, kLoS));
                     pr *= tk;
-                    if constexpr (GRAD) gl[k] = (lg[k] < -t_lo || lg[k] > t_hi) ? 0.f : fmaf(wc[k], fast_rcp(tk), -wc[k]);
+                    if constexpr (GRAD) gl[k] = (lg[k] < -kLoS || lg[k] > kHiS) ? 0.f : fmaf(wc[k], fast_rcp(tk), -wc[k]);
                 }
             }
         } else {
@@ -841,7 +851,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 float& pr = (k & 1) ? pr1 : pr0;
                 gl[k] = 0.f;
                 // 3PL: p = guess + (1 - guess) sigmoid(l)  (models.py:758-765), probability clamp on p itself
-                const float l = lg[k] * sc_up;
+                const float l = lg[k];
                 const float ee = fast_exp2(-fabsf(l));
                 const float rr_ = fast_rcp(1.0f + ee);
                 const float er_ = ee * rr_;
@@ -913,8 +923,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         acc_gt[0] = acc_gt[1] = zero4;
     };
     auto read_theta_ops = [&]() {
-        const half8 ones = half8{(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)0.f,
-                                 (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        const half8 ones = half8{one_b, one_b, one_b, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const half8 v = *reinterpret_cast<const half8*>(&cl.thA[g >> 1][16 * mt + i16][0]);
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     {
         // 1PL/2PL: every cell without an observation contributed exactly log2(1 + 2^0) = 1 to s_log
         const float ll = (IRT == 3 ? kLn2 : -kLn2) * wave_total(s_log - (float)unobs);
-        if (lane == 0) wl.red[0] = ll;
+        if (lane == 0) wl.red[0] = range_fault ? __builtin_nanf("") : ll;      // (operands beyond the rescaling range: loud)
     }
     __syncthreads();
     // scalars: 0 ll | 1 kl | 2 logq0 | 3 logp | 4 ladj | 5 nobs
@@ -1097,7 +1106,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 if constexpr (IRT != 1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = (acc_ga[u][t][j] + dpp_f<0x128>(acc_ga[u][t][j])) * sc_dn;
+                        const float v = (acc_ga[u][t][j] + dpp_f<0x128>(acc_ga[u][t][j])) * sc_a;       // sum g theta' = 2^-jsh sum g theta
                         const int il = kMsSpan * q + 64 * u + 4 * (4 * g + j) + t;
                         if (i16 < A && il < I) out[p.lay.off_item + (size_t)i16 * p.lay.i_pad + il] = -v;
                     }
@@ -1108,12 +1117,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 b += __shfl_xor(b, 32);
                 const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
                 const int brow = IRT == 1 ? 0 : A;
-                if (g == 0 && il < I) out[p.lay.off_item + (size_t)brow * p.lay.i_pad + il] = b * sc_dn;
+                if (g == 0 && il < I) out[p.lay.off_item + (size_t)brow * p.lay.i_pad + il] = b;
                 if constexpr (IRT == 3) {
                     float gg = acc_g[u][t];
                     gg += __shfl_xor(gg, 16);
                     gg += __shfl_xor(gg, 32);
-                    if (g == 0 && il < I) out[p.lay.off_item + (size_t)(A + 1) * p.lay.i_pad + il] = gg * sc_dn;
+                    if (g == 0 && il < I) out[p.lay.off_item + (size_t)(A + 1) * p.lay.i_pad + il] = gg;
                 }
             }
     }

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
+#include "vibo_philox.hpp"
 
 namespace vibo {
 
@@ -20,44 +21,6 @@ __host__ __device__ inline MlpOffsets mlp_offsets(int H, int O) {
 }
 
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
-
-// ---------------------------------------------------------------------------
-// N(0,1) fill: Philox4x32-10 (Salmon et al. 2011) + Box-Muller, 4 normals per counter
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t k0, const uint32_t k1) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
-}
-
-// the 4 normals of counter group g (outputs 4g .. 4g+3 of the stream)
-__device__ __forceinline__ float4 philox_normal4(const long long g, const uint32_t step, const uint32_t stream_id, const uint32_t seed_lo,
-                                                 const uint32_t seed_hi) {
-    uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), step, stream_id};
-    uint32_t k0 = seed_lo, k1 = seed_hi;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    // uniforms in (0, 1]; v_sin / v_cos take their argument in revolutions
-    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
-    const float r0 = sqrtf(-2.0f * kLn2 * fast_log2(u0)), r1 = sqrtf(-2.0f * kLn2 * fast_log2(u2));
-    return float4{r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
-                  r1 * __builtin_amdgcn_sinf(u3)};
-}
-__device__ __forceinline__ void store_normal4(float* __restrict__ out, const long long n, const long long g, const float4 z) {
-    if (4 * g + 3 < n && (((uintptr_t)out & 15) == 0)) {
-        reinterpret_cast<float4*>(out)[g] = z;
-    } else {
-        const float zz[4] = {z.x, z.y, z.z, z.w};
-        for (int k = 0; k < 4; ++k)
-            if (4 * g + k < n) out[4 * g + k] = zz[k];
-    }
-}
-
 
 __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n_item_entries, const float* __restrict__ P,
                                                              const float* __restrict__ mu, const float* __restrict__ lv,

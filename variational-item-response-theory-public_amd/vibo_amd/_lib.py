@@ -66,7 +66,8 @@ EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_by
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
                     'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise',
-                    'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd', 'vibo_flow_stack_forward', 'vibo_flow_stack_backward')
+                    'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd', 'vibo_flow_stack_forward', 'vibo_flow_stack_backward',
+                    'vibo_ctrain_param_floats', 'vibo_ctrain_scratch_floats', 'vibo_ctrain_prologue', 'vibo_ctrain_epilogue')
 
 _lib = None
 
@@ -137,6 +138,15 @@ def load():
     lib.vibo_flow_stack_forward.argtypes = [ctypes.c_int] * 3 + [vp] * 5 + [vp]
     lib.vibo_flow_stack_backward.restype = ctypes.c_int
     lib.vibo_flow_stack_backward.argtypes = [ctypes.c_int] * 3 + [vp] * 7 + [vp]
+    lib.vibo_ctrain_param_floats.restype = ctypes.c_int64
+    lib.vibo_ctrain_param_floats.argtypes = [dp, ctypes.c_int]
+    lib.vibo_ctrain_scratch_floats.restype = ctypes.c_int64
+    lib.vibo_ctrain_scratch_floats.argtypes = [dp, ctypes.c_int]
+    lib.vibo_ctrain_prologue.restype = ctypes.c_int
+    lib.vibo_ctrain_prologue.argtypes = [dp, ctypes.c_int, fp, fp, fp, fp, ctypes.c_uint64, ctypes.c_int, fp, ctypes.c_uint32,
+                                         fp, fp, fp, fp, fp, vp, vp]
+    lib.vibo_ctrain_epilogue.restype = ctypes.c_int
+    lib.vibo_ctrain_epilogue.argtypes = [dp, ctypes.c_int] + [fp] * 6 + [vp] + [fp] * 9 + [vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

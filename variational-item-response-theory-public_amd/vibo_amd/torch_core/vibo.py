@@ -236,7 +236,10 @@ class GraphedModuleStep:
         self.side = torch.cuda.Stream(device=data.device)
 
     def _eager(self, rows, beta):
-        self.optimizer.zero_grad(set_to_none=True)
+        # Once the graph exists its kernels zero, accumulate into and read the p.grad buffers allocated before the capture:
+        # the epoch's last, shorter minibatch runs through here and must not free them (set_to_none=True would hand them
+        # back to the allocator, and every later replay would write gradients into memory that may belong to someone else).
+        self.optimizer.zero_grad(set_to_none=self.graph is None)
         loss = self.model.elbo_step(self.data.response, self.data.mask, annealing_factor=beta, row_index=rows)
         loss.backward()
         self.optimizer.step()
@@ -452,11 +455,13 @@ def main(argv=None):
     if world > 1:
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
     trainer = None
-    if (args.cuda and not args.conditional_posterior and args.n_norm_flows == 0 and args.ability_merge == 'product'
-            and args.generative_model == 'irt'
-            and not args.torch_optimizer and args.hidden_dim <= 256):      # (wider encoders: module + torch.optim.Adam)
+    plain = not args.conditional_posterior and args.n_norm_flows == 0
+    if (args.cuda and args.ability_merge == 'product' and args.generative_model == 'irt' and not args.torch_optimizer
+            and (args.hidden_dim <= 256 if plain else args.hidden_dim in (32, 64))):      # (other widths: module + torch.optim.Adam)
+        # the whole step natively: FusedTrainer's kernels, or (conditional posterior / planar flows) FusedCondFlowTrainer's --
+        # same Adam arithmetic, 4-12 launches per step, no PyTorch autograd inside the replayed graph
         from ..trainer import FusedTrainer
-        trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)       # same Adam arithmetic, 5-7 launches per step
+        trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)
     graphed = None
     # The captured module step is opt-in (--graph-module-step): it is 3-4 x faster at small minibatches and follows the eager
     # step exactly in every configuration tests/test_gpu_trainer.py replays 60-150 times, but on this PyTorch / ROCm stack a

@@ -17,10 +17,29 @@ import torch
 from . import _lib, ops
 
 
+def fused_trainer_covers(model, hidden_dim=None):
+    """True when one of the fused trainers of this module runs the model's whole train step natively: the product-of-experts
+    encoder with the IRT decoder -- plain (FusedTrainer's kernels), or with the conditional posterior and / or planar flows
+    (FusedCondFlowTrainer's, hidden width 64 or 32).  --ability-merge mean and the MLP decoders train through the module +
+    torch.optim.Adam."""
+    if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
+        return False
+    if model.conditional_posterior or model.n_norm_flows > 0:
+        H = hidden_dim if hidden_dim is not None else model.ability_encoder.mlp[0].weight.shape[0]
+        return H in (32, 64)
+    return True
+
+
 class FusedTrainer:
+    def __new__(cls, model, *args, **kwargs):
+        # one entry point: the conditional posterior / planar flows are served by the sibling class below
+        if cls is FusedTrainer and (model.conditional_posterior or model.n_norm_flows > 0):
+            return super().__new__(FusedCondFlowTrainer)
+        return super().__new__(cls)
+
     def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True):
-        if model.conditional_posterior or model.n_norm_flows > 0 or model.ability_merge != 'product':
-            raise NotImplementedError('FusedTrainer covers the unconditional product-of-experts posterior without flows; '
+        if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
+            raise NotImplementedError('the fused trainers cover the product-of-experts encoder with the IRT decoder; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
         self.model = model
         mlp = model.ability_encoder.mlp
@@ -144,4 +163,119 @@ class FusedTrainer:
                                      p(self.mlp_m), p(self.mlp_v), p(self.item_mu), p(self.item_lv), p(self.item_m),
                                      p(self.item_v), p(self.loss), stream)
         _lib.check(rc, 'vibo_train_epilogue')
+        return self.loss
+
+
+class FusedCondFlowTrainer(FusedTrainer):
+    """The fused train step for --conditional-posterior and / or --n-norm-flows models (vibo.py:243-268 with
+    models.py:337-354, 380-443, 664-710, flows.py:21-66): vibo_ctrain_prologue (item sample, item-side flows, ability-flow
+    packing, the encoder MLP on the 2 x I rows [c, item_i] -> expert table; optionally the Philox noise) -> vibo_elbo_fwd_bwd
+    -> [one all-reduce when person-sharded] -> vibo_ctrain_epilogue (loss, table-MLP / flow / sample backward, Adam on
+    everything).  No PyTorch autograd node: the step replays from a hipGraph like FusedTrainer's.  Same interface
+    (`FusedTrainer(model, ...)` returns this class for such models).  Hidden width 64 or 32."""
+
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True):
+        if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
+            raise NotImplementedError('the fused trainers cover the product-of-experts encoder with the IRT decoder; '
+                                      'use model.elbo_step + torch.optim.Adam otherwise')
+        self.model = model
+        mlp = model.ability_encoder.mlp
+        self.hidden = mlp[0].weight.shape[0]
+        if self.hidden not in (32, 64):
+            raise NotImplementedError('FusedCondFlowTrainer: hidden_dim 64 or 32 (the rows of the expert table keep their '
+                                      'activations in registers); use model.elbo_step + torch.optim.Adam otherwise')
+        plist = [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, mlp[4].weight, mlp[4].bias]
+        F = model.n_norm_flows
+        if F > 0:
+            for st in (model.ability_norm_flows, model.item_norm_flows):
+                for fl in st.flows:
+                    plist += [fl.u, fl.w, fl.b]
+        dev = plist[0].device
+        # one flat buffer (the layout of include/vibo_hip.h: vibo_ctrain_*); the nn.Parameters become views of it
+        self.par_flat = torch.cat([p.detach().reshape(-1) for p in plist]).contiguous()
+        off = 0
+        for p in plist:
+            n = p.numel()
+            p.data = self.par_flat[off:off + n].view_as(p)
+            off += n
+        self.par_m = torch.zeros_like(self.par_flat)
+        self.par_v = torch.zeros_like(self.par_flat)
+        self.item_mu = model.item_encoder.mu_lookup.weight
+        self.item_lv = model.item_encoder.logvar_lookup.weight
+        assert self.item_mu.is_contiguous() and self.item_lv.is_contiguous()
+        I, D = self.item_mu.shape
+        A = model.ability_dim
+        n_item = I * D
+        self.item_m = torch.zeros(2 * n_item, device=dev)
+        self.item_v = torch.zeros(2 * n_item, device=dev)
+        self._steps = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.lr = torch.tensor(float(lr), device=dev)
+        self.beta = torch.tensor(1.0, device=dev)
+        self._beta_host = 1.0
+        self.item_feat = torch.empty_like(self.item_mu)
+        self.item_k = torch.empty_like(self.item_mu) if F > 0 else self.item_feat
+        self.table = torch.empty((2, I, 2 * A) if model.conditional_posterior else (2, 2 * A), device=dev)
+        self.flow_packed = torch.empty(F, 2 * A + 1, device=dev) if F > 0 else None
+        self._desc0 = ops._make_desc(model.spec, 1, I, _lib.MASK_NONE, _lib.REG_SAMPLED if F > 0 else _lib.REG_KL, True, I, 0)
+        lib = _lib.load()
+        if lib.vibo_ctrain_param_floats(ctypes.byref(self._desc0), self.hidden) != self.par_flat.numel():
+            raise RuntimeError('FusedCondFlowTrainer: parameter layout mismatch')
+        self.scratch = torch.empty(int(lib.vibo_ctrain_scratch_floats(ctypes.byref(self._desc0), self.hidden)), device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self.last = None
+        self._pending = None
+        if rng not in ('torch', 'native'):
+            raise ValueError("rng must be 'torch' or 'native'")
+        self.rng, self.seed = rng, int(seed)
+        self.fused_noise = True
+        self._eps_item = torch.empty_like(self.item_mu)
+        self._eps_ab = {}
+
+    @torch.no_grad()
+    def forward_backward(self, response, mask, beta=None, row_index=None):
+        if beta is not None:
+            self.set_beta(beta)
+        model, spec, lib = self.model, self.model.spec, _lib.load()
+        response, mask, code = ops.prepare_rows(response, mask)
+        B = int(row_index.numel()) if row_index is not None else response.shape[0]
+        I = response.shape[1]
+        dev = response.device
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        F = model.n_norm_flows
+        reg_mode = _lib.REG_SAMPLED if F > 0 else _lib.REG_KL
+        d = ops._make_desc(spec, B, I, code, reg_mode, True, response.stride(0), mask.stride(0) if mask is not None else 0)
+        p = ops._ptr
+        ab_stream = 1 + getattr(model, '_shard_rank', 0)
+        native = self.rng == 'native'
+        if native:
+            eps_item = self._eps_item
+            eps_ab = self._eps_ab.get(B)
+            if eps_ab is None:
+                eps_ab = self._eps_ab[B] = torch.empty(B, model.ability_dim, device=dev)
+        else:
+            # reference draw order: item eps, then ability eps (models.py:361,368)
+            eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
+            eps_ab = None
+        rc = lib.vibo_ctrain_prologue(ctypes.byref(d), self.hidden, p(self.par_flat), p(self.item_mu), p(self.item_lv),
+                                      p(eps_item), self.seed, 1 if native else 0, p(eps_ab), ab_stream, p(self.item_feat),
+                                      p(self.item_k), p(self.table), p(self.flow_packed), p(self.scratch), p(self._steps), stream)
+        _lib.check(rc, 'vibo_ctrain_prologue')
+        if not native:
+            eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
+        raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_k, eps_ab, self.flow_packed,
+                                   reg_mode, True, B)
+        self._pending = (d, eps_item, raw)
+        self.last = raw
+        return raw
+
+    @torch.no_grad()
+    def update(self):
+        d, eps_item, raw = self._pending
+        lib, p = _lib.load(), ops._ptr
+        stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
+        rc = lib.vibo_ctrain_epilogue(ctypes.byref(d), self.hidden, p(raw.flat), p(eps_item), p(self.item_feat), p(self.item_k),
+                                      p(self.beta), p(self.lr), p(self._steps), p(self.par_flat), p(self.par_m), p(self.par_v),
+                                      p(self.item_mu), p(self.item_lv), p(self.item_m), p(self.item_v), p(self.scratch),
+                                      p(self.loss), stream)
+        _lib.check(rc, 'vibo_ctrain_epilogue')
         return self.loss
