@@ -321,6 +321,18 @@ def main():
                         dist.all_reduce(static_raw.flat)
                         g2.replay()
                         return static_loss
+
+                    def phases(n=10):
+                        """ms per step spent in [noise + prologue + ELBO kernel + finalize | all-reduce | epilogue + Adam], by HIP
+                        events around the three pieces of the same replayed step (after the timed region: diagnosis of a scaling run)."""
+                        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)]
+                        for k in range(n):
+                            ev[k][0].record(); g.replay(); ev[k][1].record()
+                            dist.all_reduce(static_raw.flat); ev[k][2].record()
+                            g2.replay(); ev[k][3].record()
+                        torch.cuda.synchronize()
+                        return [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / n for i in range(3)]
+                    step2.phases = phases
                     return step2
 
                 def capture_one():
@@ -385,6 +397,13 @@ def main():
                 eager_step()
             torch.cuda.synchronize()
             recording['on'] = False
+        phase_ms = None
+        if dist is not None and getattr(step, 'phases', None) is not None:
+            ph = torch.tensor(step.phases(), device=dev, dtype=torch.float64)
+            dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+            phase_ms = {'forward_backward_graph': float(ph[0]), 'all_reduce': float(ph[1]), 'update_graph': float(ph[2]),
+                        'note': 'max over ranks of the mean over 10 replayed steps, HIP events on the launch stream; '
+                                'forward_backward_graph = noise + prologue + fused ELBO kernel + finalize, update_graph = epilogue + Adam'}
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
         if last_call:
             # sustained-load duration of the fused call: the same launch (item_prep + ELBO kernel + finalize) 10 times back to
@@ -410,7 +429,7 @@ def main():
         del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()
         return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None, rel=rel, sweep=sweep,
-                    launch=launch_mode if graph is not None else 'eager')
+                    launch=launch_mode if graph is not None else 'eager', phase_ms=phase_ms)
 
     def elbo_rel_err(model, resp, mask, A, n=4096):
         """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64).
@@ -594,7 +613,8 @@ def main():
                        'global_batch': int(total_persons), 'parallelism': f'person-sharded dp{world}', 'launch': m['launch'],
                        'optimizer': 'torch.optim.Adam (fused)' if (args.torch_optimizer or args.eval_only) else 'fused prologue/epilogue HIP kernels (Adam)',
                        'noise': 'torch.randn' if (args.torch_optimizer or args.eval_only or args.rng == 'torch') else 'Philox4x32-10 drawn in the prologue kernel (vibo_train_prologue_noise = the vibo_fill_normal streams)',
-                       'final_loss_per_term': final_loss / (total_persons * I)},
+                       'final_loss_per_term': final_loss / (total_persons * I),
+                       'persons_per_rank': P, 'phases_ms': m.get('phase_ms')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
                          # the same bytes over the whole timed step (noise, prologue, kernel, finalize, [all-reduce], epilogue + Adam)

@@ -48,7 +48,7 @@ def test_golden_through_module(golden):
     golden.response, golden.mask = golden.response.to(d), golden.mask.to(d)
     golden.eps_item, golden.eps_ability = golden.eps_item.to(d), golden.eps_ability.to(d)
     outs, loss = run_reference_pattern(model, golden)
-    check_against_golden(model, golden, outs, loss, tol_loss=TOL_ELBO, tol_truth=3e-4)
+    check_against_golden(model, golden, outs, loss, tol_loss=TOL_ELBO, tol_grad=3e-4, strict=True)
 
 
 def test_golden_adam_trajectory(golden):

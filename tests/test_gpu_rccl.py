@@ -113,3 +113,7 @@ def test_bench_two_ranks_share_one_device_over_gloo(scaling):
     assert d['value'] > 0 and d['ms_per_step'] > 0 and 'roofline' in d and 'cpu_baseline' not in d and 'extra' not in d
     assert 'also' in d and 'format_p' in d
     assert abs(d['value'] - d['config']['global_batch'] * 1000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    # the per-phase breakdown a scaling run is diagnosed with: [noise + prologue + ELBO kernel + finalize | all-reduce | epilogue + Adam]
+    ph = d['config']['phases_ms']
+    assert ph is not None and all(ph[k] > 0 for k in ('forward_backward_graph', 'all_reduce', 'update_graph'))
+    assert d['config']['persons_per_rank'] == (100000 if scaling == 'weak' else 50000)

@@ -52,7 +52,7 @@ def run_reference_pattern(model, golden, mask_dtype=torch.int64):
     return outs, loss
 
 
-def check_against_golden(model, golden, outs, loss, tol_loss=1e-4, tol_grad=3e-4, tol_truth=1.5e-3):
+def check_against_golden(model, golden, outs, loss, tol_loss=1e-4, tol_grad=3e-4, tol_truth=1.5e-3, strict=False):
     m = golden.meta
     assert rel_err(loss.detach(), golden.out['loss']) < tol_loss
     flows = m['n_norm_flows'] > 0
@@ -79,6 +79,18 @@ def check_against_golden(model, golden, outs, loss, tol_loss=1e-4, tol_grad=3e-4
         else:
             # the fp32 CPU stand-in is as noisy as the reference (whose own fp32 gradients sit up to 1.6e-2 from fp64 on
             # the mean-merge encoder's first layer): allow the reference's own distance from the fp64 oracle on top
+            if strict:
+                # the HIP path (tests/test_gpu_parity.py): within tol of the exact (fp64) gradient, or -- where the reference's
+                # own fp32 arithmetic sits further from it than that (3PL cells inside the probability clamp band) -- within
+                # tol of the reference's gradient.  No allowance added on top of either.
+                e_truth, e_ref = rel_err(g, truth[name]), rel_err(g, g_ref)
+                ref_off = rel_err(g_ref, truth[name])
+                # (one golden, 3pl_a8_uncond_mean_miss: the reference's own fp32 gradient of the mean-merge encoder's first
+                #  layer is 3 % away from the exact one -- saturated 3PL cells; a tensor the reference gets that wrong is held to
+                #  a tenth of the reference's own error instead)
+                tol = tol_grad if ref_off < 1e-2 else max(tol_grad, 0.1 * ref_off)
+                assert min(e_truth, e_ref) < tol, (name, e_truth, e_ref, ref_off)
+                continue
             assert rel_err(g, truth[name]) < tol_truth + rel_err(g_ref, truth[name]), name
             assert rel_err(g, g_ref) < tol_grad + rel_err(g_ref, truth[name]), name
 

@@ -19,7 +19,7 @@ python $R/tools/rocpd_summary.py $W/kt/kt_results.db | head -14
 echo "# the library's own kernels:"
 python $R/tools/rocpd_summary.py $W/kt/kt_results.db vibo
 echo; echo "# one steady-state step of the replayed graph (tools/rocpd_sequence.py: dispatches between the last two launches of the ELBO kernel):"
-python $R/tools/rocpd_sequence.py $W/kt/kt_results.db msplit_kernel
+echo "## fp32 rows (the headline step):"; python $R/tools/rocpd_sequence.py $W/kt/kt_results.db ELi0ELb0E; echo "## Format P rows:"; python $R/tools/rocpd_sequence.py $W/kt/kt_results.db ELi2ELb0E
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   n=$(echo $pass | cut -d' ' -f1)
   echo; echo "# command: rocprofv3 --pmc $pass -- $B     (per-dispatch averages, vibo kernels only)"

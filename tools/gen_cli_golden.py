@@ -41,24 +41,35 @@ VARIANTS = {      # extra reference-CLI flags of the additional VIBO runs
 def main(script='vibo'):
     variant, extra = script, []
     cli_seed = None
+    if '@' in script:
+        # a VARIANT under another --seed (`vibo_cond@43`): the reference's own seed-to-seed scatter of that configuration, the
+        # yardstick for its tolerances in tests/test_gpu_trainer.py (-> cli_trained_<variant>_seed<k>_2pl.npz)
+        script, sd = script.split('@')
+        cli_seed, variant = int(sd), f'{script}_seed{sd}'
     if script.startswith('vibo_seed'):
         # the headline run again under another --seed (initialisation, noise; the dataset and the hidden cells stay those
         # of seed 42): what the REFERENCE's own numbers scatter by from seed to seed -- the yardstick for the tolerances of
         # tests/test_gpu_trainer.py::test_trained_model_matches_the_reference_cli_run (our GPU run is one more noise stream)
         cli_seed, script = int(script[len('vibo_seed'):]), 'vibo'
+    base = script
     if script in VARIANTS:
         extra, script = VARIANTS[script], 'vibo'
         ARGS['epochs'] = 15
-        if variant == 'vibo_cond':
+        variant_base = base
+        if variant_base == 'vibo_cond':
             ARGS['ability_dim'] = 2
-        if variant == 'vibo_3pl_flows':
+        if variant_base == 'vibo_3pl_flows':
             ARGS['irt'] = '3pl'
-        if variant == 'vibo_1pl_drop95':
+        if variant_base == 'vibo_1pl_drop95':
             ARGS['irt'], ARGS['num_item'] = '1pl', 95
-        if variant == 'vibo_a8_1100':
+        if variant_base == 'vibo_a8_1100':
             ARGS.update(num_person=400, num_item=1100, ability_dim=8, epochs=10)
-        if variant == 'vibo_cond_1030':
+        if variant_base == 'vibo_cond_1030':
             ARGS.update(num_person=400, num_item=1030, epochs=10)
+    if script == 'critlangacq':
+        # BASELINE configs[3]: --dataset critlangacq --artificial-missing-perc 0.2 on a synthetic data.csv of the loader's format
+        # (vibo_amd.simulate.synthetic_critlangacq_csv; the real file is not in the container), 2PL, 15 epochs
+        return critlangacq_run()
     if script == 'mle':          # the reference's mle.py feeds the -1 of hidden cells to F.binary_cross_entropy as a target, which
         ARGS['perc'] = 0.0       # current PyTorch rejects ("all elements of target should be between 0 and 1"): complete data only
     sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
@@ -119,6 +130,42 @@ def main(script='vibo'):
         rec.update(ability_mu=ck['infer_dict']['ability_mu'].numpy(), ability_logvar=ck['infer_dict']['ability_logvar'].numpy(),
                    item_feat_mu=ck['infer_dict']['item_feat_mu'].cpu().numpy())
     out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_2pl.npz' if variant == 'vibo' else f'cli_trained_{variant}_2pl.npz')
+    np.savez_compressed(out, **rec)
+    print('wrote', out, 'train loss', rec['train_losses'][-1], 'imputation acc', float(rec['missing_imputation_accuracy']))
+
+
+CRIT = dict(num_person=2500, csv_seed=7, epochs=15, batch=16, samples=20, seed=42, perc=0.2)
+
+
+def critlangacq_run():
+    sys.path.insert(0, os.path.join(ROOT, 'variational-item-response-theory-public_amd'))
+    from vibo_amd import simulate
+    tmp = tempfile.mkdtemp(prefix='vibo_cli_golden_')
+    data_dir, out_dir = os.path.join(tmp, 'data'), os.path.join(tmp, 'out')
+    os.makedirs(out_dir)
+    simulate.synthetic_critlangacq_csv(os.path.join(data_dir, 'critlangacq', 'data.csv'), CRIT['num_person'], CRIT['csv_seed'])
+    sys.modules.setdefault('nltk', types.SimpleNamespace(word_tokenize=None))
+    sys.path.insert(0, REF)
+    torch.distributions.Distribution.set_default_validate_args(False)
+    _load = torch.load
+    torch.load = lambda *a, **k: _load(*a, **{**k, 'weights_only': False})
+    import src.config as cfg
+    cfg.DATA_DIR, cfg.OUT_DIR = data_dir, out_dir
+    cfg.CHILDREN_LANG_DIR = os.path.join(data_dir, 'critlangacq')
+    sys.argv = ['vibo.py', '--irt-model', '2pl', '--dataset', 'critlangacq', '--ability-dim', '1', '--artificial-missing-perc',
+                str(CRIT['perc']), '--epochs', str(CRIT['epochs']), '--batch-size', str(CRIT['batch']), '--num-posterior-samples',
+                str(CRIT['samples']), '--no-marginal', '--seed', str(CRIT['seed']), '--out-dir', out_dir]
+    runpy.run_path(os.path.join(REF, 'src', 'torch_core', 'vibo.py'), run_name='__main__')
+    (run,) = os.listdir(out_dir)
+    ck = _load(os.path.join(out_dir, run, 'checkpoint.pth.tar'), weights_only=False)
+    rec = {
+        'meta': json.dumps(dict(CRIT, run_dir=run, script='vibo', dataset='critlangacq', irt='2pl', torch=torch.__version__)),
+        'train_losses': np.load(os.path.join(out_dir, run, 'train_losses.npy')),
+        'test_losses': np.load(os.path.join(out_dir, run, 'test_losses.npy')),
+        'missing_imputation_accuracy': np.float64(ck.get('missing_imputation_accuracy', float('nan'))),
+        'ability_mu': ck['infer_dict']['ability_mu'].numpy(), 'item_feat_mu': ck['infer_dict']['item_feat_mu'].cpu().numpy(),
+    }
+    out = os.path.join(ROOT, 'tests', 'golden', 'cli_trained_critlangacq_2pl.npz')
     np.savez_compressed(out, **rec)
     print('wrote', out, 'train loss', rec['train_losses'][-1], 'imputation acc', float(rec['missing_imputation_accuracy']))
 

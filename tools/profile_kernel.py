@@ -26,6 +26,8 @@ ap.add_argument('--gather', action='store_true', help='rows through a random row
 ap.add_argument('--given', action='store_true', help='caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN, the --ability-merge mean path)')
 ap.add_argument('--codes', action='store_true', help='rows as 1-byte cell codes (VIBO_MASK_CODES, Format P) instead of fp32 + mask')
 ap.add_argument('--kernel', choices=['auto', 'matrix', 'valu'], default='auto', help='pin a row-split kernel (vibo_desc.flags)')
+ap.add_argument('--item-scale', type=float, default=1.0, help='scale of the N(0,1) item sample (larger: more logits past the Bernoulli clamp, i.e. more tiles on the slow path)')
+ap.add_argument('--init-like', action='store_true', help='item sample as a freshly initialised model draws it: mu + exp(.5 logvar) eps with mu, logvar, eps ~ N(0,1)')
 ap.add_argument('--cached-rows', type=int, default=0, help='gather rows from the first N rows only (L2-resident): compute-only timing')
 a = ap.parse_args()
 ops.DESC_FLAGS = {'auto': 0, 'matrix': _lib.FLAG_KERNEL_MATRIX, 'valu': _lib.FLAG_KERNEL_VALU}[a.kernel]
@@ -39,7 +41,9 @@ spec = ElboSpec(irt_model=a.irt, ability_dim=A, conditional=a.cond, n_flows=a.fl
 table = torch.randn(*spec.table_shape(I, P), device=d, generator=g) * 0.5
 flow = torch.randn(a.flows, 2 * A + 1, device=d, generator=g) * 0.5 if a.flows else None
 reg = _lib.REG_SAMPLED if a.flows else _lib.REG_KL
-item = torch.randn(I, D, device=d, generator=g)
+item = torch.randn(I, D, device=d, generator=g) * a.item_scale
+if a.init_like:
+    item = torch.randn(I, D, device=d, generator=g) + torch.exp(0.5 * torch.randn(I, D, device=d, generator=g)) * torch.randn(I, D, device=d, generator=g)
 eps = torch.randn(P, A, device=d, generator=g)
 m, code = ops.prepare_mask(mask)
 if a.codes:

@@ -812,18 +812,38 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             // the plain formula for all cells first, and ONE branch to the slow path that overrides it.
             // (the maxima read the exponents u = -w l, not the logits: the MFMA -> VALU wait states are the compiler's business
             //  -- it knows nothing about registers read inside an asm statement -- and a missing cell, u = 0, never triggers)
-            float tt[8], uu[8];
+            float tt[8], uu[8], ee[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 uu[k] = wc[k] * lg[k];
-                tt[k] = 1.0f + fast_exp2(uu[k]);
+                ee[k] = fast_exp2(uu[k]);
+                tt[k] = 1.0f + ee[k];
             }
+#ifndef VIBO_MS_RCP_EACH
+            {
+                // products of four (one log2 per 4 terms, <= (1 + 2^23)^4) -- and ONE reciprocal per two cells: with
+                // p = t_a t_b,  1 / t_a = t_b / p  and  1 / t_b = t_a / p  (two packed multiplies instead of a second
+                // quarter-rate v_rcp; ~2 ulp instead of 1)
+                const float2v t01 = {tt[0], tt[1]}, t23 = {tt[2], tt[3]}, t45 = {tt[4], tt[5]}, t67 = {tt[6], tt[7]};
+                const float2v pa = t01 * t23, pb = t45 * t67;          // (t0 t2, t1 t3), (t4 t6, t5 t7)
+                const float2v pp = pa * pb;
+                pr0 = pp[0]; pr1 = pp[1];
+                if constexpr (GRAD) {
+                    const float2v ra = {fast_rcp(pa[0]), fast_rcp(pa[1])}, rb = {fast_rcp(pb[0]), fast_rcp(pb[1])};
+                    const float2v r01 = ra * t23, r23 = ra * t01, r45 = rb * t67, r67 = rb * t45;
+                    const float rr[8] = {r01[0], r01[1], r23[0], r23[1], r45[0], r45[1], r67[0], r67[1]};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gl[k] = fmaf(wc[k], rr[k], -wc[k]);
+                }
+            }
+#else
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float& pr = (k & 1) ? pr1 : pr0;
                 pr *= tt[k];                                          // <= (1 + 2^23)^4: one log2 per 4 terms
                 if constexpr (GRAD) gl[k] = fmaf(wc[k], fast_rcp(tt[k]), -wc[k]);
             }
+#endif
 #ifdef VIBO_MS_PRODCHK
             // (A/B only: "some e > 2^23" from the products -- misses the likely-side band where the reference's gradient is an exact 0)
             float lmax = fmaxf(pr0, pr1) < 8388608.0f ? 0.f : 1e30f;
@@ -839,9 +859,19 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float& pr = (k & 1) ? pr1 : pr0;
+                    // exp2 is monotone and exact at +-23: clamping e = 2^u to [2^-23, 2^23] IS the clamp of the logit -- no second
+                    // exponential; the gradient's zero band (l < -15.94 or l > 16.64) as "clamping l to it changes l".
+                    // (A saturated item sends its wave through here in every batch and the other waves wait for it at the
+                    //  barrier: a freshly initialised model has a few such items, ~10 % of the kernel before this was trimmed.)
+#ifndef VIBO_MS_OLDSLOW
+                    const float tk = 1.0f + med3(ee[k], 0x1p-23f, 0x1p23f);
+                    pr *= tk;
+                    if constexpr (GRAD) gl[k] = (med3(lg[k], -kLoS, kHiS) != lg[k]) ? 0.f : fmaf(wc[k], fast_rcp(tk), -wc[k]);
+#else
                     const float tk = 1.0f + fast_exp2(wc[k] * med3(lg[k], -kLoS, kLoS));
                     pr *= tk;
                     if constexpr (GRAD) gl[k] = (lg[k] < -kLoS || lg[k] > kHiS) ? 0.f : fmaf(wc[k], fast_rcp(tk), -wc[k]);
+#endif
                 }
             }
         } else {

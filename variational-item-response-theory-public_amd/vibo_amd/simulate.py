@@ -49,6 +49,31 @@ def generate(irt_model, num_person, num_item, ability_dim, seed=42, nonlinear=Fa
     return {'response': response, 'ability': ability, 'item_feat': item_feat}
 
 
+def synthetic_critlangacq_csv(path, num_person=2500, seed=7, native_missing=0.03):
+    """A stand-in for DATA_DIR/critlangacq/data.csv (the real file, datasets.py:283-440, is not redistributable): the 95
+    item columns of the loader -- in a scrambled file order, with a decoy q-column and metadata columns in between -- filled
+    with 2PL responses (ability_dim 1, `generate`'s draws) and `native_missing` of the cells set to -1.  Deterministic in
+    (num_person, seed): tools/gen_cli_golden.py feeds the same file to the reference CLI."""
+    import numpy as np
+    import pandas as pd
+    from .datasets import critlangacq_item_keys
+    keys = list(critlangacq_item_keys())
+    sim = generate('2pl', num_person, len(keys), 1, seed=seed)
+    resp = sim['response'][:, :, 0].numpy().astype(np.int64)
+    rs = np.random.RandomState(seed)
+    resp[rs.rand(*resp.shape) < native_missing] = -1
+    cols = {'id': np.arange(num_person), 'age': rs.randint(7, 80, num_person), 'education': rs.randint(0, 6, num_person)}
+    order = list(range(len(keys)))
+    rs.shuffle(order)
+    for pos, k in enumerate(order):
+        if pos == 7:
+            cols['q4_decoy'] = (rs.rand(num_person) < 0.5).astype(np.int64)      # a q-column that is NOT one of the 95 items
+        cols[keys[k]] = resp[:, k]
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    pd.DataFrame(cols).to_csv(path, index=False)
+    return path
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--irt-model', type=str, default='3pl', choices=['1pl', '2pl', '3pl'])
