@@ -593,10 +593,11 @@ def main():
     # HBM bytes per launch: parsed from the committed rocprofv3 summary of this command (tools/collect_profile.sh); only
     # meaningful for the workload that summary was taken on (the default one)
     default_wl = (args.persons, I, irt, abs(args.missing - 0.1) < 1e-9, world) == (1_000_000, 1000, 2, True, 1)
-    kernel_tag = f'msplit_kernelILi{irt}ELb{0 if args.eval_only else 1}ELi0E'
+    # (mangled template arguments <IRT, GRAD, RM = 0 fp32 rows, FLOWS = 0, ...> of vibo::msplit_kernel: the summary keeps the names' tails)
+    kernel_tag = f'ILi{irt}ELb{0 if args.eval_only else 1}ELi0ELb0E'
     traffic, traffic_note = (parse_traffic(kernel_tag) if default_wl and A == 8 else (None, 'not measured for this workload'))
     if format_p is not None and default_wl and A == 8:
-        format_p['traffic'], _ = parse_traffic(f'msplit_kernelILi{irt}ELb{0 if args.eval_only else 1}ELi2E')
+        format_p['traffic'], _ = parse_traffic(f'ILi{irt}ELb{0 if args.eval_only else 1}ELi2ELb0E')
     if rank == 0:
         terms = total_persons * I * args.steps
         line = {

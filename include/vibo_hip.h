@@ -317,6 +317,24 @@ int vibo_ctrain_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, 
                          float* loss_out, void* stream);
 
 /*
+ * --ability-merge mean WITH --conditional-posterior (models.py:664-710 with _forward_mean :631-650): the per-term feature
+ * depends on the item, feature[c][i][:] = elu(mlp1([c, item_i])) (the caller's 2 x I-row MLP), and the encoder's input is its mean
+ * over a person's observed cells.  The sum over the cells -- one-hot(codes) [B, 2I] x feature [2I, H], the path's one dense
+ * encoder contraction -- and its transpose for the backward run on the matrix pipe from the 1-byte cell codes
+ * (VIBO_MASK_CODES layout: 0 wrong / 1 right / 2 missing; rows 4-byte aligned, stride % 4 == 0), the dense operand as
+ * hi + lo f16 pieces with fp32 accumulation (fp32-grade):
+ *     vibo_code_table_sum_forward    out_sum [B][H]          = sum_i [observed] feature[code_pi][i][:]
+ *     vibo_code_table_sum_backward   grad_feature [2][I][H]  = sum_p [code_pi == c] grad_sum[p][:]      (fixed-order: reproducible)
+ * H = 64.  scratch: vibo_code_table_scratch_bytes(B, I, H) bytes, 256-byte aligned, need not survive between the two calls.
+ * The division by the number of observed cells (vibo_row_counts) and mlp2 -- a plain [B, 64] x [64, 64] GEMM -- stay with the caller.
+ */
+size_t vibo_code_table_scratch_bytes(int64_t num_person, int num_item, int hidden_dim);
+int vibo_code_table_sum_forward(int64_t num_person, int num_item, int hidden_dim, const uint8_t* codes, int64_t codes_row_stride,
+                                const float* feature, float* out_sum, void* scratch, size_t scratch_bytes, void* stream);
+int vibo_code_table_sum_backward(int64_t num_person, int num_item, int hidden_dim, const uint8_t* codes, int64_t codes_row_stride,
+                                 const float* grad_sum, float* grad_feature, void* scratch, size_t scratch_bytes, void* stream);
+
+/*
  * Standard-normal fill for the reparameterisation noise (replaces the torch.randn_like calls of utils.py:85-88 as
  * used at models.py:361,368 when the caller does not need PyTorch's generator stream):
  *     out[i] ~ N(0,1),  Philox4x32-10 keyed by `seed`, counter (i / 4, *step_count, stream_id), Box-Muller.

@@ -162,8 +162,19 @@ def install(ops):
             total = total + torch.log(torch.abs(1.0 + (1.0 - t * t) * torch.dot(w, uhat)) + 1e-8)
         return z, total
 
+    def cond_mean_sum(feature, response, mask, row_index):
+        """vibo_code_table_sum_forward/backward as two dense products on indicator matrices (autograd)."""
+        if isinstance(response, ops.CellCodes):
+            codes = _gather(response.codes, row_index)
+            r, m = (codes == 1).to(feature.dtype), (codes != 2).to(feature.dtype)
+        else:
+            r = _gather(ops.prepare_response(response), row_index)
+            m = torch.ones_like(r) if mask is None else (_gather(ops.prepare_mask(mask)[0], row_index) != 0).to(r.dtype)
+            r = (r == 1).to(m.dtype) * m
+        return m @ feature[0] + r @ (feature[1] - feature[0]), m.sum(1)
+
     ops._BACKEND.update(decoder=decoder, flow_stack=flow_stack, elbo=elbo, encode=encode, decode=decode, multi=multi, decode_mean=decode_mean, counts=counts, mean_fwd=mean_fwd,
-                        mean_bwd=mean_bwd)
+                        mean_bwd=mean_bwd, cond_mean_sum=cond_mean_sum)
 
     def restore():
         ops._BACKEND.update(saved)

@@ -232,3 +232,35 @@ def test_row_counts_are_cached_per_resident_matrix():
         assert len(calls) == 4 and torch.equal(e[rows], f) and torch.equal(e, ops.row_counts(resp, mask))
     finally:
         ops._BACKEND['counts'] = native
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,I,missing', [(64, 64, 0.0), (200, 1000, 0.2), (77, 95, 0.3), (1, 7, 0.0), (513, 130, 0.1), (4099, 1000, 0.1)])
+def test_code_table_sum_kernels_match_dense_products(B, I, missing):
+    """vibo_code_table_sum_forward / _backward (--ability-merge mean with --conditional-posterior, models.py:631-650 +
+    695-710: the one-hot [B, 2I] x [2I, H] contraction on the matrix pipe from the cell codes, hi + lo f16 operands) against
+    the same sums as float64 products on materialised indicator matrices: fp32-grade, bitwise run to run, ragged shapes."""
+    from vibo_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B + I)
+    resp = (torch.rand(B, I, generator=g) < 0.5).float()
+    mask = torch.rand(B, I, generator=g) >= missing
+    feat = (torch.randn(2, I, 64, generator=g) * 1.5).to(dev).requires_grad_(True)
+    gout = torch.randn(B, 64, generator=g).to(dev)
+    cc = ops.pack_cell_codes(resp.to(dev), mask.to(dev))
+    S = ops.CodeTableSumFn.apply(feat, cc)
+    (dfeat,) = torch.autograd.grad(S, feat, gout)
+    f64 = feat.detach().double().cpu()
+    obs, right = mask.double(), (resp.double() * mask.double())
+    S_ref = (obs - right) @ f64[0] + right @ f64[1]
+    d_ref = torch.stack([(obs - right).t() @ gout.double().cpu(), right.t() @ gout.double().cpu()])
+    assert (S.double().cpu() - S_ref).abs().max() < 2e-6 * max(1.0, float(S_ref.abs().max()))
+    assert (dfeat.double().cpu() - d_ref).abs().max() < 2e-6 * max(1.0, float(d_ref.abs().max()))
+    S2 = ops.CodeTableSumFn.apply(feat, cc)
+    (d2,) = torch.autograd.grad(S2, feat, gout)
+    assert torch.equal(S, S2) and torch.equal(dfeat, d2)
+    # the whole backend entry (codes packed from the fp32 rows, a gathered minibatch, observed counts)
+    rows = torch.randperm(B, generator=g)[:max(1, B // 2)].to(dev)
+    S3, nobs = ops._BACKEND['cond_mean_sum'](feat.detach(), resp.to(dev), mask.to(dev), rows)
+    assert (S3.double().cpu() - S_ref[rows.cpu()]).abs().max() < 2e-6 * max(1.0, float(S_ref.abs().max()))
+    assert torch.equal(nobs.cpu(), mask[rows.cpu()].sum(1).float())

@@ -67,7 +67,8 @@ EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_by
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
                     'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise',
                     'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd', 'vibo_flow_stack_forward', 'vibo_flow_stack_backward',
-                    'vibo_ctrain_param_floats', 'vibo_ctrain_scratch_floats', 'vibo_ctrain_prologue', 'vibo_ctrain_epilogue')
+                    'vibo_ctrain_param_floats', 'vibo_ctrain_scratch_floats', 'vibo_ctrain_prologue', 'vibo_ctrain_epilogue',
+                    'vibo_code_table_scratch_bytes', 'vibo_code_table_sum_forward', 'vibo_code_table_sum_backward')
 
 _lib = None
 
@@ -147,6 +148,11 @@ def load():
                                          fp, fp, fp, fp, fp, vp, vp]
     lib.vibo_ctrain_epilogue.restype = ctypes.c_int
     lib.vibo_ctrain_epilogue.argtypes = [dp, ctypes.c_int] + [fp] * 6 + [vp] + [fp] * 9 + [vp]
+    lib.vibo_code_table_scratch_bytes.restype = ctypes.c_size_t
+    lib.vibo_code_table_scratch_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    for fn in (lib.vibo_code_table_sum_forward, lib.vibo_code_table_sum_backward):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int64, fp, fp, vp, ctypes.c_size_t, vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

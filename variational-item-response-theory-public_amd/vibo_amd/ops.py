@@ -490,11 +490,67 @@ def _hip_decode_mean(spec, abilities, items):
     return out
 
 
-# The three entry points of the native library.  tests/ swap these for the CPU
+class CodeTableSumFn(torch.autograd.Function):
+    """S[p, :] = sum over person p's observed cells of feature[code_pi, i, :]  (vibo_code_table_sum_forward / _backward: the
+    one-hot [B, 2I] x [2I, H] contraction of --ability-merge mean with --conditional-posterior and its transpose, on the
+    matrix pipe from the 1-byte cell codes).  feature [2, I, 64] fp32; codes = CellCodes of the minibatch's rows."""
+
+    @staticmethod
+    def forward(ctx, feature, cell_codes):
+        lib = _lib.load()
+        codes = cell_codes.codes
+        B, I = codes.shape
+        H = feature.shape[2]
+        feat = feature.detach().contiguous().float()
+        _require_device(feat, codes)
+        out = torch.empty(B, H, dtype=torch.float32, device=codes.device)
+        nbytes = lib.vibo_code_table_scratch_bytes(B, I, H)
+        if nbytes == 0:
+            raise _lib.ViboLibraryError('vibo_code_table_sum: hidden_dim must be 64')
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=codes.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(codes.device).cuda_stream)
+        rc = lib.vibo_code_table_sum_forward(B, I, H, _ptr(codes), codes.stride(0), _ptr(feat), _ptr(out), _ptr(scratch), nbytes, stream)
+        _lib.check(rc, 'vibo_code_table_sum_forward')
+        ctx.cell_codes, ctx.shape = cell_codes, (I, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        codes = ctx.cell_codes.codes
+        B = codes.shape[0]
+        I, H = ctx.shape
+        g = g.contiguous().float()
+        dfeat = torch.empty(2, I, H, dtype=torch.float32, device=codes.device)
+        nbytes = lib.vibo_code_table_scratch_bytes(B, I, H)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=codes.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(codes.device).cuda_stream)
+        rc = lib.vibo_code_table_sum_backward(B, I, H, _ptr(codes), codes.stride(0), _ptr(g), _ptr(dfeat), _ptr(scratch), nbytes, stream)
+        _lib.check(rc, 'vibo_code_table_sum_backward')
+        return dfeat, None
+
+
+def _hip_cond_mean_sum(feature, response, mask, row_index):
+    """(S [B, H], n_observed [B]) for the minibatch: the cells as CellCodes (packed here from fp32 rows + mask if need be),
+    the sum on the matrix pipe (CodeTableSumFn), the observed counts from vibo_row_counts."""
+    if isinstance(response, CellCodes):
+        cc = response.rows(row_index) if row_index is not None else response
+    else:
+        r = prepare_response(response)
+        m = None if mask is None else prepare_mask(mask)[0]
+        if row_index is not None:
+            r, m = r[row_index], (None if m is None else m[row_index])
+        cc = pack_cell_codes(r, m)
+    counts = _BACKEND['counts'](cc.codes, cc.codes, _lib.MASK_CODES, None)
+    nobs = (counts & 0xffff).to(feature.dtype)
+    return CodeTableSumFn.apply(feature, cc), nobs
+
+
+# The three entry points of the native library.  tests/ swap these for the CPU# The three entry points of the native library.  tests/ swap these for the CPU
 # oracle to exercise the host logic without a GPU (never done by product code).
 _BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward,
             'decode_mean': _hip_decode_mean, 'counts': _hip_row_counts, 'mean_fwd': _hip_mean_encoder_fwd,
-            'mean_bwd': _hip_mean_encoder_bwd, 'flow_stack': _hip_flow_stack}
+            'mean_bwd': _hip_mean_encoder_bwd, 'flow_stack': _hip_flow_stack, 'cond_mean_sum': _hip_cond_mean_sum}
 
 
 class FusedELBO(torch.autograd.Function):

@@ -145,11 +145,12 @@ class MeanAbilityEncoder(nn.Module):
         self.mlp1, self.mlp2 = nets(1 + (item_dim if conditional else 0))
         self.register_buffer('_response_values', torch.tensor([[0.0], [1.0]]), persistent=False)
 
-    def posterior_conditional(self, response, mask, item_feat, reducer=None):
+    def posterior_conditional(self, response, mask, item_feat, reducer=None, row_index=None):
         """--conditional-posterior (models.py:695-710 with _forward_mean :631-650): the per-term feature depends on the item
         too, h[c, i] = elu(mlp1([c, item_i])), so a person's mean over its observed items is the [B, 2I] x [2I, H]
-        contraction of its one-hot coded row with the 2 x I feature table -- two dense GEMMs on the observed / correct
-        indicator matrices (the GEMM library's job), then mlp2.  response [B, I] fp32, mask [B, I] bool/u8 or None."""
+        contraction of its one-hot coded row with the 2 x I feature table -- the encoder's one dense contraction, on the
+        matrix pipe straight from the cell codes (ops.CodeTableSumFn: vibo_code_table_sum_forward / _backward; hidden width
+        64) -- then mlp2, a plain [B, 64] GEMM.  response: fp32 rows [.., I] + mask, or CellCodes; row_index selects the minibatch."""
         I = item_feat.shape[0]
         vals = self._response_values.to(item_feat.dtype)
         x = torch.cat([vals.unsqueeze(1).expand(2, I, 1), item_feat.unsqueeze(0).expand(2, I, -1)], dim=2)
@@ -158,9 +159,21 @@ class MeanAbilityEncoder(nn.Module):
         w0, b0, w2, b2 = l0.weight, l0.bias, l2.weight, l2.bias
         if reducer is not None:      # person-sharded: these see only this rank's persons
             h, w0, b0, w2, b2 = (_SumGradAcrossRanks.apply(t, reducer) for t in (h, w0, b0, w2, b2))
-        obs = torch.ones_like(response) if mask is None else (mask != 0).to(response.dtype)
-        right = (response == 1).to(response.dtype) * obs
-        hid_mean = (obs @ h[0] + right @ (h[1] - h[0])) / obs.sum(1, keepdim=True)   # (no observed item: 0/0 = NaN like the reference)
+        if h.shape[2] == 64:
+            hid_sum, nobs = ops._BACKEND['cond_mean_sum'](h, response, mask, row_index)
+        else:
+            # other hidden widths: two dense GEMMs on the observed / correct indicator matrices (the GEMM library's job)
+            if isinstance(response, ops.CellCodes):
+                r, m = (response.rows(row_index) if row_index is not None else response).unpack()
+            else:
+                r = ops.prepare_response(response)
+                m = None if mask is None else ops.prepare_mask(mask)[0]
+                if row_index is not None:
+                    r, m = r[row_index], (None if m is None else m[row_index])
+            obs = torch.ones_like(r) if m is None else (m != 0).to(r.dtype)
+            right = (r == 1).to(r.dtype) * obs
+            hid_sum, nobs = obs @ h[0] + right @ (h[1] - h[0]), obs.sum(1)
+        hid_mean = hid_sum / nobs.unsqueeze(1)             # (no observed item: 0/0 = NaN like the reference)
         return F.linear(F.elu(F.linear(hid_mean, w0, b0)), w2, b2)
 
     def posterior(self, counts, reducer=None):
@@ -432,8 +445,7 @@ class VIBO_1PL(nn.Module):
             if counts is None:
                 counts = ops.row_counts(response, mask, row_index)
             return self.ability_encoder.posterior(counts, reducer=self._reducer)
-        r, m = self._dense_rows(response, mask, row_index)
-        return self.ability_encoder.posterior_conditional(r, m, item_feat, reducer=self._reducer)
+        return self.ability_encoder.posterior_conditional(response, mask, item_feat, reducer=self._reducer, row_index=row_index)
 
     def _posterior_from_counts(self, counts):
         """(mu, logvar) [B, A] of the unconditional product of experts (models.py:596-629, utils.py:105-113) from the packed
