@@ -15,7 +15,9 @@ import torch.multiprocessing as mp
 
 from conftest import GOLDEN_DIR, Golden, rel_err
 
-CASES = ['2pl_a8_uncond_miss_prior', '3pl_a1_cond_miss_drop', '2pl_a2_uncond_flows2_miss', '2pl_a2_uncond_mean_miss']
+CASES = ['2pl_a8_uncond_miss_prior', '3pl_a1_cond_miss_drop', '2pl_a2_uncond_flows2_miss', '2pl_a2_uncond_mean_miss',
+         # MLP decoders (models.py:769-919): autograd on the rank's persons + ONE flat gradient all-reduce (allreduce_grads)
+         '2pl_a2_deep_miss', '1pl_a3_residual_mean_miss_drop', '3pl_a2_link_flows2', '2pl_a2_cond_residual_miss']
 
 
 def _free_port():
@@ -56,7 +58,11 @@ def _worker(rank, world, port, case, out_path):
             loss = model.elbo(*outs, annealing_factor=m['annealing_factor'],
                               use_kl_divergence=m['use_kl_divergence'])
         loss.backward()
-        if m.get('ability_merge', 'product') == 'mean':
+        if m.get('generative_model', 'irt') != 'irt':
+            assert model.needs_grad_allreduce and len(calls) == 0
+            loss = model.allreduce_grads(loss)
+            assert len(calls) == 1, 'exactly one collective per step'
+        elif m.get('ability_merge', 'product') == 'mean':
             # the per-person posterior gradients stay local; scalars and item gradients are reduced in the forward,
             # the 8 small encoder tensors (mlp1 features, mlp2 weights / biases) in the backward
             assert 2 <= len(calls) <= 8 and max(calls) <= 64 * 64 + 2 * g.grad['item_encoder.mu_lookup.weight'].numel()

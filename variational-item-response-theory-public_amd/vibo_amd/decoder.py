@@ -67,8 +67,10 @@ class _DecoderLogLik(torch.autograd.Function):
     through in chunks of PERSON_CHUNK, the per-chunk partial records are summed here (fixed order)."""
 
     @staticmethod
-    def forward(ctx, response, mask, resid, U, V, L, guess, w1, W2, b2, w3, b3):
-        want_grad = any(t is not None and t.requires_grad for t in (U, V, L, guess, w1, W2, b2, w3, b3))
+    def forward(ctx, response, mask, resid, want_grad, U, V, L, guess, w1, W2, b2, w3, b3):
+        # (want_grad is decided by the caller: inside Function.forward grad mode is off and nn.Parameters always say
+        #  requires_grad -- under no_grad (test epochs, log_marginal's hundreds of samples) the GRAD kernel variant and its
+        #  ~1 GB of d V records per 65 536 persons were produced for nothing)
         Up, Vp, Lp, gp, w1p, W2p, b2p, w3p, b3p = (_prep(t) for t in (U, V, L, guess, w1, W2, b2, w3, b3))
         B = response.shape[0]
         ll = None
@@ -105,7 +107,7 @@ class _DecoderLogLik(torch.autograd.Function):
         o = ctx.out
         has_u, has_l, has_g, has_w1 = ctx.has
         dvec = o['dvec']
-        return (None, None, None,
+        return (None, None, None, None,
                 g * o['dU'] if has_u else None,
                 g * o['dV'],
                 g * o['dL'] if has_l else None,
@@ -127,7 +129,8 @@ def decoder_log_lik(response, mask, *, U, V, W2, b2, w3, b3, logit=None, w1=None
     """sum_{p,i} mask * log Bernoulli(response | P) of the per-term network (see the module docstring); differentiable in
     every tensor argument but response / mask.  response [B, I(, 1)] fp32, mask [B, I(, 1)] bool/u8 or None."""
     response, mask = _rows(response, mask)
-    return _DecoderLogLik.apply(response, mask, float(resid), U, V, logit, guess, w1, W2, b2, w3, b3)
+    want_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (U, V, logit, guess, w1, W2, b2, w3, b3))
+    return _DecoderLogLik.apply(response, mask, float(resid), want_grad, U, V, logit, guess, w1, W2, b2, w3, b3)
 
 
 @torch.no_grad()

@@ -41,44 +41,6 @@ def _encoder_mlp(in_dim, hidden_dim, out_dim):
     )
 
 
-class _TableMLP(torch.autograd.Function):
-    """Linear -> ELU -> Linear -> ELU -> Linear on the rows of the conditional expert table ([2I, 1 + D] inputs), with the
-    backward written out as GEMMs over row blocks of 1024 (weight and bias gradients: batched short-K products).  Same
-    arithmetic as nn.Sequential + autograd; the point is hipGraph capture: on this PyTorch / ROCm stack the captured
-    column reduction of a [>= 12 000, 64] gradient starts returning wrong bias gradients after a dozen replays
-    (tests/test_gpu_trainer.py::test_graphed_module_step_follows_the_eager_module_step, 12 800-row case)."""
-
-    @staticmethod
-    def forward(ctx, x, w0, b0, w1, b1, w2, b2):
-        h0 = F.elu(torch.addmm(b0, x, w0.t()))
-        h1 = F.elu(torch.addmm(b1, h0, w1.t()))
-        ctx.save_for_backward(x, w0, w1, w2, h0, h1)
-        return torch.addmm(b2, h1, w2.t())
-
-    @staticmethod
-    def _wgrad(g, x):
-        """g^T x and the column sums of g, rows taken 1024 at a time (batched GEMMs with a short contraction + a small
-        sum: no long-K GEMM / reduction kernel in the captured graph)."""
-        n = g.shape[0]
-        c = (n + 1023) // 1024
-        if c * 1024 != n:
-            g, x = F.pad(g, (0, 0, 0, c * 1024 - n)), F.pad(x, (0, 0, 0, c * 1024 - n))
-        g3, x3 = g.view(c, 1024, -1), x.view(c, 1024, -1)
-        return torch.bmm(g3.transpose(1, 2), x3).sum(0), g3.sum(1).sum(0)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, w0, w1, w2, h0, h1 = ctx.saved_tensors
-        g = g.contiguous()
-        gz1 = (g @ w2) * torch.where(h1 > 0, torch.ones_like(h1), h1 + 1.0)          # ELU' = 1 | e^z = h + 1
-        gz0 = (gz1 @ w1) * torch.where(h0 > 0, torch.ones_like(h0), h0 + 1.0)
-        gx = gz0 @ w0 if ctx.needs_input_grad[0] else None
-        gw0, gb0 = _TableMLP._wgrad(gz0, x)
-        gw1, gb1 = _TableMLP._wgrad(gz1, h0)
-        gw2, gb2 = _TableMLP._wgrad(g, h1)
-        return gx, gw0, gb0, gw1, gb1, gw2, gb2
-
-
 class AbilityEncoder(nn.Module):
     """Holds ``mlp`` (keys ability_encoder.mlp.{0,2,4}.*; models.py:575-582).
 
@@ -359,6 +321,7 @@ class VIBO_1PL(nn.Module):
         self.apply(self.weights_init)
 
         self._reducer = None          # set by enable_person_sharding()
+        self._shard_world = 1
         self._last_ctx = None         # the most recent fused step (elbo() with a materialised response_mu finds it here)
         self._last_eps_item = None
         self._item_gen = None
@@ -372,12 +335,19 @@ class VIBO_1PL(nn.Module):
             nn.init.xavier_normal_(m.weight.data, gain=nn.init.calculate_gain('relu'))
             nn.init.constant_(m.bias.data, 0)
 
-    def enable_person_sharding(self, reducer, seed, rank):
+    def enable_person_sharding(self, reducer, seed, rank, world=None):
         """Data parallelism over persons: `reducer(flat)` all-reduces (sum) the
         kernel's flat [scalars | grads] buffer in place.  Item noise must be
-        identical on every rank, ability noise must differ: dedicated generators."""
+        identical on every rank, ability noise must differ: dedicated generators.
+        MLP-decoder models (--generative-model link | deep | residual) take their gradients from autograd on this rank's
+        persons: their loss counts the replicated item-side terms 1 / world times and `allreduce_grads()` (one flat
+        collective per step, called by the training loop after backward) sums every parameter gradient over the ranks."""
         self._reducer = reducer
         self._shard_rank = int(rank)
+        if world is None:
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._shard_world = int(world)
         dev = self.item_encoder.mu_lookup.weight.device
         self._item_gen = torch.Generator(device=dev).manual_seed(int(seed))
         self._ability_gen = torch.Generator(device=dev).manual_seed(int(seed) + 1 + int(rank))
@@ -438,14 +408,15 @@ class VIBO_1PL(nn.Module):
         self._last_ctx = ctx
         return ctx
 
-    def _mean_posterior(self, response, mask, row_index, item_feat, counts=None):
+    def _mean_posterior(self, response, mask, row_index, item_feat, counts=None, reduce_in_backward=True):
         """(mu | logvar) [B, 2A] of the --ability-merge mean encoder: from the row counts, or (conditional posterior) from
-        the minibatch's dense rows and the item sample."""
+        the minibatch's rows and the item sample.  reduce_in_backward=False: the caller sums all gradients itself."""
+        reducer = self._reducer if reduce_in_backward else None
         if not self.conditional_posterior:
             if counts is None:
                 counts = ops.row_counts(response, mask, row_index)
-            return self.ability_encoder.posterior(counts, reducer=self._reducer)
-        return self.ability_encoder.posterior_conditional(response, mask, item_feat, reducer=self._reducer, row_index=row_index)
+            return self.ability_encoder.posterior(counts, reducer=reducer)
+        return self.ability_encoder.posterior_conditional(response, mask, item_feat, reducer=reducer, row_index=row_index)
 
     def _posterior_from_counts(self, counts):
         """(mu, logvar) [B, A] of the unconditional product of experts (models.py:596-629, utils.py:105-113) from the packed
@@ -490,12 +461,11 @@ class VIBO_1PL(nn.Module):
 
     def _run_decoder(self, response, mask, *, eps_item=None, eps_ability=None, row_index=None):
         """forward() with a per-term MLP decoder: item sample, posterior from the row counts, sample, flows."""
-        if self._reducer is not None:
-            raise NotImplementedError('person sharding covers --generative-model irt')
+        # (person-sharded: plain autograd on this rank's persons; allreduce_grads() sums the gradients after backward)
         item_feat, item_mu, item_lv = self._item_side(eps_item)
         if self.ability_merge == 'mean':
             counts = None if self.conditional_posterior else ops.row_counts(response, mask, row_index)
-            amu, alv = torch.chunk(self._mean_posterior(response, mask, row_index, item_feat, counts), 2, dim=1)
+            amu, alv = torch.chunk(self._mean_posterior(response, mask, row_index, item_feat, counts, reduce_in_backward=False), 2, dim=1)
         elif self.conditional_posterior:
             amu, alv = self._conditional_posterior_dense(response, mask, row_index, item_feat)
         else:
@@ -591,21 +561,46 @@ class VIBO_1PL(nn.Module):
         return -(ll + log_p_d - reg - log_q_d)
 
     def _decoder_elbo(self, ctx, annealing_factor, use_kl_divergence):
-        """models.py:380-443 with the decoder kernel's log-likelihood; the small per-person / per-item terms are autograd."""
+        """models.py:380-443 with the decoder kernel's log-likelihood; the small per-person / per-item terms are autograd.
+        Person-sharded: this rank's persons and 1 / world of the (replicated) item-side terms -- the ranks' losses and
+        gradients add up to the unsharded ones (allreduce_grads)."""
         ll = ctx.ll
+        iw = 1.0 / self._shard_world if self._reducer is not None else 1.0
         if self.n_norm_flows > 0:
             log_q = (_normal_logpdf(ctx.ability, ctx.ability_mu, ctx.ability_logvar).sum() - ctx.ability_ladj.sum()
-                     + _normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum() - ctx.item_ladj.sum())
-            log_p = ll + _std_normal_logpdf(ctx.ability_k).sum() + _std_normal_logpdf(ctx.item_k).sum()
+                     + iw * (_normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum() - ctx.item_ladj.sum()))
+            log_p = ll + _std_normal_logpdf(ctx.ability_k).sum() + iw * _std_normal_logpdf(ctx.item_k).sum()
             return -(log_p - log_q)
         if use_kl_divergence:
             kl_u = (-0.5 * (1.0 + ctx.ability_logvar - ctx.ability_mu.pow(2) - ctx.ability_logvar.exp())).sum()
             kl_d = (-0.5 * (1.0 + ctx.item_lv - ctx.item_mu.pow(2) - ctx.item_lv.exp())).sum()
-            return -(ll - annealing_factor * kl_u - annealing_factor * kl_d)
-        log_p = ll + _std_normal_logpdf(ctx.ability).sum() + _std_normal_logpdf(ctx.item_feat).sum()
+            return -(ll - annealing_factor * kl_u - annealing_factor * iw * kl_d)
+        log_p = ll + _std_normal_logpdf(ctx.ability).sum() + iw * _std_normal_logpdf(ctx.item_feat).sum()
         log_q = (_normal_logpdf(ctx.ability, ctx.ability_mu, ctx.ability_logvar).sum()
-                 + _normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum())
+                 + iw * _normal_logpdf(ctx.item_feat, ctx.item_mu, ctx.item_lv).sum())
         return -(log_p - log_q)
+
+    @property
+    def needs_grad_allreduce(self):
+        """True for a person-sharded MLP-decoder model: call allreduce_grads() between backward() and the optimizer step."""
+        return self._reducer is not None and self.generative_model != 'irt'
+
+    def allreduce_grads(self, loss=None):
+        """Sum every parameter gradient (and, if given, the detached loss) over the person shards: ONE flat collective."""
+        ps = [p for p in self.parameters() if p.requires_grad]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps]
+                         + ([loss.detach().reshape(1)] if loss is not None else []))
+        self._reducer(flat)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        return flat[off] if loss is not None else None
 
     def log_marginal(self, response, mask, num_samples=100, eps_item=None, eps_ability=None):
         """Importance-weighted bound with batch-level weights (models.py:445-504).  eps_item [S,I,D] / eps_ability
@@ -681,10 +676,15 @@ class VIBO_1PL(nn.Module):
         out = self.forward(response, mask, row_index=row_index)
         if self.n_norm_flows > 0:
             (r, m, rmu, ak, a0, amu, alv, aladj, ik, i0, imu, ilv, iladj) = out
-            return self.elbo(r, m, rmu, a0, amu, alv, i0, imu, ilv, annealing_factor=annealing_factor,
+            loss = self.elbo(r, m, rmu, a0, amu, alv, i0, imu, ilv, annealing_factor=annealing_factor,
                              use_kl_divergence=False, ability_k=ak, item_feat_k=ik,
                              ability_logabsdetjac=aladj, item_logabsdetjac=iladj)
-        return self.elbo(*out, annealing_factor=annealing_factor, use_kl_divergence=True)
+        else:
+            loss = self.elbo(*out, annealing_factor=annealing_factor, use_kl_divergence=True)
+        # the step's context (autograd graph, row references, the decoder kernel's gradient records) has been consumed: do not
+        # keep it alive until the next forward (it exists for elbo() calls with a materialised response_mu)
+        self._last_ctx = None
+        return loss
 
 
 class VIBO_2PL(VIBO_1PL):

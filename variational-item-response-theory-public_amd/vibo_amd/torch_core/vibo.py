@@ -293,6 +293,8 @@ def train_epoch(model, optimizer, data, args, epoch, batch_size, trainer=None, g
             optimizer.zero_grad(set_to_none=True)
             loss = model.elbo_step(data.response, data.mask, annealing_factor=beta, row_index=rows)
             loss.backward()
+            if getattr(model, 'needs_grad_allreduce', False):      # person-sharded MLP-decoder model: one flat collective
+                loss = model.allreduce_grads(loss)
             optimizer.step()
         wsum += loss.detach() * rows.numel()          # AverageMeter weighting (vibo.py:270), one sync per epoch
         count += rows.numel()
@@ -441,6 +443,15 @@ def main(argv=None):
     local_bs = max(1, args.batch_size // world)
     # steps per epoch: identical on every rank (one all-reduce per step), derived from the largest shard
     n_batches = train.num_batches(local_bs, train_dataset.num_person, world)
+    if world > 1:
+        # every rank must be able to cut its shard into that many minibatches -- decided from the shard sizes every rank can
+        # compute, BEFORE the first collective (a rank that raised alone would leave its peers hanging in their all-reduce)
+        for name, n_total, bs_steps in (('train', train_dataset.num_person, n_batches),
+                                        ('test', test_dataset.num_person, test.num_batches(local_bs, test_dataset.num_person, world))):
+            smallest = min((r + 1) * n_total // world - r * n_total // world for r in range(world))
+            if smallest < bs_steps:
+                raise SystemExit(f'{name} split: the smallest person shard has {smallest} rows for {bs_steps} steps per epoch over '
+                                 f'{world} ranks: raise --batch-size or use fewer ranks')
     n_train_steps = n_batches if world > 1 else None
     n_test_steps = test.num_batches(local_bs, test_dataset.num_person, world) if world > 1 else None
     if args.max_iters != -1:
