@@ -15,14 +15,17 @@ from vibo_amd.trainer import FusedTrainer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES],
-                ids=['matrix-kernel', 'valu-kernel', 'matrix-kernel-fp32-passes'])
+@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU,
+                        _lib.FLAG_KERNEL_VALU],
+                ids=['matrix-kernel', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-matrix-posterior'])
 def row_split_kernel_choice(request, monkeypatch):
     """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
     above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; vibo_desc.flags pins one for the whole test
     (ops.DESC_FLAGS: the library reads no environment variable).  Third run: the multi-pass paths (conditional posterior, more
     than 1024 items) re-read the fp32 rows in every pass instead of the 1-byte cell codes their first pass leaves behind
-    (VIBO_FLAG_NO_EMIT_CODES)."""
+    (VIBO_FLAG_NO_EMIT_CODES).  The conditional posterior's two passes have a matrix-pipe form (vibo_cmean.hip, the default
+    for 4 096 persons or more whose rows are cell codes) and a VALU form (vibo_cond.hip, VIBO_FLAG_COND_VALU): the second and
+    third runs pin the VALU form, the fourth the VALU row-split kernel around whatever the planner picks."""
     monkeypatch.setattr(ops, 'DESC_FLAGS', request.param)
 dev = torch.device('cuda:0')
 

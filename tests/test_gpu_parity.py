@@ -21,14 +21,17 @@ from vibo_amd.ops import ElboSpec
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES],
-                ids=['matrix-kernel', 'valu-kernel', 'matrix-kernel-fp32-passes'])
+@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU,
+                        _lib.FLAG_KERNEL_VALU],
+                ids=['matrix-kernel', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-matrix-posterior'])
 def row_split_kernel_choice(request, monkeypatch):
     """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
     above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; vibo_desc.flags pins one for the whole test
     (ops.DESC_FLAGS: the library reads no environment variable).  Third run: the multi-pass paths (conditional posterior, more
     than 1024 items) re-read the fp32 rows in every pass instead of the 1-byte cell codes their first pass leaves behind
-    (VIBO_FLAG_NO_EMIT_CODES)."""
+    (VIBO_FLAG_NO_EMIT_CODES).  The conditional posterior's two passes have a matrix-pipe form (vibo_cmean.hip, the default
+    for 4 096 persons or more whose rows are cell codes) and a VALU form (vibo_cond.hip, VIBO_FLAG_COND_VALU): the second and
+    third runs pin the VALU form, the fourth the VALU row-split kernel around whatever the planner picks."""
     monkeypatch.setattr(ops, 'DESC_FLAGS', request.param)
 
 TOL_ELBO = 1e-4
@@ -563,6 +566,70 @@ def test_wide_conditional_posterior_is_deterministic(A, I, codes):
     torch.cuda.synchronize()
     assert torch.equal(a.flat, b.flat) and torch.equal(a.grad_table(0), b.grad_table(0))
     compare_raw(a, ref, (I, A + 1))
+
+
+MATRIX_PIPE_POSTERIOR = [
+    # irt, A, B, I, flows, gather, codes, drop
+    (2, 1, 4100, 1000, 0, False, True, False),     # caller's cell codes: both passes on the matrix pipe
+    (2, 8, 4100, 1000, 0, True, True, False),      # rows through row_index, 2 N-tiles of coefficients
+    (3, 3, 4500, 95, 2, False, False, True),       # fp32 rows, 3 dims: count-and-emit pass in front; one whole step + a 31-item tail
+    (2, 2, 4100, 200, 0, False, False, False),     # fp32 rows, 2 dims: VALU pre pass (emits the codes) + matrix-pipe post pass
+    (2, 5, 4200, 1500, 0, True, False, False),     # more than one 1024-item panel around all-item passes
+    (1, 4, 5000, 63, 0, False, True, False),       # fewer than 64 items: only the partial step
+    (2, 1, 4096, 64, 0, False, True, False),       # exactly one whole step, nothing else
+]
+
+
+@pytest.mark.parametrize('irt,A,B,I,n_flows,gather,codes,drop', MATRIX_PIPE_POSTERIOR)
+def test_matrix_pipe_passes_of_the_conditional_posterior(irt, A, B, I, n_flows, gather, codes, drop, monkeypatch):
+    """From 4 096 persons per call the two extra passes of --conditional-posterior (the experts' precision sums per person,
+    models.py:664-710 + utils.py:105-113, and the scatter of the table gradient) run as one-hot x table contractions on the
+    matrix pipe (vibo_cmean.hip): against the fp64 oracle, bit-identical between runs, and in agreement with the VALU passes
+    (VIBO_FLAG_COND_VALU) the smaller calls keep."""
+    kernel = ops.DESC_FLAGS & (_lib.FLAG_KERNEL_MATRIX | _lib.FLAG_KERNEL_VALU)
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=True, n_flows=n_flows, drop_missing=drop)
+    resp, mask, table, item, eps = random_problem(irt, A, B + 9, I, 0.2, seed=A * I + B, cond=True)
+    if drop:
+        mask[:, 0] = 1
+        resp[:, 0] = resp[:, 0].clamp(min=0)
+    g = torch.Generator().manual_seed(I)
+    flow = torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5 if n_flows else None
+    flows = [(f_[:A].double(), f_[A:2 * A].double(), f_[2 * A:].double()) for f_ in flow] if n_flows else None
+    rows = torch.randperm(B + 9, generator=g)[:B] if gather else torch.arange(B)
+    ref = T.fused_elbo_ref(table.double(), item.double(), resp[rows].double(), mask[rows], eps.double()[:B], irt_model=irt,
+                           ability_dim=A, conditional_posterior=True, replace_missing_with_prior=not drop,
+                           mode='sampled' if n_flows else 'kl', flow_uhat_w_b=flows)
+    d = dev()
+    reg = _lib.REG_SAMPLED if n_flows else _lib.REG_KL
+    ri = rows.to(d) if gather else None
+    if not gather:
+        resp, mask = resp[:B], mask[:B]
+    if codes:
+        r = m = ops.pack_cell_codes(resp.to(d), mask.to(d)).codes
+        code = _lib.MASK_CODES
+    else:
+        r_, m_ = ops.pad_rows(resp.to(d), mask.bool().to(d))          # 16-byte rows: the row-split path (95 items: padded strides)
+        r, m, code = ops.prepare_rows(r_, m_)
+    args = (spec, r, m, code, ri, table.to(d).contiguous(), item.to(d).contiguous(), eps[:B].to(d).contiguous(),
+            flow.to(d).contiguous() if flow is not None else None, reg)
+
+    def run(flags, want_grad=True):
+        monkeypatch.setattr(ops, 'DESC_FLAGS', kernel | flags)
+        out = ops._hip_launch_elbo(*args, want_grad, B)
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run(0), run(0)
+    assert torch.equal(a.flat, b.flat) and torch.equal(a.ability_mu, b.ability_mu)
+    compare_raw(a, ref, (I, spec.item_dim), tol=5e-4)
+    v = run(_lib.FLAG_COND_VALU)
+    assert (a.ability_mu - v.ability_mu).abs().max() < 1e-5 * max(1.0, float(v.ability_mu.abs().max()))
+    assert (a.ability_logvar - v.ability_logvar).abs().max() < 1e-5 * max(1.0, float(v.ability_logvar.abs().max()))
+    for s_ in range(2):
+        assert rel_err(a.grad_table(s_), v.grad_table(s_)) < 2e-5
+    f = run(0, want_grad=False)                      # forward only: the same posterior and scalars
+    assert torch.equal(f.ability_mu, a.ability_mu) and torch.equal(f.ability_logvar, a.ability_logvar)
+    assert rel_err(f.scalars[_lib.S_LL], a.scalars[_lib.S_LL]) < 1e-6
 
 
 @pytest.mark.parametrize('irt,A,I,cond,n_flows', [(2, 1, 95, False, 0), (2, 8, 1003, False, 0), (3, 2, 333, False, 2),

@@ -24,13 +24,13 @@ rows = con.execute(f'select d.id, k.{name_col}, d.start, d.end, d.grid_size_x, d
 by = defaultdict(list)
 info = {}
 for did, name, s, e, gx, wx, lds, scr in rows:
-    short = name.split('(')[0][-70:]
+    if flt and flt not in name:
+        continue
+    short = name.split('(')[0][:70]
     by[short].append((e - s) / 1e3)
     info[short] = (gx, wx, lds, scr)
 print(f'{"kernel":72s} {"calls":>5s} {"avg_us":>10s} {"min_us":>10s} {"max_us":>10s}  grid wg lds scratch')
 for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
-    if flt and flt not in k:
-        continue
     print(f'{k:72s} {len(v):5d} {sum(v)/len(v):10.1f} {min(v):10.1f} {max(v):10.1f}  {info[k]}')
 n = con.execute(f'select count(*) from {T("rocpd_pmc_event")}').fetchone()[0]
 if n:
@@ -41,7 +41,7 @@ if n:
     nd = {k: len(v) for k, v in by.items()}
     print('\nPMC (sum over dispatches / number of dispatches):')
     for name, ctr, val, cnt in pm:
-        short = name.split('(')[0][-70:]
-        if flt and flt not in short:
+        if flt and flt not in name:
             continue
-        print(f'  {short[-52:]:52s} {ctr:28s} {val / nd[short]:16.0f}')
+        short = name.split('(')[0][:70]
+        print(f'  {short[:52]:52s} {ctr:28s} {val / nd[short]:16.0f}')

@@ -51,7 +51,7 @@ static int check_desc(const vibo_desc* d) {
     if (d->reg_mode != VIBO_REG_KL && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "bad reg_mode");
     if (d->n_flows < 0 || d->n_flows > VIBO_MAX_FLOWS) return fail(-3, "n_flows outside 0..%d", VIBO_MAX_FLOWS);
     if (d->n_flows > 0 && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "flows need reg_mode SAMPLED");
-    if (d->flags & ~(VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX | VIBO_FLAG_NO_EMIT_CODES)) return fail(-3, "unknown flags");
+    if (d->flags & ~(VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX | VIBO_FLAG_NO_EMIT_CODES | VIBO_FLAG_COND_VALU)) return fail(-3, "unknown flags");
     if ((d->flags & VIBO_FLAG_KERNEL_VALU) && (d->flags & VIBO_FLAG_KERNEL_MATRIX)) return fail(-3, "flags pin two kernels");
     return 0;
 }
@@ -69,6 +69,7 @@ struct Plan {
     int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
     size_t off_cnt;           // panel mode: per-person packed counts of the whole row
     bool cond;                // panel mode with the conditional posterior: cond_pre / split / cond_post per panel
+    bool cmat_pre, cmat_post; // ... whose first / last pass runs on the matrix pipe from the cell codes, all items at once (vibo_cmean.hip)
     bool given;               // panel mode with a caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN)
     size_t off_pre, off_coef, off_cpart;
     size_t off_codes;         // fp32 rows read by more than one pass: the first pass's 1-byte cell codes [B][codes_stride] (0: not used)
@@ -202,6 +203,17 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         pl->panels = (I + 1023) / 1024;
         pl->cond = is_cond;
         pl->given = is_given;
+        // the conditional posterior's passes on the matrix pipe need the rows as cell codes: the caller's, or the ones the
+        // first pass over fp32 rows leaves behind
+        // (launch-bound minibatches stay on the VALU passes: two launches fewer).  Measured on 1M x 1k, per pass:
+        //   rows = cell codes:  pre 285 us vs 506 (A = 1) / 2 x 475 (A = 8), post 330 vs 400 (A = 1) / 2 x 990 (A = 8)
+        //   rows = fp32:        the VALU pre pass reads the rows AND leaves the codes behind (1.22 ms = the 5 B/cell stream);
+        //                       a count-and-emit pass in front of the matrix-pipe pre pass costs the same 1.25 ms again, so
+        //                       the VALU pre pass stays up to 2 ability dims (one launch at template width <= 2)
+        const bool have_codes = d->mask_dtype == VIBO_MASK_CODES || (emit_codes_wanted(d) && d->mask_dtype != VIBO_MASK_I64);
+        const bool cmat_ok = is_cond && !(d->flags & VIBO_FLAG_COND_VALU) && have_codes && d->num_person >= 4096;
+        pl->cmat_post = cmat_ok && d->want_grad;
+        pl->cmat_pre = cmat_ok && (d->mask_dtype == VIBO_MASK_CODES || A >= 3);
         const int at_min = 2;
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
@@ -235,7 +247,8 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
             pl->off_coef = off;
             off += up((size_t)pl->panels * d->num_person * 4 * A * 4);
             pl->off_cpart = off;
-            {
+            if (pl->cmat_pre || pl->cmat_post) off += up(cond_mfma_scratch_bytes(d->num_person, I, A));
+            if (!pl->cmat_post) {
                 // cond_post on cell codes (the caller's, or the ones cond_pre leaves behind) has no fp32 row registers: 3 waves per SIMD
                 const bool post_codes = d->mask_dtype == VIBO_MASK_CODES ||
                                         (emit_codes_wanted(d) && d->mask_dtype != VIBO_MASK_I64);
@@ -243,8 +256,8 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
                     pl->cond_post_nblk = num_cu * 3;
                     if (pl->cond_post_nblk > (d->num_person + 7) / 8) pl->cond_post_nblk = (d->num_person + 7) / 8;
                 }
+                off += up((size_t)pl->panels * pl->cond_post_nblk * pl->cond_rec * 4);
             }
-            off += up((size_t)pl->panels * pl->cond_post_nblk * pl->cond_rec * 4);
         } else if (is_given) {
             pl->off_pre = off;
             off += up((size_t)d->num_person * (2 * A + 1) * 4);
@@ -927,6 +940,8 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
         float* pre = reinterpret_cast<float*>(wsb + pl.off_pre);
         float* coef = reinterpret_cast<float*>(wsb + pl.off_coef);
         float* cpart = reinterpret_cast<float*>(wsb + pl.off_cpart);
+        void* mscratch = cpart;          // matrix-pipe passes: images + records first, the VALU post pass's records (if any) behind
+        if (pl.cmat_pre && !pl.cmat_post) cpart = reinterpret_cast<float*>(wsb + pl.off_cpart + ((cond_mfma_scratch_bytes(d->num_person, I, A) + 255) & ~(size_t)255));
         CondParams cp;
         memset(&cp, 0, sizeof(cp));
         const int cond_blocks = pl.cond_nblk;
@@ -948,6 +963,25 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
             p.pre_stats = pre;
             p.pre_panels = 1;
             p.table = item;               // the 2-row expert table is not used in this mode: any finite floats (>= 4 A of them)
+        } else if (pl.cmat_pre) {
+            // matrix-pipe pre pass: fp32 rows are turned into cell codes first (one streaming pass, minibatch order)
+            const uint8_t* crows = static_cast<const uint8_t*>(mask);
+            long long cstride = d->mask_row_stride;
+            const int64_t* cidx = row_index;
+            if (emit) {
+                int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
+                int cgrid = num_cu * 8;
+                if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
+                hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
+                                   (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype,
+                                   code_rows, (long long)pl.codes_stride);
+                e = hipGetLastError();
+                crows = code_rows; cstride = pl.codes_stride; cidx = nullptr;
+            }
+            if (e == hipSuccess)
+                e = launch_cond_pre_mfma(crows, cstride, cidx, d->num_person, I, A, table, pre, mscratch, s);
+            p.pre_stats = pre;
+            p.pre_panels = 1;
         } else if (pl.cond) {
             for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
                 cp.item0 = pn * 1024;
@@ -1005,14 +1039,20 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                 e = hipGetLastError();
                 cp.coef_panels = 1;
             }
-            for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
-                cp.item0 = pn * 1024;
-                cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
-                cp.partial = cpart + (size_t)pn * pl.cond_post_nblk * pl.cond_rec;
-                for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
-                    e = launch_cond_post(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.cond_post_nblk, s);
+            if (pl.cmat_post) {
+                if (e == hipSuccess)
+                    e = launch_cond_post_mfma(static_cast<const uint8_t*>(cp.mask), cp.mask_stride, cp.row_index, d->num_person, I, A, table,
+                                              coef, grad_table, mscratch, s);
+            } else {
+                for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
+                    cp.item0 = pn * 1024;
+                    cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
+                    cp.partial = cpart + (size_t)pn * pl.cond_post_nblk * pl.cond_rec;
+                    for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
+                        e = launch_cond_post(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.cond_post_nblk, s);
+                }
+                if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.cond_post_nblk, pl.cond_rec, s);
             }
-            if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.cond_post_nblk, pl.cond_rec, s);
         }
         if (pl.given && grad && e == hipSuccess) {
             const long long n = (long long)d->num_person * A;

@@ -1,285 +1,639 @@
-// vibo_cmean.hip -- --ability-merge mean WITH --conditional-posterior (models.py:664-710 with _forward_mean :631-650):
-// the per-term feature depends on the item, h[c, i, :] = elu(mlp1([c, item_i])) in R^H, and a person's encoder input is the
-// mean of h over its observed cells.  The sum over the cells is the one genuinely dense contraction of the VIBO encoder:
+// vibo_cmean.hip -- the two dense contractions of the VIBO encoder over a person's observed cells, on the matrix pipe.
 //
-//     S[p, :]  = sum_i [cell (p, i) observed] h[code_pi, i, :]          = onehot(codes) [B, 2I] x h [2I, H]
-//     dh[c, i, :] = sum_p [code_pi == c] G[p, :]                         = onehot(codes)^T [2I, B] x G [B, H]
+// With --conditional-posterior (models.py:664-710) every per-term quantity of the encoder depends on the response code AND the
+// item, X[c, i, :], and a person needs its sum over the observed cells; the transposed sum is the gradient:
 //
-// Both run on the matrix pipe (v_mfma_f32_16x16x32_f16) straight from the 1-byte cell codes (0 wrong / 1 right / 2 missing):
-// the one-hot operand is exact in f16, the dense operand (h, or the upstream gradient G) goes in as hi + lo f16 pieces
-// (round toward zero, |x - hi - lo| <= 2^-22 |x|) with fp32 accumulation -- fp32-grade, like the matrix ELBO kernel.
-// Round 2 did this as two rocBLAS GEMMs on materialised fp32 indicator matrices (three extra passes over the rows).
+//     S[p, :]     = sum_i [cell (p, i) observed] X[code_pi, i, :]        = onehot(codes) [B, 2I] x X [2I, N]
+//     dX[c, i, :] = sum_p [code_pi == c] G[p, :]                          = onehot(codes)^T [2I, B] x G [B, N]
+//
+// Two users:
+//   * --ability-merge mean (_forward_mean :631-650): X = elu(mlp1([c, item_i])) in R^64, G = the upstream gradient of the
+//     row sums  (N = 64; exported as vibo_code_table_sum_forward / _backward);
+//   * --ability-merge product (the product of experts of the conditional posterior, models.py:664-710 + utils.py:105-113):
+//     X = [tau | mu tau] with tau = 1/(exp(logvar) + eps) (N = 2 A <= 16: the precision and the precision-weighted mean of a
+//     person's experts, plus the observed count), G = the ELBO kernel's per-person coefficients [head][P1 | P2][dim]
+//     (N = 4 A <= 32), from which d/d mu = S1 tau, d/d logvar = -(S1 mu + S2) tau^2 exp(logvar)  (launch_cond_pre_mfma /
+//     launch_cond_post_mfma, called by vibo_capi.hip around the row-split kernel; round 2 ran these as VALU kernels with one
+//     register accumulator per (item, code, coefficient): two launches each at ability_dim 5..8, 4.8 ms at 1M x 1k A = 8).
+//
+// Both run on v_mfma_f32_16x16x32_bf16 straight from the 1-byte cell codes (0 wrong / 1 right / 2 missing).  The one-hot
+// operand is exact (entries 2.0 = bf16 0x4000, a byte permute away from the code bits); the dense operand goes in as THREE
+// bf16 pieces hi + mid + lo of 0.5 x (truncation: 8 + 8 + 8 significant bits, |x - pieces| <= 2^-24 |x|) with fp32
+// accumulation.  bf16 has fp32's exponent range, so no operand rescaling and no range fault: an Inf / NaN input stays
+// Inf / NaN in the output (x - hi is NaN then).
 //
 // Operand layouts (16x16x32: A lane (row = lane & 15, g = lane >> 4) holds k = 8 g .. 8 g + 7; B lane (col = lane & 15, g)
 // likewise; D lane (col = lane & 15, g) holds rows 4 g .. 4 g + 3):
 //   * K order of the forward, per super-step S of 64 items: K-step j in 0..3, lane group g, kk in 0..7 <-> item
 //     64 S + 16 g + 4 j + (kk >> 1), code kk & 1 -- so that a lane's four K-steps are the four dwords of ONE 16-byte load of
 //     its person's code row (a wave reads 16 rows x 64 contiguous bytes per load);
-//   * the dense operands are pre-arranged once per call into "images" whose 16-byte lane pieces are contiguous per wave load.
-// H = 64 (the reference's --hidden-dim default); other widths stay on the GEMM path of the caller.
+//   * the dense operands are pre-arranged once per call into "images" whose 16-byte lane pieces are contiguous per wave load;
+//   * the backward's one-hot^T operand comes out of an LDS tile [64 persons][128 (item, code) columns] by
+//     ds_read_b64_tr_b16 (the 4 x 16 block of a 16-lane group is 4 persons x 16 columns; a lane receives its column's 4 persons).
+// NT = N-tiles of 16 output columns (1, 2 or 4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
+#include "vibo_cond.hpp"
 
 namespace vibo {
 
-typedef _Float16 cm_half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cm_bf8 __attribute__((ext_vector_type(8)));
 typedef float cm_f32x4 __attribute__((ext_vector_type(4)));
+typedef short cm_s4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cm_u4 __attribute__((ext_vector_type(4)));
 constexpr int kCmH = 64;
+constexpr int kCmNP = 3;                // bf16 pieces per fp32 value
 
-__device__ __forceinline__ void cm_split(float x, _Float16& hi, _Float16& lo) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x, 0.f));
-    hi = a[0];
-    lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x - (float)a[0], 0.f))[0];
+// 8 fp32 values (x 0.5: the one-hot entries are 2.0) -> three bf16 piece vectors, element kk in half kk
+__device__ __forceinline__ void cm_split3(const float (&v)[8], uint4& hi, uint4& mid, uint4& lo) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const float x = 0.5f * v[kk];
+        h[kk] = __float_as_uint(x) & 0xffff0000u;
+        const float r = x - __uint_as_float(h[kk]);
+        m[kk] = __float_as_uint(r) & 0xffff0000u;
+        const float r2 = r - __uint_as_float(m[kk]);
+        l[kk] = __float_as_uint(r2) & 0xffff0000u;
+    }
+    hi = uint4{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]};
+    mid = uint4{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]};
+    lo = uint4{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3], (l[4] >> 16) | l[5], (l[6] >> 16) | l[7]};
 }
-// 4 cell codes (one dword) -> the 8 one-hot halfs [c0 == 0, c0 == 1, c1 == 0, c1 == 1, ...] (f16 1.0 = 0x3C00)
-__device__ __forceinline__ cm_half8 cm_onehot(const uint32_t w) {
+// 4 cell codes (one dword) -> the 8 one-hot bf16 [c0 == 0, c0 == 1, c1 == 0, c1 == 1, ...] with entries 2.0 (0x4000)
+__device__ __forceinline__ uint4 cm_onehot(const uint32_t w) {
     const uint32_t e1 = w & 0x01010101u;                                 // code == 1
     const uint32_t e0 = ~(w | (w >> 1)) & 0x01010101u;                   // code == 0
-    const uint32_t t0 = __builtin_amdgcn_perm(0u, 0x00003C00u, e0);      // bytes 0x3C where the cell is a 0
-    const uint32_t t1 = __builtin_amdgcn_perm(0u, 0x00003C00u, e1);
+    const uint32_t t0 = __builtin_amdgcn_perm(0u, 0x00004000u, e0);      // bytes 0x40 where the cell is a 0
+    const uint32_t t1 = __builtin_amdgcn_perm(0u, 0x00004000u, e1);
     // cell b -> dword [0x00, t0.b, 0x00, t1.b]  (perm: S0 = t1 -> bytes 4..7, S1 = t0 -> bytes 0..3, 0x0c = constant 0)
-    uint32_t d[4];
-    d[0] = __builtin_amdgcn_perm(t1, t0, 0x040c000cu);
-    d[1] = __builtin_amdgcn_perm(t1, t0, 0x050c010cu);
-    d[2] = __builtin_amdgcn_perm(t1, t0, 0x060c020cu);
-    d[3] = __builtin_amdgcn_perm(t1, t0, 0x070c030cu);
-    return __builtin_bit_cast(cm_half8, uint4{d[0], d[1], d[2], d[3]});
+    return uint4{__builtin_amdgcn_perm(t1, t0, 0x040c000cu), __builtin_amdgcn_perm(t1, t0, 0x050c010cu),
+                 __builtin_amdgcn_perm(t1, t0, 0x060c020cu), __builtin_amdgcn_perm(t1, t0, 0x070c030cu)};
 }
-__device__ __forceinline__ cm_f32x4 cm_mfma(const cm_half8 a, const cm_half8 b, const cm_f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ cm_f32x4 cm_mfma(const uint4 a, const uint4 b, const cm_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cm_bf8, a), __builtin_bit_cast(cm_bf8, b), c, 0, 0, 0);
 }
 
 // ---- images -----------------------------------------------------------------------------------------------------------
-// forward B operand: img[(((S * 4 + j) * 4 + nt) * 2 + plane) * 64 + lane] = half8 over kk of h[kk & 1][item][16 nt + (lane & 15)]
-__global__ __launch_bounds__(256) void cm_table_image_kernel(const float* __restrict__ h /* [2][I][64] */, cm_half8* __restrict__ img, int I, int nS) {
+// forward B operand: img[(((S * 4 + j) * NT + nt) * 3 + piece) * 64 + lane] = 8 pieces over kk of X[kk & 1][item][16 nt + (lane & 15)]
+// COND: X is built from the encoder table [2][I][2A] (mu | logvar): columns [0, A) tau, [A, 2A) mu tau (utils.py:105-113)
+template <bool COND>
+__global__ __launch_bounds__(256) void cm_table_image_kernel(const float* __restrict__ src, uint4* __restrict__ img, int I, int nS, int NT,
+                                                             int ncols) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nS * 4 * 4 * 64) return;
-    const int lane = t & 63, nt = (t >> 6) & 3, j = (t >> 8) & 3, S = t >> 10;
-    const int n = lane & 15, g = lane >> 4;
-    cm_half8 hi, lo;
+    if (t >= nS * 4 * NT * 64) return;
+    const int lane = t & 63, nt = (t >> 6) % NT, j = ((t >> 6) / NT) & 3, S = (t >> 6) / (NT * 4);
+    const int n = 16 * nt + (lane & 15), g = lane >> 4;
+    float v[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const int item = 64 * S + 16 * g + 4 * j + (kk >> 1), c = kk & 1;
-        const float v = item < I ? h[((size_t)c * I + item) * kCmH + 16 * nt + n] : 0.f;
-        _Float16 a, b;
-        cm_split(v, a, b);
-        hi[kk] = a; lo[kk] = b;
+        float x = 0.f;
+        if (item < I && n < ncols) {
+            if constexpr (COND) {
+                const int A = ncols >> 1, a = n < A ? n : n - A;
+                const float* te = src + ((size_t)c * I + item) * 2 * A;
+                const float tau = 1.0f / (expf(te[A + a]) + kPoeEps);
+                x = n < A ? tau : te[a] * tau;
+            } else {
+                x = src[((size_t)c * I + item) * ncols + n];
+            }
+        }
+        v[kk] = x;
     }
-    const size_t o = ((size_t)((S * 4 + j) * 4 + nt) * 2) * 64 + lane;
+    uint4 hi, mid, lo;
+    cm_split3(v, hi, mid, lo);
+    const size_t o = ((size_t)((S * 4 + j) * NT + nt) * kCmNP) * 64 + lane;
     img[o] = hi;
-    img[o + 64] = lo;
+    img[o + 64] = mid;
+    img[o + 128] = lo;
 }
-// backward B operand: gimg[((c32 * 4 + nt) * 2 + plane) * 64 + lane] = half8 over kk of G[32 c32 + 8 g + kk][16 nt + (lane & 15)]
-__global__ __launch_bounds__(256) void cm_grad_image_kernel(const float* __restrict__ G /* [B][64] */, cm_half8* __restrict__ gimg, long long B, long long n32) {
+// backward B operand: gimg[((c32 * NT + nt) * 3 + piece) * 64 + lane] = 8 pieces over kk of G[32 c32 + 8 g + kk][16 nt + (lane & 15)]
+// (G row stride = ncols; columns >= ncols are zero)
+__global__ __launch_bounds__(256) void cm_grad_image_kernel(const float* __restrict__ G, uint4* __restrict__ gimg, long long B, long long n32,
+                                                            int NT, int ncols) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n32 * 4 * 64) return;
-    const int lane = (int)(t & 63), nt = (int)((t >> 6) & 3);
-    const long long c32 = t >> 8;
-    const int n = lane & 15, g = lane >> 4;
-    cm_half8 hi, lo;
+    if (t >= n32 * NT * 64) return;
+    const int lane = (int)(t & 63), nt = (int)((t >> 6) % NT);
+    const long long c32 = (t >> 6) / NT;
+    const int n = 16 * nt + (lane & 15), g = lane >> 4;
+    float v[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const long long p = 32 * c32 + 8 * g + kk;
-        const float v = p < B ? G[p * kCmH + 16 * nt + n] : 0.f;
-        _Float16 a, b;
-        cm_split(v, a, b);
-        hi[kk] = a; lo[kk] = b;
+        v[kk] = (p < B && n < ncols) ? G[p * ncols + n] : 0.f;
     }
-    const size_t o = ((size_t)(c32 * 4 + nt) * 2) * 64 + lane;
+    uint4 hi, mid, lo;
+    cm_split3(v, hi, mid, lo);
+    const size_t o = ((size_t)(c32 * NT + nt) * kCmNP) * 64 + lane;
     gimg[o] = hi;
-    gimg[o + 64] = lo;
+    gimg[o + 64] = mid;
+    gimg[o + 128] = lo;
 }
 
-// the 16 code bytes of person `p` at items [64 S + 16 g, +16): missing (2) beyond the matrix / the row's end
-__device__ __forceinline__ uint4 cm_load_codes(const uint8_t* __restrict__ codes, long long stride, long long B, int I, long long p, int S, int g) {
-    uint4 w = uint4{0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u};
-    const int i0 = 64 * S + 16 * g;
-    if (p < B && i0 < I) {
-        const uint8_t* rp = codes + p * stride + i0;
-        if (i0 + 16 <= I) {
-            w = *reinterpret_cast<const uint4*>(rp);                      // (rows are 4-byte aligned with a stride % 4 == 0: 16-byte
-        } else {                                                          //  alignment holds when stride % 16 == 0, else dwords)
-            uint32_t d[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                d[k] = 0x02020202u;
-                const int left = I - (i0 + 4 * k);
-                if (left >= 4) d[k] = *reinterpret_cast<const uint32_t*>(rp + 4 * k);
-                else if (left > 0) {
-                    uint32_t v = 0x02020202u;
-                    for (int b = 0; b < left; ++b) v = (v & ~(0xffu << (8 * b))) | ((uint32_t)rp[4 * k + b] << (8 * b));
-                    d[k] = v;
-                }
-            }
-            w = uint4{d[0], d[1], d[2], d[3]};
-        }
-    }
-    return w;
+// the 16 code bytes at items [i0, i0 + 16) of the row at `rp`.  AL: rows 16-byte aligned (one load), else 4-byte aligned (four).
+// cm_load_full: the 16 bytes lie inside the row (every step below I / 64: no bounds logic anywhere near the pipelined loads);
+// cm_load_tail: the row's last, partial step -- dword by dword (rows are whole dwords), bytes past the row's end read as missing (2)
+template <bool AL>
+__device__ __forceinline__ uint4 cm_load_full(const uint8_t* __restrict__ rp, int i0) {
+    if constexpr (AL) return *reinterpret_cast<const uint4*>(rp + i0);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(rp + i0);
+    return uint4{q[0], q[1], q[2], q[3]};
 }
-__device__ __forceinline__ uint4 cm_load_codes_any(const uint8_t* __restrict__ codes, long long stride, long long B, int I, long long p, int S, int g,
-                                                   bool aligned16) {
-    if (aligned16) return cm_load_codes(codes, stride, B, I, p, S, g);
-    // rows only 4-byte aligned: four dword loads
-    uint32_t d[4] = {0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u};
-    const int i0 = 64 * S + 16 * g;
-    if (p < B) {
-        const uint8_t* rp = codes + p * stride + i0;
+// cm_load_padded: the same partial step when the rows are padded to whole 64-byte steps (the library's own code rows, and
+// pack_cell_codes' from 256 items): one full load, the bytes past the row's end forced to missing
+template <bool AL>
+__device__ __forceinline__ uint4 cm_load_padded(const uint8_t* __restrict__ rp, int I, int i0) {
+    uint4 w = cm_load_full<AL>(rp, i0);
+    uint32_t d[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int left = I - (i0 + 4 * k);
-            if (left >= 4) d[k] = *reinterpret_cast<const uint32_t*>(rp + 4 * k);
-            else if (left > 0) {
-                uint32_t v = 0x02020202u;
-                for (int b = 0; b < left; ++b) v = (v & ~(0xffu << (8 * b))) | ((uint32_t)rp[4 * k + b] << (8 * b));
-                d[k] = v;
-            }
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int left = I - (i0 + 4 * k);
+        const uint32_t keep = left >= 4 ? 0xffffffffu : left <= 0 ? 0u : (1u << (8 * left)) - 1u;
+        d[k] = (d[k] & keep) | (0x02020202u & ~keep);
     }
     return uint4{d[0], d[1], d[2], d[3]};
 }
+__device__ __forceinline__ uint4 cm_load_tail(const uint8_t* __restrict__ rp, int I, int i0) {
+    uint32_t d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int left = I - (i0 + 4 * k);
+        uint32_t v = 0x02020202u;
+        if (left > 0) v = *reinterpret_cast<const uint32_t*>(rp + i0 + 4 * k);
+        if (left < 4) {
+            const uint32_t keep = left <= 0 ? 0u : (1u << (8 * left)) - 1u;
+            v = (v & keep) | (0x02020202u & ~keep);
+        }
+        d[k] = v;
+    }
+    return uint4{d[0], d[1], d[2], d[3]};
+}
+// row of person p (clamped to the last person: what a wave reads for persons that do not exist never reaches an output --
+// the forward does not store their rows, the backward multiplies them by zero coefficients)
+__device__ __forceinline__ const uint8_t* cm_row(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
+                                                 long long B, long long p) {
+    p = p < B ? p : B - 1;
+    return codes + (row_index ? row_index[p] : p) * stride;
+}
+__device__ __forceinline__ int cm_observed(const uint4 w) {
+    return __popc(~(w.x >> 1) & 0x01010101u) + __popc(~(w.y >> 1) & 0x01010101u) + __popc(~(w.z >> 1) & 0x01010101u) +
+           __popc(~(w.w >> 1) & 0x01010101u);
+}
+template <int J>
+__device__ __forceinline__ uint32_t cm_dword(const uint4 w) { return J == 0 ? w.x : J == 1 ? w.y : J == 2 ? w.z : w.w; }
 
-// ---- forward: S[p][:] = sum_i onehot . h ; a wave owns 64 persons (4 M-tiles) x all 64 hidden units ---------------------
-__global__ __launch_bounds__(256) void cm_forward_kernel(const uint8_t* __restrict__ codes, long long stride, long long B, int I, int nS,
-                                                         const cm_half8* __restrict__ img, float* __restrict__ Sout, int aligned16) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// ---- forward: S[p][:] = sum_i onehot . X ; a wave owns 64 persons (4 M-tiles) x all 16 NT columns ------------------------
+// out[p * out_stride + n] for n < ncols; COUNT: out[p * out_stride + ncols] = observed cells of the row.
+// A workgroup is 4 compute waves + 1 producer wave.  Vector-memory loads return in order, so a wave that waits for a
+// (short, L2-resident) dense-operand load also waits for every code-row load it issued before it -- which would expose the
+// code rows' whole HBM latency at every step.  Hence the split: the producer wave streams the dense operand into LDS in 12 KB
+// chunks (4 / NT K-steps x NT N-tiles x 3 pieces, double-buffered, one barrier per chunk); the only vector-memory loads a
+// compute wave ever waits on are its own code rows, issued two 64-item steps ahead (three register sets, rotated by name).
+template <int NT, bool COUNT, bool AL>
+__global__ __launch_bounds__(320) void cm_forward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
+                                                         long long B, int I, int nS, const uint4* __restrict__ img, float* __restrict__ out,
+                                                         int out_stride, int ncols) {
+    constexpr int JC = 4 / NT;                      // K-steps per chunk
+    __shared__ uint4 bimg[2][768];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nQ = nS * NT;
+    if (wv == 4) {                                   // ---- producer wave
+        const cm_u4* src = reinterpret_cast<const cm_u4*>(img) + lane;
+        cm_u4* lds = reinterpret_cast<cm_u4*>(&bimg[0][0]) + lane;
+        cm_u4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11;
+#define CM_CHUNK_LOAD(np) { r0 = (np)[0]; r1 = (np)[64]; r2 = (np)[128]; r3 = (np)[192]; r4 = (np)[256]; r5 = (np)[320]; \
+                            r6 = (np)[384]; r7 = (np)[448]; r8 = (np)[512]; r9 = (np)[576]; r10 = (np)[640]; r11 = (np)[704]; }
+#define CM_CHUNK_STORE(dp) { (dp)[0] = r0; (dp)[64] = r1; (dp)[128] = r2; (dp)[192] = r3; (dp)[256] = r4; (dp)[320] = r5; \
+                             (dp)[384] = r6; (dp)[448] = r7; (dp)[512] = r8; (dp)[576] = r9; (dp)[640] = r10; (dp)[704] = r11; }
+        CM_CHUNK_LOAD(src)
+        CM_CHUNK_STORE(lds)
+        CM_CHUNK_LOAD(src + (size_t)(1 < nQ ? 1 : 0) * 768)
+        __syncthreads();
+        for (int q = 0; q < nQ; ++q) {
+            cm_u4* dst = lds + ((q + 1) & 1) * 768;
+            CM_CHUNK_STORE(dst)                                           // chunk q + 1 (fetched while chunk q - 1 was being used)
+            const cm_u4* np = src + (size_t)(q + 2 < nQ ? q + 2 : nQ - 1) * 768;
+            CM_CHUNK_LOAD(np)
+            __syncthreads();
+        }
+#undef CM_CHUNK_LOAD
+#undef CM_CHUNK_STORE
+        return;
+    }
     const int m = lane & 15, g = lane >> 4;
     const long long p0 = ((long long)blockIdx.x * 4 + wv) * 64;
-    if (p0 >= B) return;
-    cm_f32x4 acc[4][4];
+    // Loads: lane l fetches piece l & 3 of row l >> 2 of the M-tile (4 adjacent lanes = 64 contiguous bytes: one cache access
+    // instead of four); a lane permutation then hands lane (m, g) the operand layout's piece g of row m.
+    const int lrow = lane >> 2, lpiece = lane & 3;
+    const int perm_addr = 4 * (4 * m + g);
+    const uint8_t* rp[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) rp[mt] = cm_row(codes, stride, row_index, B, p0 + 16 * mt + lrow);
+    cm_f32x4 acc[4][NT];
+    int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = cm_f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int S = 0; S < nS; ++S) {
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = cm_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nFull = I >> 6;                        // steps whose 64 items all exist; one partial step may follow
+    uint4 w0[4], w1[4], w2[4], wt[4];
+    // code rows of step S (clamped to the last whole step: the final prefetches re-read it)
+    auto fetch = [&](uint4 (&w)[4], const int S) {
+        const int i0 = 64 * (S < nFull ? S : nFull - 1) + 16 * lpiece;
+#ifdef CM_EXP_NOLOAD
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w[mt] = uint4{(uint32_t)(i0 + mt) & 0x01010101u, (uint32_t)lane & 0x01010101u, 0u, 0x01000100u};
+#else
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w[mt] = cm_load_full<AL>(rp[mt], i0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        wt[mt] = uint4{0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u};
+        if (nS > nFull) wt[mt] = cm_load_tail(rp[mt], I, 64 * nFull + 16 * lpiece);
+    }
+    if (nFull > 0) {
+        fetch(w0, 0);
+        fetch(w1, 1);
+    }
+    __syncthreads();
+    // one 64-item step on the code words w: NT chunks of the dense operand
+    auto step = [&](const int S, const uint4 (&wl)[4]) {
+#ifdef CM_EXP_NOMFMA
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) cnt[mt] += __popc(wl[mt].x ^ wl[mt].y ^ wl[mt].z ^ wl[mt].w);
+#ifndef CM_EXP_NOSYNC
+#pragma unroll
+        for (int jc = 0; jc < NT; ++jc) __syncthreads();
+#endif
+        return;
+#endif
         uint4 w[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) w[mt] = cm_load_codes_any(codes, stride, B, I, p0 + 16 * mt + m, S, g, aligned16 != 0);
+        for (int mt = 0; mt < 4; ++mt)
+            w[mt] = uint4{(uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].x), (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].y),
+                          (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].z), (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].w)};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cm_half8 a[4];
+        for (int jc = 0; jc < NT; ++jc) {
+            const int cur = (S * NT + jc) & 1;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[mt] = cm_onehot(j == 0 ? w[mt].x : j == 1 ? w[mt].y : j == 2 ? w[mt].z : w[mt].w);
-            const cm_half8* ip = img + ((size_t)(S * 4 + j) * 4 * 2) * 64 + lane;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const cm_half8 bh = ip[(size_t)(nt * 2) * 64], bl = ip[(size_t)(nt * 2 + 1) * 64];
+            for (int jj = 0; jj < JC; ++jj) {
+                uint4 a[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    acc[mt][nt] = cm_mfma(a[mt], bh, acc[mt][nt]);
-                    acc[mt][nt] = cm_mfma(a[mt], bl, acc[mt][nt]);
+                    const int j = jc * JC + jj;
+                    a[mt] = cm_onehot(j == 0 ? w[mt].x : j == 1 ? w[mt].y : j == 2 ? w[mt].z : w[mt].w);
+                }
+                const uint4* bp = &bimg[cur][(jj * NT) * kCmNP * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uint4 b0 = bp[(nt * kCmNP) * 64], b1 = bp[(nt * kCmNP + 1) * 64], b2 = bp[(nt * kCmNP + 2) * 64];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        acc[mt][nt] = cm_mfma(a[mt], b2, acc[mt][nt]);        // smallest pieces first
+                        acc[mt][nt] = cm_mfma(a[mt], b1, acc[mt][nt]);
+                        acc[mt][nt] = cm_mfma(a[mt], b0, acc[mt][nt]);
+                    }
                 }
             }
+            __syncthreads();
         }
+        if constexpr (COUNT) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) cnt[mt] += cm_observed(w[mt]);
+        }
+    };
+    int S = 0;
+    for (; S + 3 <= nFull; S += 3) {
+        fetch(w2, S + 2); step(S, w0);
+        fetch(w0, S + 3); step(S + 1, w1);
+        fetch(w1, S + 4); step(S + 2, w2);
     }
+    if (S < nFull) {
+        step(S, w0);
+        if (S + 1 < nFull) step(S + 1, w1);
+    }
+    if (nS > nFull) step(nFull, wt);
     // D: lane (col n = m, g) holds rows 4 g + jj of the M-tile
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const long long p = p0 + 16 * mt + 4 * g + jj;
             if (p < B) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) Sout[p * kCmH + 16 * nt + m] = acc[mt][nt][jj];
+                for (int nt = 0; nt < NT; ++nt)
+                    if (16 * nt + m < ncols) out[p * out_stride + 16 * nt + m] = acc[mt][nt][jj];
             }
         }
+        if constexpr (COUNT) {
+            int t = cnt[mt];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            const long long p = p0 + 16 * mt + m;
+            if (g == 0 && p < B) out[p * out_stride + ncols] = (float)t;
+        }
+    }
 }
 
-// ---- backward: dh = onehot^T G ; a wave (= workgroup) owns a stripe of 64 items x a range of persons -------------------
-constexpr int kCmTileStride = 136;      // halfs per person row of the one-hot tile (128 + 8: 16-byte aligned rows, staggered banks)
-__global__ __launch_bounds__(64) void cm_backward_kernel(const uint8_t* __restrict__ codes, long long stride, long long B, int I,
-                                                         const cm_half8* __restrict__ gimg, float* __restrict__ rec, int nR, long long per_r,
-                                                         int aligned16) {
-    __shared__ __attribute__((aligned(16))) _Float16 tile[64 * kCmTileStride];
+// ---- backward: dX = onehot^T G ; a wave (= workgroup) owns a stripe of 64 items x a range of persons x NT N-tiles -------
+// One-hot tile [64 persons][128 (item, code) columns] of bf16, 256-byte rows, XOR-swizzled so that neither the 16-byte writes
+// of a code row's pieces nor the transposed 8-byte reads of a 16-lane group (4 persons x 32 bytes) share banks:
+//   byte offset in the row = ((unit ^ swz(person)) << 5) | ((half ^ person bit 1) << 4) | byte,   unit = 32-byte unit (16 columns),
+//   swz(person) = (person & 3) | (person bit 3) << 2
+// Loads and tile writes: lane l handles piece l & 3 (16 bytes = 16 items) of row l >> 2 of each 16-person M-tile -- 4 adjacent
+// lanes fetch 64 contiguous bytes (one cache access instead of four).
+// Per 64-person step the coefficient operands are fetched first and the code rows of the step after next behind them (loads
+// return in order: what is waited for must have been issued before what may stay in flight).  NT is 1 or 2; wider outputs
+// (the 64 hidden units of --ability-merge mean) run as blockIdx.y slices of 2 N-tiles (nt0 = 2 blockIdx.y of ntot).
+__device__ __forceinline__ uint2 cm_lds_tr(const char* p) {
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((cm_s4 __attribute__((address_space(3)))*)p));
+}
+__device__ __forceinline__ int cm_tile_swz(int person) { return (person & 3) | (((person >> 3) & 1) << 2); }
+template <int NT, bool AL, int TAIL /* 0: whole step, 1: partial step of padded rows, 2: partial step */, bool GATHER>
+__device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
+                                                 long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
+                                                 long long per_r, char* tile, int S, int r, int ntot, int nt0) {
     const int lane = threadIdx.x;
     const int m = lane & 15, g = lane >> 4;
-    const int S = blockIdx.x / nR, r = blockIdx.x % nR;
+    const int lrow = lane >> 2, lpiece = lane & 3;
+    const int i0 = 64 * S + 16 * lpiece;
     const long long pa = (long long)r * per_r, pb = pa + per_r < B ? pa + per_r : B;        // per_r is a multiple of 64
-    cm_f32x4 acc[8][4];
+    cm_f32x4 acc[8][NT];
 #pragma unroll
     for (int T = 0; T < 8; ++T)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[T][nt] = cm_f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long long p0 = pa; p0 < pb; p0 += 64) {
-        // one-hot tile [64 persons][128 (item, code) columns]: lane (m, g) of M-tile mt writes its 4 x 8 halfs at columns 32 g + 8 j
+        for (int nt = 0; nt < NT; ++nt) acc[T][nt] = cm_f32x4{0.f, 0.f, 0.f, 0.f};
+    // code rows of the 64 persons from p (persons past the last one read the last one's row: their coefficients are zero)
+    auto fetch = [&](uint4 (&w)[4], const long long p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const uint4 w = cm_load_codes_any(codes, stride, B, I, p0 + 16 * mt + m, S, g, aligned16 != 0);
-            _Float16* row = tile + (16 * mt + m) * kCmTileStride + 32 * g;
-            *reinterpret_cast<cm_half8*>(row) = cm_onehot(w.x);
-            *reinterpret_cast<cm_half8*>(row + 8) = cm_onehot(w.y);
-            *reinterpret_cast<cm_half8*>(row + 16) = cm_onehot(w.z);
-            *reinterpret_cast<cm_half8*>(row + 24) = cm_onehot(w.w);
+            long long q = p + 16 * mt + lrow;
+            q = q < B ? q : B - 1;
+            if constexpr (GATHER) q = row_index[q];
+            const uint8_t* rp = codes + q * stride;
+            if constexpr (TAIL == 0) w[mt] = cm_load_full<AL>(rp, i0);
+            else if constexpr (TAIL == 1) w[mt] = cm_load_padded<AL>(rp, I, i0);
+            else w[mt] = cm_load_tail(rp, I, i0);
         }
-        // the upstream gradient of these 64 persons as B operands: [2 K-chunks of 32 persons][4 N-tiles][hi | lo]
-        cm_half8 bg[2][4][2];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // write side: lane l of M-tile mt owns person 16 mt + (l >> 2), columns 32 (l & 3) .. + 31 = units 2 (l & 3), + 1 (4 x 16 bytes)
+    int wofs[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int person = 16 * mt + lrow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            wofs[mt][j] = person * 256 + ((((2 * lpiece + (j >> 1)) ^ cm_tile_swz(person)) << 5) | ((((j & 1) ^ (person >> 1)) & 1) << 4));
+    }
+    // read side: lane i of a 16-lane group addresses person 8 g + (i >> 2) (+ 4 for the second read, + 32 c), 8-byte piece i & 3 of
+    // the unit; the unit index T is XORed in per read
+    int rofs[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int person = 8 * g + (m >> 2) + 4 * h;
+        rofs[h] = person * 256 + ((cm_tile_swz(person) << 5) | (((((m & 3) >> 1) ^ (person >> 1)) & 1) << 4) | ((m & 1) << 3));
+    }
+    auto step = [&](const long long p0, const uint4 (&w)[4], uint4 (&wnext)[4]) {
         const long long c32 = p0 >> 5;
+        uint4 bg[2][NT][kCmNP];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const cm_half8* gp = gimg + ((size_t)((c32 + c) * 4 + nt) * 2) * 64 + lane;
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint4* gp = gimg + ((size_t)((c32 + c) * ntot + nt0 + nt) * kCmNP) * 64 + lane;
                 bg[c][nt][0] = gp[0];
                 bg[c][nt][1] = gp[64];
+                bg[c][nt][2] = gp[128];
             }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(wnext, p0 + 128);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            *reinterpret_cast<uint4*>(tile + wofs[mt][0]) = cm_onehot(w[mt].x);
+            *reinterpret_cast<uint4*>(tile + wofs[mt][1]) = cm_onehot(w[mt].y);
+            *reinterpret_cast<uint4*>(tile + wofs[mt][2]) = cm_onehot(w[mt].z);
+            *reinterpret_cast<uint4*>(tile + wofs[mt][3]) = cm_onehot(w[mt].w);
+        }
         __syncthreads();
 #pragma unroll
-        for (int T = 0; T < 8; ++T) {
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int T = 0; T < 8; ++T) {
                 // A operand: row = column 16 T + m of the tile, k = persons 32 c + 8 g + kk
-                cm_half8 a;
-                const _Float16* col = tile + (32 * c + 8 * g) * kCmTileStride + 16 * T + m;
+                const uint2 a0 = cm_lds_tr(tile + 32 * c * 256 + (rofs[0] ^ (T << 5)));
+                const uint2 a1 = cm_lds_tr(tile + 32 * c * 256 + (rofs[1] ^ (T << 5)));
+                const uint4 a = uint4{a0.x, a0.y, a1.x, a1.y};
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) a[kk] = col[kk * kCmTileStride];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    acc[T][nt] = cm_mfma(a, bg[c][nt][0], acc[T][nt]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[T][nt] = cm_mfma(a, bg[c][nt][2], acc[T][nt]);
                     acc[T][nt] = cm_mfma(a, bg[c][nt][1], acc[T][nt]);
+                    acc[T][nt] = cm_mfma(a, bg[c][nt][0], acc[T][nt]);
                 }
             }
         }
         __syncthreads();
+    };
+    uint4 w0[4], w1[4], w2[4];
+    fetch(w0, pa);
+    fetch(w1, pa + 64);
+    long long p0 = pa;
+    for (; p0 + 128 < pb; p0 += 192) {
+        step(p0, w0, w2);
+        step(p0 + 64, w1, w0);
+        step(p0 + 128, w2, w1);
     }
-    // record [128 columns = 32 g' + 8 j + kk][64 hidden]; D: lane (col n = m, g) holds rows 4 g + jj of tile T
-    float* out = rec + (size_t)blockIdx.x * 128 * kCmH;
+    if (p0 < pb) {
+        step(p0, w0, w2);
+        if (p0 + 64 < pb) step(p0 + 64, w1, w0);
+    }
+    // record [128 columns = 32 g' + 8 j + kk][16 ntot]; D: lane (col n = m, g) holds rows 4 g + jj of tile T
+    float* out = rec + (size_t)blockIdx.x * 128 * (16 * ntot);
 #pragma unroll
     for (int T = 0; T < 8; ++T)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) out[(size_t)(16 * T + 4 * g + jj) * kCmH + 16 * nt + m] = acc[T][nt][jj];
+            for (int nt = 0; nt < NT; ++nt) out[(size_t)(16 * T + 4 * g + jj) * (16 * ntot) + 16 * (nt0 + nt) + m] = acc[T][nt][jj];
 }
-// dh[c][item][n] = sum over the person ranges of the records, fixed order.  column (g', j, kk) <-> item 64 S + 16 g' + 4 j + (kk >> 1), code kk & 1
-__global__ __launch_bounds__(256) void cm_backward_reduce_kernel(const float* __restrict__ rec, float* __restrict__ dh, int I, int nR) {
+template <int NT, bool AL, bool GATHER>
+__global__ __launch_bounds__(64) void cm_backward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
+                                                         long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
+                                                         long long per_r, int ntot) {
+    __shared__ __attribute__((aligned(256))) char tile[64 * 256];
+    const int S = blockIdx.x / nR, r = blockIdx.x % nR;
+    const int nt0 = NT * blockIdx.y;
+    if (64 * S + 64 <= I) cm_backward_body<NT, AL, 0, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
+    else if (64 * S + 64 <= stride) cm_backward_body<NT, AL, 1, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
+    else cm_backward_body<NT, AL, 2, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
+}
+// record column of (item, code): (g', j, kk) <-> item 64 S + 16 g' + 4 j + (kk >> 1), code kk & 1
+__device__ __forceinline__ int cm_rec_column(int item, int c) {
+    const int il = item & 63;
+    return 32 * (il >> 4) + 8 * ((il >> 2) & 3) + (((il & 3) << 1) | c);
+}
+// dX[c][item][n] = sum over the person ranges of the records, fixed order
+__global__ __launch_bounds__(256) void cm_backward_reduce_kernel(const float* __restrict__ rec, float* __restrict__ dX, int I, int nR, int N) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= 2 * I * kCmH) return;
-    const int n = t % kCmH, item = (t / kCmH) % I, c = t / (kCmH * I);
-    const int S = item >> 6, il = item & 63;
-    const int gq = il >> 4, j = (il >> 2) & 3, kk = ((il & 3) << 1) | c;
-    const int colm = 32 * gq + 8 * j + kk;
-    const float* rp = rec + ((size_t)S * nR * 128 + colm) * kCmH + n;
+    if (t >= 2 * I * N) return;
+    const int n = t % N, item = (t / N) % I, c = t / (N * I);
+    const float* rp = rec + ((size_t)(item >> 6) * nR * 128 + cm_rec_column(item, c)) * N + n;
     float a = 0.f;
-    for (int r = 0; r < nR; ++r) a += rp[(size_t)r * 128 * kCmH];
-    dh[t] = a;
+    for (int r = 0; r < nR; ++r) a += rp[(size_t)r * 128 * N];
+    dX[t] = a;
+}
+// conditional posterior: S1, S2 per (head, code, item, dim) from the records -> grad_table[head][code][I][mu dims | logvar dims]
+//   d/d mu = S1 tau,  d/d logvar = -(S1 mu + S2) tau^2 exp(logvar)       (the chain through utils.py:105-113)
+// One workgroup per (stripe S, quarter g' of its 128 record columns = 16 items x 2 codes): the records' 32 x N block is summed
+// over the person ranges with whole-row loads (fixed order), the chain rule runs on the sums in LDS.
+__global__ __launch_bounds__(1024) void cm_cond_finalize_kernel(const float* __restrict__ rec, const float* __restrict__ table,
+                                                                float* __restrict__ grad_table, int I, int A, int nR, int N) {
+    __shared__ float part[1024];
+    __shared__ float sum[32 * 32];
+    const int S = blockIdx.x, gq = blockIdx.y, tid = threadIdx.x;
+    const int E = 32 * N, nsl = 1024 / E;            // E = 512 or 1024 record values of this quarter; nsl person-range slices
+    {
+        const int e = tid % E, sl = tid / E;
+        const float* q = rec + ((size_t)S * nR * 128 + 32 * gq) * N + e;
+        const size_t rs = (size_t)128 * N;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = sl;
+        for (; r + 7 * nsl < nR; r += 8 * nsl) {         // 8 loads in flight per thread
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += q[(size_t)(r + u * nsl) * rs];
+        }
+        for (; r < nR; r += nsl) a[0] += q[(size_t)r * rs];
+        part[tid] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    __syncthreads();
+    if (tid < E) {
+        float t = part[tid];
+        for (int sl = 1; sl < nsl; ++sl) t += part[sl * E + tid];
+        sum[tid] = t;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * A; e += 1024) {
+        const int a = e % A, col = e / A;                 // col = 8 j + kk: item 64 S + 16 g' + 4 j + (kk >> 1), code kk & 1
+        const int item = 64 * S + 16 * gq + 4 * (col >> 3) + ((col & 7) >> 1), c = col & 1;
+        if (item >= I) continue;
+        const float* sp = sum + col * N;
+        const float* te = table + ((size_t)c * I + item) * 2 * A;
+        const float es = expf(te[A + a]), tau = 1.0f / (es + kPoeEps), mu = te[a];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float s1 = sp[(2 * h) * A + a], s2 = sp[(2 * h + 1) * A + a];
+            float* go = grad_table + ((size_t)(h * 2 + c) * I + item) * 2 * A;
+            go[a] = s1 * tau;
+            go[A + a] = -(s1 * mu + s2) * tau * tau * es;
+        }
+    }
 }
 
-}  // namespace vibo
-
-using namespace vibo;
-
+// ~2048 workgroups: nS item stripes x nR person ranges of a multiple of 64 persons; nR a multiple of 8 where the persons
+// allow it, so that the stripes of one person range (block index S nR + r) share an XCD's L2 for the coefficient image
 static int cm_ranges(long long B, int nS, long long* per_r) {
-    // ~2048 workgroups: nS item stripes x nR person ranges of a multiple of 64 persons
     int nR = 2048 / (nS > 0 ? nS : 1);
-    if (nR < 1) nR = 1;
+    nR = (nR + 7) / 8 * 8;
+    if (nR < 8) nR = 8;
     long long per = (B + nR - 1) / nR;
     per = (per + 63) / 64 * 64;
     if (per < 64) per = 64;
     *per_r = per;
     return (int)((B + per - 1) / per);
 }
+static size_t cm_up(size_t b) { return (b + 255) & ~(size_t)255; }
+static size_t cm_timg_bytes(int nS, int NT) { return cm_up((size_t)nS * 4 * NT * kCmNP * 64 * 16); }
+static size_t cm_gimg_bytes(long long B, int NT) { return cm_up((size_t)((B + 63) / 64 * 2) * NT * kCmNP * 64 * 16); }
+static size_t cm_rec_bytes(long long B, int nS, int NT) {
+    long long per_r;
+    const int nR = cm_ranges(B, nS, &per_r);
+    return cm_up((size_t)nS * nR * 128 * 16 * NT * 4);
+}
+
+template <int NT, bool COUNT>
+static void cm_launch_forward_nt(bool al, dim3 grid, hipStream_t s, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I,
+                                 int nS, const uint4* img, float* out, int out_stride, int ncols) {
+    if (al) hipLaunchKernelGGL((cm_forward_kernel<NT, COUNT, true>), grid, dim3(320), 0, s, codes, stride, row_index, B, I, nS, img, out, out_stride, ncols);
+    else hipLaunchKernelGGL((cm_forward_kernel<NT, COUNT, false>), grid, dim3(320), 0, s, codes, stride, row_index, B, I, nS, img, out, out_stride, ncols);
+}
+template <bool COUNT>
+static hipError_t cm_launch_forward(int NT, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int nS,
+                                    const uint4* img, float* out, int out_stride, int ncols, hipStream_t s) {
+    const bool al = stride % 16 == 0 && ((uintptr_t)codes & 15) == 0;
+    const dim3 grid((unsigned)((B + 255) / 256));
+    if (NT == 1) cm_launch_forward_nt<1, COUNT>(al, grid, s, codes, stride, row_index, B, I, nS, img, out, out_stride, ncols);
+    else if (NT == 2) cm_launch_forward_nt<2, COUNT>(al, grid, s, codes, stride, row_index, B, I, nS, img, out, out_stride, ncols);
+    else cm_launch_forward_nt<4, COUNT>(al, grid, s, codes, stride, row_index, B, I, nS, img, out, out_stride, ncols);
+    return hipGetLastError();
+}
+template <int NT>
+static void cm_launch_backward_nt(bool al, dim3 grid, hipStream_t s, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I,
+                                  const uint4* gimg, float* rec, int nR, long long per_r, int ntot) {
+    if (row_index) {
+        if (al) hipLaunchKernelGGL((cm_backward_kernel<NT, true, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+        else hipLaunchKernelGGL((cm_backward_kernel<NT, false, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    } else {
+        if (al) hipLaunchKernelGGL((cm_backward_kernel<NT, true, false>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+        else hipLaunchKernelGGL((cm_backward_kernel<NT, false, false>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    }
+}
+// ntot N-tiles in all; launches of 1 N-tile, or of blockIdx.y slices of 2
+static hipError_t cm_launch_backward(int ntot, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int nS,
+                                     const uint4* gimg, float* rec, hipStream_t s, int* nR_out) {
+    long long per_r;
+    const int nR = cm_ranges(B, nS, &per_r);
+    *nR_out = nR;
+    const bool al = stride % 16 == 0 && ((uintptr_t)codes & 15) == 0;
+    if (ntot == 1) cm_launch_backward_nt<1>(al, dim3((unsigned)(nS * nR)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    else cm_launch_backward_nt<2>(al, dim3((unsigned)(nS * nR), (unsigned)(ntot / 2)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    return hipGetLastError();
+}
+
+// ---- the conditional posterior's two passes (vibo_cond.hpp) -------------------------------------------------------------
+size_t cond_mfma_scratch_bytes(long long B, int I, int A) {
+    const int nS = (I + 63) / 64;
+    const int NTb = (4 * A + 15) / 16;
+    return cm_timg_bytes(nS, 1) + cm_gimg_bytes(B, NTb) + cm_rec_bytes(B, nS, NTb);
+}
+// pre[B][2A + 1] = lam | s | nobs of every person from its code row (all items in one launch)
+hipError_t launch_cond_pre_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,
+                                const float* table, float* pre, void* scratch, hipStream_t s) {
+    const int nS = (I + 63) / 64;
+    uint4* img = static_cast<uint4*>(scratch);
+    hipLaunchKernelGGL((cm_table_image_kernel<true>), dim3((nS * 4 * 64 + 255) / 256), dim3(256), 0, s, table, img, I, nS, 1, 2 * A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return cm_launch_forward<true>(1, codes, stride, row_index, B, I, nS, img, pre, 2 * A + 1, 2 * A, s);
+}
+// grad_table[2 heads][2][I][2A] from the per-person coefficients coef[B][4A] = [head][P1 | P2][dim]
+hipError_t launch_cond_post_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,
+                                 const float* table, const float* coef, float* grad_table, void* scratch, hipStream_t s) {
+    const int nS = (I + 63) / 64;
+    const int NT = (4 * A + 15) / 16;
+    char* base = static_cast<char*>(scratch) + cm_timg_bytes(nS, 1);
+    uint4* gimg = reinterpret_cast<uint4*>(base);
+    float* rec = reinterpret_cast<float*>(base + cm_gimg_bytes(B, NT));
+    const long long n32 = (B + 63) / 64 * 2;
+    hipLaunchKernelGGL(cm_grad_image_kernel, dim3((unsigned)((n32 * NT * 64 + 255) / 256)), dim3(256), 0, s, coef, gimg, B, n32, NT, 4 * A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int nR = 0;
+    e = cm_launch_backward(NT, codes, stride, row_index, B, I, nS, gimg, rec, s, &nR);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cm_cond_finalize_kernel, dim3(nS, 4), dim3(1024), 0, s, (const float*)rec, table, grad_table, I, A, nR, 16 * NT);
+    return hipGetLastError();
+}
+
+}  // namespace vibo
+
+using namespace vibo;
 
 extern "C" {
 
@@ -287,12 +641,7 @@ extern "C" {
 size_t vibo_code_table_scratch_bytes(int64_t num_person, int num_item, int hidden_dim) {
     if (num_person < 1 || num_item < 1 || hidden_dim != kCmH) return 0;
     const int nS = (num_item + 63) / 64;
-    long long per_r;
-    const int nR = cm_ranges(num_person, nS, &per_r);
-    const size_t timg = ((size_t)nS * 4 * 4 * 2 * 64 * 16 + 255) & ~(size_t)255;
-    const size_t gimg = ((size_t)((num_person + 63) / 64 * 2) * 4 * 2 * 64 * 16 + 255) & ~(size_t)255;
-    const size_t rec = (size_t)nS * nR * 128 * kCmH * 4;
-    return timg + gimg + rec + 256;
+    return cm_timg_bytes(nS, 4) + cm_gimg_bytes(num_person, 4) + cm_rec_bytes(num_person, nS, 4) + 256;
 }
 
 /* S [B][64] = sum over the observed cells of feature[code][item][:]   (feature = elu(mlp1([c, item_i])), [2][I][64]) */
@@ -305,14 +654,12 @@ int vibo_code_table_sum_forward(int64_t num_person, int num_item, int hidden_dim
     if (scratch_bytes < vibo_code_table_scratch_bytes(num_person, num_item, hidden_dim)) return -7;
     const int nS = (num_item + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
-    cm_half8* img = static_cast<cm_half8*>(scratch);
-    hipLaunchKernelGGL(cm_table_image_kernel, dim3((nS * 4 * 4 * 64 + 255) / 256), dim3(256), 0, s, feature, img, num_item, nS);
+    uint4* img = static_cast<uint4*>(scratch);
+    hipLaunchKernelGGL((cm_table_image_kernel<false>), dim3((nS * 4 * 4 * 64 + 255) / 256), dim3(256), 0, s, feature, img, num_item, nS, 4, kCmH);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const int aligned16 = (codes_row_stride % 16 == 0 && ((uintptr_t)codes & 15) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(cm_forward_kernel, dim3((unsigned)((num_person + 255) / 256)), dim3(256), 0, s, codes, (long long)codes_row_stride,
-                       (long long)num_person, num_item, nS, (const cm_half8*)img, out_sum, aligned16);
-    return (int)hipGetLastError();
+    return (int)cm_launch_forward<false>(4, codes, (long long)codes_row_stride, nullptr, (long long)num_person, num_item, nS, img, out_sum, kCmH,
+                                         kCmH, s);
 }
 
 /* d feature [2][I][64] = sum over the persons of [code == c] grad_sum[p][:] */
@@ -324,24 +671,20 @@ int vibo_code_table_sum_backward(int64_t num_person, int num_item, int hidden_di
     if (codes_row_stride % 4 != 0 || ((uintptr_t)codes & 3) || ((uintptr_t)scratch & 255)) return -8;
     if (scratch_bytes < vibo_code_table_scratch_bytes(num_person, num_item, hidden_dim)) return -7;
     const int nS = (num_item + 63) / 64;
-    long long per_r;
-    const int nR = cm_ranges(num_person, nS, &per_r);
     hipStream_t s = (hipStream_t)stream;
-    const size_t timg = ((size_t)nS * 4 * 4 * 2 * 64 * 16 + 255) & ~(size_t)255;
-    char* base = static_cast<char*>(scratch) + timg;
-    cm_half8* gimg = reinterpret_cast<cm_half8*>(base);
+    char* base = static_cast<char*>(scratch) + cm_timg_bytes(nS, 4);
+    uint4* gimg = reinterpret_cast<uint4*>(base);
+    float* rec = reinterpret_cast<float*>(base + cm_gimg_bytes(num_person, 4));
     const long long n32 = (num_person + 63) / 64 * 2;
-    const size_t gbytes = ((size_t)n32 * 4 * 2 * 64 * 16 + 255) & ~(size_t)255;
-    float* rec = reinterpret_cast<float*>(base + gbytes);
-    hipLaunchKernelGGL(cm_grad_image_kernel, dim3((unsigned)((n32 * 4 * 64 + 255) / 256)), dim3(256), 0, s, grad_sum, gimg, (long long)num_person, n32);
+    hipLaunchKernelGGL(cm_grad_image_kernel, dim3((unsigned)((n32 * 4 * 64 + 255) / 256)), dim3(256), 0, s, grad_sum, gimg, (long long)num_person, n32,
+                       4, kCmH);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const int aligned16 = (codes_row_stride % 16 == 0 && ((uintptr_t)codes & 15) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(cm_backward_kernel, dim3(nS * nR), dim3(64), 0, s, codes, (long long)codes_row_stride, (long long)num_person, num_item,
-                       (const cm_half8*)gimg, rec, nR, per_r, aligned16);
-    e = hipGetLastError();
+    int nR = 0;
+    e = cm_launch_backward(4, codes, (long long)codes_row_stride, nullptr, (long long)num_person, num_item, nS, gimg, rec, s, &nR);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cm_backward_reduce_kernel, dim3((2 * num_item * kCmH + 255) / 256), dim3(256), 0, s, (const float*)rec, grad_feature, num_item, nR);
+    hipLaunchKernelGGL(cm_backward_reduce_kernel, dim3((2 * num_item * kCmH + 255) / 256), dim3(256), 0, s, (const float*)rec, grad_feature, num_item,
+                       nR, kCmH);
     return (int)hipGetLastError();
 }
 

@@ -121,7 +121,8 @@ def prepare_mask(mask, keep_int64=False):
 class CellCodes:
     """"Format P" rows: one byte per cell holding the whole cell (0 = answered wrong, 1 = answered right, 2 = missing;
     VIBO_MASK_CODES of include/vibo_hip.h) instead of an fp32 response plus a mask byte -- 1 B instead of 5 B of HBM
-    per cell.  `codes` is a [P, I] uint8 view of rows padded to a multiple of 4 cells.  Passed wherever a `response`
+    per cell.  `codes` is a [P, I] uint8 view of rows whose stride is a multiple of 4 cells (pack_cell_codes pads to whole 16-
+    or 64-byte pieces, which the matrix-pipe passes of the conditional posterior read fastest).  Passed wherever a `response`
     tensor goes (with mask=None): model.forward / elbo_step / encode / log_marginal, FusedTrainer.step, fused_elbo."""
     __slots__ = ('codes',)
 
@@ -161,8 +162,10 @@ def pack_cell_codes(response, mask):
     mask, code = prepare_mask(mask, keep_int64=True)
     _require_device(response, mask)
     P, I = response.shape
-    I4 = (I + 3) // 4 * 4
-    codes = torch.empty(P, I4, dtype=torch.uint8, device=response.device)
+    # row stride: whole 64-byte pieces for wide matrices (the matrix-pipe passes of the conditional posterior fetch 64 bytes
+    # per row and load: 16-byte aligned, never straddling a 128-byte line), 16-byte rows otherwise
+    I4 = (I + 63) // 64 * 64 if I >= 256 else (I + 15) // 16 * 16
+    codes = torch.full((P, I4), 2, dtype=torch.uint8, device=response.device)       # padding cells read as missing
     spec = ElboSpec(irt_model=1, ability_dim=1)
     d = _make_desc(spec, P, I, code, _lib.REG_KL, False, response.stride(0), mask.stride(0) if mask is not None else 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(response.device).cuda_stream)
