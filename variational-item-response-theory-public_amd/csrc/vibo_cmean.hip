@@ -62,12 +62,12 @@ __device__ __forceinline__ void cm_split3(const float (&v)[8], uint4& hi, uint4&
     mid = uint4{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]};
     lo = uint4{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3], (l[4] >> 16) | l[5], (l[6] >> 16) | l[7]};
 }
-// 4 cell codes (one dword) -> the 8 one-hot bf16 [c0 == 0, c0 == 1, c1 == 0, c1 == 1, ...] with entries 2.0 (0x4000)
+// 4 cell codes (one dword) -> the 8 one-hot bf16 [c0 == 0, c0 == 1, c1 == 0, c1 == 1, ...] with entries 2.0 (0x4000).
+// The code bytes themselves are the byte selectors of v_perm_b32 (selector 0..3 = bytes of the second source): two table
+// look-ups give the 0x40 high bytes of the "is 0" / "is 1" halfs, four more permutes lay them out.
 __device__ __forceinline__ uint4 cm_onehot(const uint32_t w) {
-    const uint32_t e1 = w & 0x01010101u;                                 // code == 1
-    const uint32_t e0 = ~(w | (w >> 1)) & 0x01010101u;                   // code == 0
-    const uint32_t t0 = __builtin_amdgcn_perm(0u, 0x00004000u, e0);      // bytes 0x40 where the cell is a 0
-    const uint32_t t1 = __builtin_amdgcn_perm(0u, 0x00004000u, e1);
+    const uint32_t t0 = __builtin_amdgcn_perm(0u, 0x00000040u, w);      // bytes 0x40 where the cell is a 0   (code 2 -> 0x00)
+    const uint32_t t1 = __builtin_amdgcn_perm(0u, 0x00004000u, w);      // ... where it is a 1
     // cell b -> dword [0x00, t0.b, 0x00, t1.b]  (perm: S0 = t1 -> bytes 4..7, S1 = t0 -> bytes 0..3, 0x0c = constant 0)
     return uint4{__builtin_amdgcn_perm(t1, t0, 0x040c000cu), __builtin_amdgcn_perm(t1, t0, 0x050c010cu),
                  __builtin_amdgcn_perm(t1, t0, 0x060c020cu), __builtin_amdgcn_perm(t1, t0, 0x070c030cu)};
@@ -92,11 +92,14 @@ __global__ __launch_bounds__(256) void cm_table_image_kernel(const float* __rest
         const int item = 64 * S + 16 * g + 4 * j + (kk >> 1), c = kk & 1;
         float x = 0.f;
         if (item < I && n < ncols) {
-            if constexpr (COND) {
+            if constexpr (COND) {                     // ncols = 2 A, or 2 A + 1 with a column of ones (-> the observed count)
                 const int A = ncols >> 1, a = n < A ? n : n - A;
-                const float* te = src + ((size_t)c * I + item) * 2 * A;
-                const float tau = 1.0f / (expf(te[A + a]) + kPoeEps);
-                x = n < A ? tau : te[a] * tau;
+                if (n == 2 * A) x = 1.0f;
+                else {
+                    const float* te = src + ((size_t)c * I + item) * 2 * A;
+                    const float tau = 1.0f / (expf(te[A + a]) + kPoeEps);
+                    x = n < A ? tau : te[a] * tau;
+                }
             } else {
                 x = src[((size_t)c * I + item) * ncols + n];
             }
@@ -350,8 +353,8 @@ __global__ __launch_bounds__(320) void cm_forward_kernel(const uint8_t* __restri
 // Loads and tile writes: lane l handles piece l & 3 (16 bytes = 16 items) of row l >> 2 of each 16-person M-tile -- 4 adjacent
 // lanes fetch 64 contiguous bytes (one cache access instead of four).
 // Per 64-person step the coefficient operands are fetched first and the code rows of the step after next behind them (loads
-// return in order: what is waited for must have been issued before what may stay in flight).  NT is 1 or 2; wider outputs
-// (the 64 hidden units of --ability-merge mean) run as blockIdx.y slices of 2 N-tiles (nt0 = 2 blockIdx.y of ntot).
+// return in order: what is waited for must have been issued before what may stay in flight).  NT is 1, 2 or 4 (the 64 hidden
+// units of --ability-merge mean); nt0 = NT blockIdx.y of ntot.
 __device__ __forceinline__ uint2 cm_lds_tr(const char* p) {
     return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((cm_s4 __attribute__((address_space(3)))*)p));
 }
@@ -403,9 +406,10 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
     }
     auto step = [&](const long long p0, const uint4 (&w)[4], uint4 (&wnext)[4]) {
         const long long c32 = p0 >> 5;
-        uint4 bg[2][NT][kCmNP];
+        constexpr bool kBoth = NT <= 2;              // both 32-person halves' coefficients in registers at once
+        uint4 bg[kBoth ? 2 : 1][NT][kCmNP];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < (kBoth ? 2 : 1); ++c)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const uint4* gp = gimg + ((size_t)((c32 + c) * ntot + nt0 + nt) * kCmNP) * 64 + lane;
@@ -425,6 +429,18 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+            if constexpr (!kBoth) {                  // (4 N-tiles: a step is ~3000 matrix-pipe cycles, the reload hides under the first half)
+                if (c == 1) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const uint4* gp = gimg + ((size_t)((c32 + 1) * ntot + nt0 + nt) * kCmNP) * 64 + lane;
+                        bg[0][nt][0] = gp[0];
+                        bg[0][nt][1] = gp[64];
+                        bg[0][nt][2] = gp[128];
+                    }
+                }
+            }
+            const int cb = kBoth ? c : 0;
 #pragma unroll
             for (int T = 0; T < 8; ++T) {
                 // A operand: row = column 16 T + m of the tile, k = persons 32 c + 8 g + kk
@@ -433,9 +449,9 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
                 const uint4 a = uint4{a0.x, a0.y, a1.x, a1.y};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[T][nt] = cm_mfma(a, bg[c][nt][2], acc[T][nt]);
-                    acc[T][nt] = cm_mfma(a, bg[c][nt][1], acc[T][nt]);
-                    acc[T][nt] = cm_mfma(a, bg[c][nt][0], acc[T][nt]);
+                    acc[T][nt] = cm_mfma(a, bg[cb][nt][2], acc[T][nt]);
+                    acc[T][nt] = cm_mfma(a, bg[cb][nt][1], acc[T][nt]);
+                    acc[T][nt] = cm_mfma(a, bg[cb][nt][0], acc[T][nt]);
                 }
             }
         }
@@ -463,16 +479,26 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) out[(size_t)(16 * T + 4 * g + jj) * (16 * ntot) + 16 * (nt0 + nt) + m] = acc[T][nt][jj];
 }
+#define CM_BACKWARD_KERNEL_BODY                                                                                                              \
+    __shared__ __attribute__((aligned(256))) char tile[64 * 256];                                                                            \
+    const int S = blockIdx.x / nR, r = blockIdx.x % nR;                                                                                      \
+    const int nt0 = NT * blockIdx.y;                                                                                                         \
+    if (64 * S + 64 <= I) cm_backward_body<NT, AL, 0, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);  \
+    else if (64 * S + 64 <= stride) cm_backward_body<NT, AL, 1, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0); \
+    else cm_backward_body<NT, AL, 2, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
+// 4 N-tiles: 128 accumulator + 48 coefficient + 48 code-row registers -- one wave per SIMD with the whole register file
+template <bool AL, bool GATHER>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void cm_backward_wide_kernel(
+    const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index, long long B, int I, const uint4* __restrict__ gimg,
+    float* __restrict__ rec, int nR, long long per_r, int ntot) {
+    constexpr int NT = 4;
+    CM_BACKWARD_KERNEL_BODY
+}
 template <int NT, bool AL, bool GATHER>
 __global__ __launch_bounds__(64) void cm_backward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
                                                          long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
                                                          long long per_r, int ntot) {
-    __shared__ __attribute__((aligned(256))) char tile[64 * 256];
-    const int S = blockIdx.x / nR, r = blockIdx.x % nR;
-    const int nt0 = NT * blockIdx.y;
-    if (64 * S + 64 <= I) cm_backward_body<NT, AL, 0, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
-    else if (64 * S + 64 <= stride) cm_backward_body<NT, AL, 1, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
-    else cm_backward_body<NT, AL, 2, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
+    CM_BACKWARD_KERNEL_BODY
 }
 // record column of (item, code): (g', j, kk) <-> item 64 S + 16 g' + 4 j + (kk >> 1), code kk & 1
 __device__ __forceinline__ int cm_rec_column(int item, int c) {
@@ -485,9 +511,15 @@ __global__ __launch_bounds__(256) void cm_backward_reduce_kernel(const float* __
     if (t >= 2 * I * N) return;
     const int n = t % N, item = (t / N) % I, c = t / (N * I);
     const float* rp = rec + ((size_t)(item >> 6) * nR * 128 + cm_rec_column(item, c)) * N + n;
-    float a = 0.f;
-    for (int r = 0; r < nR; ++r) a += rp[(size_t)r * 128 * N];
-    dX[t] = a;
+    const size_t rs = (size_t)128 * N;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = 0;
+    for (; r + 8 <= nR; r += 8) {                    // 8 loads in flight per thread
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += rp[(size_t)(r + u) * rs];
+    }
+    for (; r < nR; ++r) a[0] += rp[(size_t)r * rs];
+    dX[t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 // conditional posterior: S1, S2 per (head, code, item, dim) from the records -> grad_table[head][code][I][mu dims | logvar dims]
 //   d/d mu = S1 tau,  d/d logvar = -(S1 mu + S2) tau^2 exp(logvar)       (the chain through utils.py:105-113)
@@ -573,6 +605,16 @@ static hipError_t cm_launch_forward(int NT, const uint8_t* codes, long long stri
     else cm_launch_forward_nt<4, COUNT>(al, grid, s, codes, stride, row_index, B, I, nS, img, out, out_stride, ncols);
     return hipGetLastError();
 }
+static void cm_launch_backward_wide(bool al, dim3 grid, hipStream_t s, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I,
+                                    const uint4* gimg, float* rec, int nR, long long per_r, int ntot) {
+    if (row_index) {
+        if (al) hipLaunchKernelGGL((cm_backward_wide_kernel<true, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+        else hipLaunchKernelGGL((cm_backward_wide_kernel<false, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    } else {
+        if (al) hipLaunchKernelGGL((cm_backward_wide_kernel<true, false>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+        else hipLaunchKernelGGL((cm_backward_wide_kernel<false, false>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    }
+}
 template <int NT>
 static void cm_launch_backward_nt(bool al, dim3 grid, hipStream_t s, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I,
                                   const uint4* gimg, float* rec, int nR, long long per_r, int ntot) {
@@ -584,7 +626,7 @@ static void cm_launch_backward_nt(bool al, dim3 grid, hipStream_t s, const uint8
         else hipLaunchKernelGGL((cm_backward_kernel<NT, false, false>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
     }
 }
-// ntot N-tiles in all; launches of 1 N-tile, or of blockIdx.y slices of 2
+// ntot N-tiles in all (1, 2 or a multiple of 4: blockIdx.y slices of 4)
 static hipError_t cm_launch_backward(int ntot, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int nS,
                                      const uint4* gimg, float* rec, hipStream_t s, int* nR_out) {
     long long per_r;
@@ -592,7 +634,8 @@ static hipError_t cm_launch_backward(int ntot, const uint8_t* codes, long long s
     *nR_out = nR;
     const bool al = stride % 16 == 0 && ((uintptr_t)codes & 15) == 0;
     if (ntot == 1) cm_launch_backward_nt<1>(al, dim3((unsigned)(nS * nR)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
-    else cm_launch_backward_nt<2>(al, dim3((unsigned)(nS * nR), (unsigned)(ntot / 2)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    else if (ntot == 2) cm_launch_backward_nt<2>(al, dim3((unsigned)(nS * nR)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    else cm_launch_backward_wide(al, dim3((unsigned)(nS * nR), (unsigned)(ntot / 4)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
     return hipGetLastError();
 }
 
@@ -607,9 +650,13 @@ hipError_t launch_cond_pre_mfma(const uint8_t* codes, long long stride, const in
                                 const float* table, float* pre, void* scratch, hipStream_t s) {
     const int nS = (I + 63) / 64;
     uint4* img = static_cast<uint4*>(scratch);
-    hipLaunchKernelGGL((cm_table_image_kernel<true>), dim3((nS * 4 * 64 + 255) / 256), dim3(256), 0, s, table, img, I, nS, 1, 2 * A);
+    // the observed count: a column of ones while the 16-column tile has room for it (exact: a sum of 1.0s), the code words'
+    // population count at 8 ability dims
+    const int ncols = 2 * A < 16 ? 2 * A + 1 : 2 * A;
+    hipLaunchKernelGGL((cm_table_image_kernel<true>), dim3((nS * 4 * 64 + 255) / 256), dim3(256), 0, s, table, img, I, nS, 1, ncols);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (ncols > 2 * A) return cm_launch_forward<false>(1, codes, stride, row_index, B, I, nS, img, pre, 2 * A + 1, ncols, s);
     return cm_launch_forward<true>(1, codes, stride, row_index, B, I, nS, img, pre, 2 * A + 1, 2 * A, s);
 }
 // grad_table[2 heads][2][I][2A] from the per-person coefficients coef[B][4A] = [head][P1 | P2][dim]
