@@ -433,8 +433,8 @@ def main():
 
     def elbo_rel_err(model, resp, mask, A, n=4096):
         """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64).
-        4 096 persons: above the planner's 2 048-person threshold, i.e. on the SAME kernel the timed step runs
-        (`kernel` = vibo_plan_kernel's answer for this call, checked against the timed call's)."""
+        4 096 persons on the SAME kernel the timed step runs (`kernel` = vibo_plan_kernel's answer for this call, pinned to the
+        timed call's kernel through vibo_desc.flags where the planner would choose differently for the small sample)."""
         from oracle import vibo_oracle as O
         from vibo_amd import _lib
         I = args.items
@@ -450,10 +450,19 @@ def main():
             r, m = resp[:n].contiguous(), mask[:n].contiguous()
             hip_rows, hip_mask = r, m
         mcode = _lib.MASK_CODES if codes else _lib.MASK_U8
-        kernel = ops.plan_kernel(model.spec, n, I, mcode, False)
         kernel_timed = ops.plan_kernel(model.spec, resp.shape[0], I, mcode, not args.eval_only)
-        with torch.no_grad():
-            hip = float(model.elbo(*model(hip_rows, hip_mask, eps_item=eps_i, eps_ability=eps_a)))
+        # the sample is smaller than the timed call: pin the row-split kernel the timed call runs (vibo_desc.flags) where the
+        # planner would pick the other one for 4 096 persons (ability_dim <= 4: the VALU kernel below 32 768 persons)
+        saved_flags = ops.DESC_FLAGS
+        if ops.plan_kernel(model.spec, n, I, mcode, False) != kernel_timed:
+            ops.DESC_FLAGS = saved_flags | (_lib.FLAG_KERNEL_MATRIX if kernel_timed.startswith('matrix') else
+                                            _lib.FLAG_KERNEL_VALU if kernel_timed.startswith('VALU') else 0)
+        kernel = ops.plan_kernel(model.spec, n, I, mcode, False)
+        try:
+            with torch.no_grad():
+                hip = float(model.elbo(*model(hip_rows, hip_mask, eps_item=eps_i, eps_ability=eps_a)))
+        finally:
+            ops.DESC_FLAGS = saved_flags
         out = {}
         for name, dt_ in (('fp32', torch.float32), ('fp64', torch.float64)):
             params = {k: v.detach().cpu().to(dt_) for k, v in model.state_dict().items()}

@@ -152,20 +152,31 @@ static bool want_msplit(const vibo_desc* d) {
     // (32-bit row numbers and batch counters in the matrix kernel)
     if (d->num_person > 0x7fffffff - 0x10000) return false;
     if (d->flags & VIBO_FLAG_KERNEL_MATRIX) return true;
-    // small minibatches (the reference CLI's default is 16 persons): the matrix kernel's fixed cost -- operand images, 512-thread
-    // workgroups, one batch of 32 rows per workgroup -- loses to the VALU kernel's 8-row batches below ~3 000 rows
-    // (tools/batch_sweep.py at ability_dim 8: 42 vs 50 us per step at 16 rows, 46 vs 52 at 1 024, 59 vs 54 at 4 096)
-    if (d->num_person <= 2048) return false;
-    // narrow matrices: a workgroup of the matrix kernel is ceil(I / 128) waves on one CU, so with few items the chip holds few
-    // waves; the VALU kernel's 256-item waves and 2 workgroups per CU do better there (50 M cells per call: 96 items
-    // 0.143 vs 0.278 ms at ability_dim 1 -- CritLangAcq's shape -- 256 items 0.072 vs 0.142, 768 items 0.081 vs 0.100; at
-    // ability_dim 8 the contractions tip it earlier: 256 items 0.116 vs 0.151, 384 items 0.139 vs 0.121)
+    // Thresholds from tools/calibrate_planner.py (hipGraph replays of both kernels over persons x items x ability_dim on an
+    // MI355X, profiles/r03_planner_calibration.txt):
+    //  * small minibatches (the reference CLI's default is 16 persons): the matrix kernel's fixed cost -- operand images,
+    //    512-thread workgroups, one batch of 32 rows per workgroup -- loses to the VALU kernel's 8-row batches: 1 000 items,
+    //    ability_dim 8: 17 vs 22 us at 256 persons, 24 vs 24 at 2 048, 33 vs 27 at 4 096
+    //  * narrow matrices: a workgroup of the matrix kernel is ceil(I / 128) waves on one CU, so with few items the chip holds
+    //    few waves; the VALU kernel's 256-item waves and 2 workgroups per CU do better there
+    //  * ability_dim <= 4: the contractions are a small part of the VALU kernel's work, the matrix kernel only wins once every
+    //    workgroup streams several batches (65 536 x 1 000: 80 vs 91 us; 16 384 x 1 000: 36 vs 33)
+    if (d->num_person < 4096) return false;
     const int width = d->num_item < 1024 ? d->num_item : 1024;
-    return d->ability_dim > 4 ? width >= 320 : width >= 896;
+    const bool many = d->num_person >= 32768;
+    if (d->ability_dim <= 4) return many && width >= 640;
+    if (width < 320) return false;
+    // (4 waves per workgroup = 2 workgroups per CU with one batch each at 16 384 persons: 48 vs 42 us)
+    if (width > 384 && width <= 512 && !many) return false;
+    return true;
 }
 static int msplit_blocks(int num_cu, int items, long long persons) {
     const int nw = (items + 127) / 128;
-    long long nblk = (long long)num_cu * (nw >= 8 ? 1 : nw >= 4 ? 2 : nw >= 2 ? 4 : 8);
+    // workgroups per CU = what is resident at once: 2 waves per SIMD (the kernel's register budget) = 8 waves per CU, and the
+    // 17.6 KB of LDS per wave stay under 160 KB with them.  (Round 2 launched 2 per CU at 5..7 waves and 4 at 3 waves: the
+    // surplus workgroups queued behind the resident ones -- with one 32-row batch each that doubled the call:
+    // 16 384 x 768 at ability_dim 8 57 us against the VALU kernel's 45, tools/calibrate_planner.py)
+    long long nblk = (long long)num_cu * (8 / nw > 1 ? 8 / nw : 1);
     const long long nb = (persons + 31) / 32;
     return (int)(nblk < nb ? nblk : nb);
 }
