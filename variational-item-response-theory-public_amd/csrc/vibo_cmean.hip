@@ -195,12 +195,14 @@ __device__ __forceinline__ uint32_t cm_dword(const uint4 w) { return J == 0 ? w.
 // code rows' whole HBM latency at every step.  Hence the split: the producer wave streams the dense operand into LDS in 12 KB
 // chunks (4 / NT K-steps x NT N-tiles x 3 pieces, double-buffered, one barrier per chunk); the only vector-memory loads a
 // compute wave ever waits on are its own code rows, issued two 64-item steps ahead (three register sets, rotated by name).
+// (one N-tile: 4 waves per SIMD = 3 workgroups per CU; the register cap costs 4 spilled registers and wins 10 %: 261 -> 235 us per GB of codes)
 template <int NT, bool COUNT, bool AL>
-__global__ __launch_bounds__(320) void cm_forward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
+__global__ __launch_bounds__(320, NT == 1 ? 4 : 1) void cm_forward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
                                                          long long B, int I, int nS, const uint4* __restrict__ img, float* __restrict__ out,
                                                          int out_stride, int ncols) {
     constexpr int JC = 4 / NT;                      // K-steps per chunk
     __shared__ uint4 bimg[2][768];
+    __shared__ uint4 wtail[4][4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nQ = nS * NT;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(320) void cm_forward_kernel(const uint8_t* __restri
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = cm_f32x4{0.f, 0.f, 0.f, 0.f};
     const int nFull = I >> 6;                        // steps whose 64 items all exist; one partial step may follow
-    uint4 w0[4], w1[4], w2[4], wt[4];
+    uint4 w0[4], w1[4], w2[4];
     // code rows of step S (clamped to the last whole step: the final prefetches re-read it)
     auto fetch = [&](uint4 (&w)[4], const int S) {
         const int i0 = 64 * (S < nFull ? S : nFull - 1) + 16 * lpiece;
@@ -256,10 +258,10 @@ __global__ __launch_bounds__(320) void cm_forward_kernel(const uint8_t* __restri
 #endif
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the partial last step's code words wait in LDS (wave-private: 16 registers less through the whole loop)
+    if (nS > nFull) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        wt[mt] = uint4{0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u};
-        if (nS > nFull) wt[mt] = cm_load_tail(rp[mt], I, 64 * nFull + 16 * lpiece);
+        for (int mt = 0; mt < 4; ++mt) wtail[wv][mt][lane] = cm_load_tail(rp[mt], I, 64 * nFull + 16 * lpiece);
     }
     if (nFull > 0) {
         fetch(w0, 0);
@@ -322,7 +324,11 @@ __global__ __launch_bounds__(320) void cm_forward_kernel(const uint8_t* __restri
         step(S, w0);
         if (S + 1 < nFull) step(S + 1, w1);
     }
-    if (nS > nFull) step(nFull, wt);
+    if (nS > nFull) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w0[mt] = wtail[wv][mt][lane];
+        step(nFull, w0);
+    }
     // D: lane (col n = m, g) holds rows 4 g + jj of the M-tile
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -359,25 +365,30 @@ __device__ __forceinline__ uint2 cm_lds_tr(const char* p) {
     return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((cm_s4 __attribute__((address_space(3)))*)p));
 }
 __device__ __forceinline__ int cm_tile_swz(int person) { return (person & 3) | (((person >> 3) & 1) << 2); }
-template <int NT, bool AL, int TAIL /* 0: whole step, 1: partial step of padded rows, 2: partial step */, bool GATHER>
+// WV = waves per workgroup sharing the tile (1, or 2: each wave builds two of the four M-tiles and owns four of the eight column
+// tiles -- half the accumulators and code-row registers per wave, 8 KB of LDS per wave: 4 waves per SIMD instead of 2.5)
+template <int NT, bool AL, int TAIL /* 0: whole step, 1: partial step of padded rows, 2: partial step */, bool GATHER, int WV, int PS /* persons per step: 64 or 32 */>
 __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
                                                  long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
                                                  long long per_r, char* tile, int S, int r, int ntot, int nt0) {
-    const int lane = threadIdx.x;
+    constexpr int MTW = (PS / 16) / WV, TW = 8 / WV;   // M-tiles built / column tiles owned per wave
+    constexpr int NC = PS / 32;                        // 32-person K-chunks per step
+    const int lane = threadIdx.x & 63;
+    const int wv = WV > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     const int m = lane & 15, g = lane >> 4;
     const int lrow = lane >> 2, lpiece = lane & 3;
     const int i0 = 64 * S + 16 * lpiece;
     const long long pa = (long long)r * per_r, pb = pa + per_r < B ? pa + per_r : B;        // per_r is a multiple of 64
-    cm_f32x4 acc[8][NT];
+    cm_f32x4 acc[TW][NT];
 #pragma unroll
-    for (int T = 0; T < 8; ++T)
+    for (int T = 0; T < TW; ++T)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[T][nt] = cm_f32x4{0.f, 0.f, 0.f, 0.f};
     // code rows of the 64 persons from p (persons past the last one read the last one's row: their coefficients are zero)
-    auto fetch = [&](uint4 (&w)[4], const long long p) {
+    auto fetch = [&](uint4 (&w)[MTW], const long long p) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            long long q = p + 16 * mt + lrow;
+        for (int mt = 0; mt < MTW; ++mt) {
+            long long q = p + 16 * (MTW * wv + mt) + lrow;
             q = q < B ? q : B - 1;
             if constexpr (GATHER) q = row_index[q];
             const uint8_t* rp = codes + q * stride;
@@ -388,10 +399,10 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
         __builtin_amdgcn_sched_barrier(0);
     };
     // write side: lane l of M-tile mt owns person 16 mt + (l >> 2), columns 32 (l & 3) .. + 31 = units 2 (l & 3), + 1 (4 x 16 bytes)
-    int wofs[4][4];
+    int wofs[MTW][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int person = 16 * mt + lrow;
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int person = 16 * (MTW * wv + mt) + lrow;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             wofs[mt][j] = person * 256 + ((((2 * lpiece + (j >> 1)) ^ cm_tile_swz(person)) << 5) | ((((j & 1) ^ (person >> 1)) & 1) << 4));
@@ -404,12 +415,12 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
         const int person = 8 * g + (m >> 2) + 4 * h;
         rofs[h] = person * 256 + ((cm_tile_swz(person) << 5) | (((((m & 3) >> 1) ^ (person >> 1)) & 1) << 4) | ((m & 1) << 3));
     }
-    auto step = [&](const long long p0, const uint4 (&w)[4], uint4 (&wnext)[4]) {
+    auto step = [&](const long long p0, const uint4 (&w)[MTW], uint4 (&wnext)[MTW]) {
         const long long c32 = p0 >> 5;
-        constexpr bool kBoth = NT <= 2;              // both 32-person halves' coefficients in registers at once
-        uint4 bg[kBoth ? 2 : 1][NT][kCmNP];
+        constexpr bool kBoth = NT <= 2 || NC == 1;   // both 32-person halves' coefficients in registers at once
+        uint4 bg[kBoth ? NC : 1][NT][kCmNP];
 #pragma unroll
-        for (int c = 0; c < (kBoth ? 2 : 1); ++c)
+        for (int c = 0; c < (kBoth ? NC : 1); ++c)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const uint4* gp = gimg + ((size_t)((c32 + c) * ntot + nt0 + nt) * kCmNP) * 64 + lane;
@@ -418,9 +429,9 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
                 bg[c][nt][2] = gp[128];
             }
         __builtin_amdgcn_sched_barrier(0);
-        fetch(wnext, p0 + 128);
+        fetch(wnext, p0 + 2 * PS);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt) {
             *reinterpret_cast<uint4*>(tile + wofs[mt][0]) = cm_onehot(w[mt].x);
             *reinterpret_cast<uint4*>(tile + wofs[mt][1]) = cm_onehot(w[mt].y);
             *reinterpret_cast<uint4*>(tile + wofs[mt][2]) = cm_onehot(w[mt].z);
@@ -428,7 +439,7 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             if constexpr (!kBoth) {                  // (4 N-tiles: a step is ~3000 matrix-pipe cycles, the reload hides under the first half)
                 if (c == 1) {
 #pragma unroll
@@ -442,10 +453,11 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
             }
             const int cb = kBoth ? c : 0;
 #pragma unroll
-            for (int T = 0; T < 8; ++T) {
-                // A operand: row = column 16 T + m of the tile, k = persons 32 c + 8 g + kk
-                const uint2 a0 = cm_lds_tr(tile + 32 * c * 256 + (rofs[0] ^ (T << 5)));
-                const uint2 a1 = cm_lds_tr(tile + 32 * c * 256 + (rofs[1] ^ (T << 5)));
+            for (int T = 0; T < TW; ++T) {
+                // A operand: row = column 16 (TW wv + T) + m of the tile, k = persons 32 c + 8 g + kk
+                const int tq = (TW * wv + T) << 5;
+                const uint2 a0 = cm_lds_tr(tile + 32 * c * 256 + (rofs[0] ^ tq));
+                const uint2 a1 = cm_lds_tr(tile + 32 * c * 256 + (rofs[1] ^ tq));
                 const uint4 a = uint4{a0.x, a0.y, a1.x, a1.y};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -457,47 +469,53 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
         }
         __syncthreads();
     };
-    uint4 w0[4], w1[4], w2[4];
+    uint4 w0[MTW], w1[MTW], w2[MTW];
     fetch(w0, pa);
-    fetch(w1, pa + 64);
+    fetch(w1, pa + PS);
     long long p0 = pa;
-    for (; p0 + 128 < pb; p0 += 192) {
+    for (; p0 + 2 * PS < pb; p0 += 3 * PS) {
         step(p0, w0, w2);
-        step(p0 + 64, w1, w0);
-        step(p0 + 128, w2, w1);
+        step(p0 + PS, w1, w0);
+        step(p0 + 2 * PS, w2, w1);
     }
     if (p0 < pb) {
         step(p0, w0, w2);
-        if (p0 + 64 < pb) step(p0 + 64, w1, w0);
+        if (p0 + PS < pb) step(p0 + PS, w1, w0);
     }
     // record [128 columns = 32 g' + 8 j + kk][16 ntot]; D: lane (col n = m, g) holds rows 4 g + jj of tile T
     float* out = rec + (size_t)blockIdx.x * 128 * (16 * ntot);
 #pragma unroll
-    for (int T = 0; T < 8; ++T)
+    for (int T = 0; T < TW; ++T)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) out[(size_t)(16 * T + 4 * g + jj) * (16 * ntot) + 16 * (nt0 + nt) + m] = acc[T][nt][jj];
+            for (int nt = 0; nt < NT; ++nt)
+                out[(size_t)(16 * (TW * wv + T) + 4 * g + jj) * (16 * ntot) + 16 * (nt0 + nt) + m] = acc[T][nt][jj];
 }
 #define CM_BACKWARD_KERNEL_BODY                                                                                                              \
-    __shared__ __attribute__((aligned(256))) char tile[64 * 256];                                                                            \
+    __shared__ __attribute__((aligned(256))) char tile[PS * 256];                                                                            \
     const int S = blockIdx.x / nR, r = blockIdx.x % nR;                                                                                      \
     const int nt0 = NT * blockIdx.y;                                                                                                         \
-    if (64 * S + 64 <= I) cm_backward_body<NT, AL, 0, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);  \
-    else if (64 * S + 64 <= stride) cm_backward_body<NT, AL, 1, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0); \
-    else cm_backward_body<NT, AL, 2, GATHER>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
+    if (64 * S + 64 <= I) cm_backward_body<NT, AL, 0, GATHER, WV, PS>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);  \
+    else if (64 * S + 64 <= stride) cm_backward_body<NT, AL, 1, GATHER, WV, PS>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0); \
+    else cm_backward_body<NT, AL, 2, GATHER, WV, PS>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
 // 4 N-tiles: 128 accumulator + 48 coefficient + 48 code-row registers -- one wave per SIMD with the whole register file
 template <bool AL, bool GATHER>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void cm_backward_wide_kernel(
     const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index, long long B, int I, const uint4* __restrict__ gimg,
     float* __restrict__ rec, int nR, long long per_r, int ntot) {
-    constexpr int NT = 4;
+    constexpr int NT = 4, WV = 1, PS = 64;
     CM_BACKWARD_KERNEL_BODY
 }
+#ifndef CM_BWD_PS
+#define CM_BWD_PS 64
+#endif
 template <int NT, bool AL, bool GATHER>
 __global__ __launch_bounds__(64) void cm_backward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
-                                                         long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
-                                                         long long per_r, int ntot) {
+                                                             long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
+                                                             long long per_r, int ntot) {
+    constexpr int PS = CM_BWD_PS;
+    constexpr int WV = 1;       // (WV = 2, two waves sharing the tile at 4 waves per SIMD, measured slower: 336 -> 384 us at one N-tile)
     CM_BACKWARD_KERNEL_BODY
 }
 // record column of (item, code): (g', j, kk) <-> item 64 S + 16 g' + 4 j + (kk >> 1), code kk & 1
