@@ -627,6 +627,11 @@ def test_matrix_pipe_passes_of_the_conditional_posterior(irt, A, B, I, n_flows, 
     assert (a.ability_logvar - v.ability_logvar).abs().max() < 1e-5 * max(1.0, float(v.ability_logvar.abs().max()))
     for s_ in range(2):
         assert rel_err(a.grad_table(s_), v.grad_table(s_)) < 2e-5
+    # vibo_encode (inference: the posterior alone) takes the same pre pass
+    monkeypatch.setattr(ops, 'DESC_FLAGS', kernel)
+    emu, elv = ops._hip_encode(spec, r, m, code, ri, table.to(d).contiguous(), B)
+    assert (emu - a.ability_mu).abs().max() < 2e-6 * max(1.0, float(a.ability_mu.abs().max()))
+    assert (elv - a.ability_logvar).abs().max() < 2e-6 * max(1.0, float(a.ability_logvar.abs().max()))
     f = run(0, want_grad=False)                      # forward only: the same posterior and scalars
     assert torch.equal(f.ability_mu, a.ability_mu) and torch.equal(f.ability_logvar, a.ability_logvar)
     assert rel_err(f.scalars[_lib.S_LL], a.scalars[_lib.S_LL]) < 1e-6

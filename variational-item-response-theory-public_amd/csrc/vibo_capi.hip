@@ -778,12 +778,20 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const int* __restric
     ability_logvar[e] = logf(1.0f / lam);
 }
 
+// conditional posterior on cell codes, 4 096 persons or more: the experts' sums on the matrix pipe (launch_cond_pre_mfma), as in the
+// ELBO call
+static bool encode_on_matrix_pipe(const vibo_desc* d) {
+    return d->posterior == VIBO_POSTERIOR_CONDITIONAL && d->mask_dtype == VIBO_MASK_CODES && d->num_person >= 4096 &&
+           !(d->flags & VIBO_FLAG_COND_VALU);
+}
 // scratch the fast encode path needs (0: not applicable -> wave-per-person encode_kernel)
 static size_t encode_scratch_bytes(const vibo_desc* d) {
     const int I = d->num_item, A = d->ability_dim;
     if (I < 4 || I > 32767 || !rows_chunkable(d) || d->mask_dtype == VIBO_MASK_I64) return 0;
     if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) {
-        return (size_t)((I + 1023) / 1024) * d->num_person * (2 * A + 1) * 4 + 256;
+        size_t pre = ((size_t)((I + 1023) / 1024) * d->num_person * (2 * A + 1) * 4 + 255) & ~(size_t)255;
+        if (encode_on_matrix_pipe(d)) pre += cond_mfma_scratch_bytes(d->num_person, I, A);      // (only its table image is used)
+        return pre + 256;
     }
     return (size_t)d->num_person * 4 + 256;
 }
@@ -1252,7 +1260,13 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
                 cp.response = response; cp.mask = mask; cp.row_index = row_index; cp.table = table;
                 cp.resp_stride = d->response_row_stride; cp.mask_stride = d->mask_row_stride;
                 cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;
-                for (int pn = 0; pn < panels && e == hipSuccess; ++pn) {
+                const bool mfma = encode_on_matrix_pipe(d);
+                if (mfma) {
+                    const size_t pre_bytes = ((size_t)panels * d->num_person * (2 * A + 1) * 4 + 255) & ~(size_t)255;
+                    e = launch_cond_pre_mfma(static_cast<const uint8_t*>(mask), d->mask_row_stride, row_index, d->num_person, I, A, table, pre,
+                                             static_cast<char*>(workspace) + pre_bytes, s);
+                }
+                for (int pn = 0; pn < panels && e == hipSuccess && !mfma; ++pn) {
                     cp.item0 = pn * 1024;
                     cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
                     cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
@@ -1260,7 +1274,7 @@ int vibo_encode(const vibo_desc* d, const float* response, const void* mask, con
                         e = launch_cond_pre(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, grid, s);
                 }
                 if (e == hipSuccess) {
-                    hipLaunchKernelGGL(encode_finish_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, s, nullptr, pre, panels,
+                    hipLaunchKernelGGL(encode_finish_kernel, dim3((unsigned)((BA + 255) / 256)), dim3(256), 0, s, nullptr, pre, mfma ? 1 : panels,
                                        table, ability_mu, ability_logvar, (long long)d->num_person, I, A, d->missing_mode);
                     e = hipGetLastError();
                 }
