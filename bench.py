@@ -535,7 +535,7 @@ def main():
 
     def config5_probe():
         """BASELINE configs[4]'s path on a slice of its shape (3PL, 10 000 items, conditional posterior, 4 planar flows, fp32 rows):
-        one forward + backward call of 100 000 persons; three passes (cond_pre, matrix kernel per 1024-item panel, cond_post)."""
+        one forward + backward call of 100 000 persons; three passes (cond_pre, matrix kernel per 1024-item panel, table-gradient pass)."""
         from vibo_amd import _lib
         from vibo_amd.ops import ElboSpec
         Pc, Ic = 100_000, 10_000
@@ -563,7 +563,40 @@ def main():
                 'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3), 'bytes_per_term': bpt,
                 'roofline_frac': bpt * Pc * Ic / (ms * 1e-3) / 8e12,
                 'hbm_bytes_per_term_by_construction': 8.0,
-                'note': 'cond_pre reads 5 B and writes 1 B of cell codes per term, the matrix kernel and cond_post read 1 B each'}
+                'note': 'cond_pre reads 5 B and writes 1 B of cell codes per term, the matrix kernel and the table-gradient pass (matrix pipe, vibo_cmean.hip) read 1 B each'}
+
+    def conditional_probe():
+        """--conditional-posterior on the headline shape (2PL, 1M x 1k): one forward + backward call at ability_dim 1 and 8, on
+        fp32 rows and on cell codes (the experts' per-person sums and the table-gradient scatter run as one-hot x table
+        contractions on the matrix pipe from 4 096 persons per call: csrc/vibo_cmean.hip)."""
+        from vibo_amd import _lib
+        from vibo_amd.ops import ElboSpec
+        Pc, Ic = min(args.persons, 1_000_000), args.items
+        g = torch.Generator(device=dev).manual_seed(args.seed + 6)
+        r = (torch.rand(Pc, Ic, device=dev, generator=g) < 0.5).float()
+        mk = torch.rand(Pc, Ic, device=dev, generator=g) >= args.missing
+        m8, code = ops.prepare_mask(mk)
+        cc = ops.pack_cell_codes(r, mk).codes
+        out = {}
+        for Ac in (1, 8):
+            spec = ElboSpec(irt_model=2, ability_dim=Ac, conditional=True)
+            table = torch.randn(2, Ic, 2 * Ac, device=dev, generator=g) * 0.5
+            item = torch.randn(Ic, Ac + 1, device=dev, generator=g)
+            eps = torch.randn(Pc, Ac, device=dev, generator=g)
+            for name, rows in (('fp32_rows', (r, m8, code)), ('cell_codes', (cc, cc, _lib.MASK_CODES))):
+                call = lambda: ops._hip_launch_elbo(spec, rows[0], rows[1], rows[2], None, table, item, eps, None, _lib.REG_KL, True, Pc)
+                for _ in range(2):
+                    call()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    call()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 3
+                out[f'ability_dim_{Ac}_{name}'] = {'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3)}
+        out['workload'] = f'2PL, {Pc} persons x {Ic} items, conditional posterior: one forward + backward call'
+        return out
 
     P, I, A = persons_rank, args.items, args.ability_dim
     m = measure(A, extra=not args.no_extra)
@@ -640,7 +673,7 @@ def main():
             line['elbo_rel_err'] = m['rel']['vs_reference_op_sequence_fp32']
             line['elbo_rel_err_detail'] = m['rel']
         if m.get('sweep'):
-            line['extra'] = {'decoder_kernel': decoder_probe(), 'config5_path': config5_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
+            line['extra'] = {'decoder_kernel': decoder_probe(), 'config5_path': config5_probe(), 'conditional_posterior': conditional_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
         if also is not None:
             line['also'] = also
         if format_p is not None:
