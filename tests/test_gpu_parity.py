@@ -572,9 +572,9 @@ MATRIX_PIPE_POSTERIOR = [
     # irt, A, B, I, flows, gather, codes, drop
     (2, 1, 4100, 1000, 0, False, True, False),     # caller's cell codes: both passes on the matrix pipe
     (2, 8, 4100, 1000, 0, True, True, False),      # rows through row_index, 2 N-tiles of coefficients
-    (3, 3, 4500, 95, 2, False, False, True),       # fp32 rows, 3 dims: count-and-emit pass in front; one whole step + a 31-item tail
+    (3, 3, 4500, 95, 2, False, False, True),       # fp32 rows, 3 dims: VALU pre pass + matrix-pipe post pass; one whole step + a 31-item tail
     (2, 2, 4100, 200, 0, False, False, False),     # fp32 rows, 2 dims: VALU pre pass (emits the codes) + matrix-pipe post pass
-    (2, 5, 4200, 1500, 0, True, False, False),     # more than one 1024-item panel around all-item passes
+    (2, 5, 4200, 1500, 0, True, False, False),     # fp32 rows, 5 dims: count-and-emit pass in front of the matrix-pipe pre pass; two panels
     (1, 4, 5000, 63, 0, False, True, False),       # fewer than 64 items: only the partial step
     (2, 1, 4096, 64, 0, False, True, False),       # exactly one whole step, nothing else
 ]

@@ -220,11 +220,11 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         //   rows = cell codes:  pre 285 us vs 506 (A = 1) / 2 x 475 (A = 8), post 330 vs 400 (A = 1) / 2 x 990 (A = 8)
         //   rows = fp32:        the VALU pre pass reads the rows AND leaves the codes behind (1.22 ms = the 5 B/cell stream);
         //                       a count-and-emit pass in front of the matrix-pipe pre pass costs the same 1.25 ms again, so
-        //                       the VALU pre pass stays up to 2 ability dims (one launch at template width <= 2)
+        //                       the VALU pre pass stays up to 4 ability dims (one launch: 1M x 1k at 3 / 4 dims 2.60 -> 2.39 / 2.41 ms)
         const bool have_codes = d->mask_dtype == VIBO_MASK_CODES || (emit_codes_wanted(d) && d->mask_dtype != VIBO_MASK_I64);
         const bool cmat_ok = is_cond && !(d->flags & VIBO_FLAG_COND_VALU) && have_codes && d->num_person >= 4096;
         pl->cmat_post = cmat_ok && d->want_grad;
-        pl->cmat_pre = cmat_ok && (d->mask_dtype == VIBO_MASK_CODES || A >= 3);
+        pl->cmat_pre = cmat_ok && (d->mask_dtype == VIBO_MASK_CODES || A >= 5);
         const int at_min = 2;
         if (pl->AT < at_min) pl->AT = at_min;
         pl->DP = prepped_item_width(d->irt_model, pl->AT);
