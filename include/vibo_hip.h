@@ -103,6 +103,10 @@ enum { VIBO_KERNEL_MATRIX = 1,        /* msplit_kernel: contractions as f16 hi/l
        VIBO_KERNEL_TILED = 4,         /* tiled fp32-MFMA fallback (ragged rows)                                       */
        VIBO_KERNEL_GENERAL = 5 };     /* wave-per-person fallback                                                     */
 int vibo_plan_kernel(const vibo_desc* d);
+/* Conditional posterior: which of its two extra passes would run on the matrix pipe (csrc/vibo_cmean.hip) for `d` -- bit 0 the
+ * experts' per-person sums, bit 1 the scatter of the table gradient; 0 = both on the VALU kernels (csrc/vibo_cond.hip, or not a
+ * conditional-posterior call), <0 on a bad descriptor. */
+int vibo_plan_cond_passes(const vibo_desc* d);
 
 /* Library / ABI version (VIBO_ABI_VERSION of the build). */
 int vibo_version(void);

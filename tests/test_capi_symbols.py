@@ -59,6 +59,24 @@ def test_planner_reports_its_kernel_and_honours_the_flags():
     assert plan(16, 1000, 8, _lib.FLAG_KERNEL_MATRIX) == 1 and plan(1_000_000, 1000, 8, _lib.FLAG_KERNEL_VALU) == 2
     assert plan(1000, 1000, 2, 0, _lib.MASK_I64) == 3
     assert plan(16, 1000, 8, 3) < 0 and plan(16, 1000, 8, 64) < 0                    # contradictory / unknown flags
+    # the conditional posterior's two extra passes: matrix pipe from 4 096 persons when the rows are (or become) cell codes;
+    # fp32 rows keep the VALU pre pass (it emits the codes) up to 4 ability dims
+    def cond(B, I, A, flags=0, mask=_lib.MASK_U8, grad=1):
+        d = _lib.ViboDesc()
+        d.abi_version = _lib.ABI_VERSION
+        d.num_person, d.num_item, d.ability_dim, d.irt_model = B, I, A, 2
+        d.posterior = _lib.POSTERIOR_CONDITIONAL
+        d.mask_dtype, d.want_grad, d.flags = mask, grad, flags
+        d.response_row_stride = d.mask_row_stride = (I + 3) & ~3
+        return lib.vibo_plan_cond_passes(ctypes.byref(d))
+
+    assert cond(1_000_000, 1000, 8, mask=_lib.MASK_CODES) == 3 and cond(1_000_000, 1000, 1, mask=_lib.MASK_CODES) == 3
+    assert cond(1_000_000, 1000, 8) == 3 and cond(1_000_000, 1000, 4) == 2 and cond(1_000_000, 1000, 1) == 2
+    assert cond(16, 1000, 8, mask=_lib.MASK_CODES) == 0 and cond(4095, 1000, 1, mask=_lib.MASK_CODES) == 0
+    assert cond(1_000_000, 1000, 8, _lib.FLAG_COND_VALU, _lib.MASK_CODES) == 0
+    assert cond(1_000_000, 1000, 8, _lib.FLAG_NO_EMIT_CODES) == 0                    # fp32 rows that stay fp32: nothing to read
+    assert cond(1_000_000, 1000, 8, mask=_lib.MASK_CODES, grad=0) == 1               # forward only: no gradient pass at all
+    assert plan(1_000_000, 1000, 8) == 1 and lib.vibo_plan_cond_passes is not None
     import os
     os.environ['VIBO_MSPLIT'] = '0'                                                  # (round 2's switch: ignored now)
     try:

@@ -850,6 +850,16 @@ extern "C" {
 
 int vibo_version(void) { return VIBO_ABI_VERSION; }
 
+int vibo_plan_cond_passes(const vibo_desc* d) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    Plan pl;
+    rc = make_plan(d, &pl);
+    if (rc < 0) return rc;
+    if (pl.general || !pl.cond) return 0;
+    return (pl.cmat_pre ? 1 : 0) | (pl.cmat_post ? 2 : 0);
+}
+
 int vibo_plan_kernel(const vibo_desc* d) {
     int rc = check_desc(d);
     if (rc) return rc;

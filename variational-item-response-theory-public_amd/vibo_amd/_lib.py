@@ -62,7 +62,7 @@ class ViboDecoderDesc(ctypes.Structure):
     ]
 
 
-EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes', 'vibo_plan_kernel',
+EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes', 'vibo_plan_kernel', 'vibo_plan_cond_passes',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
                     'vibo_mean_encoder_forward', 'vibo_mean_encoder_backward', 'vibo_train_prologue_noise',
@@ -98,6 +98,8 @@ def load():
     lib.vibo_workspace_bytes.argtypes = [dp]
     lib.vibo_plan_kernel.restype = ctypes.c_int
     lib.vibo_plan_kernel.argtypes = [dp]
+    lib.vibo_plan_cond_passes.restype = ctypes.c_int
+    lib.vibo_plan_cond_passes.argtypes = [dp]
     lib.vibo_elbo_fwd_bwd.restype = ctypes.c_int
     lib.vibo_elbo_fwd_bwd.argtypes = [dp, fp, vp, i64p, fp, fp, fp, fp,      # inputs
                                       fp, fp, fp, fp, fp, fp,                # scalars + posterior outputs
