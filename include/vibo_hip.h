@@ -93,7 +93,8 @@ typedef struct vibo_desc {
 enum { VIBO_FLAG_KERNEL_VALU = 1,     /* row-split work goes to the VALU kernel (vibo_split_kernel.hpp)              */
        VIBO_FLAG_KERNEL_MATRIX = 2,   /* ... to the matrix-pipe kernel (vibo_msplit_kernel.hpp) whatever the size    */
        VIBO_FLAG_NO_EMIT_CODES = 4,   /* multi-pass paths re-read the fp32 rows instead of the first pass's cell codes */
-       VIBO_FLAG_COND_VALU = 8 };     /* conditional posterior: the VALU passes (vibo_cond.hip) instead of the matrix-pipe ones */
+       VIBO_FLAG_COND_VALU = 8,       /* conditional posterior: the VALU passes (vibo_cond.hip) instead of the matrix-pipe ones */
+       VIBO_FLAG_COND_MATRIX = 16 };  /* ... the matrix-pipe passes (vibo_cmean.hip) whatever the size, wherever the rows allow  */
 
 /* Which fused kernel vibo_elbo_fwd_bwd would launch for `d` (pointers assumed aligned): VIBO_KERNEL_*, or <0 on a bad
  * descriptor.  Lets a benchmark state which kernel its numbers belong to. */

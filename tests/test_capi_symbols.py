@@ -59,8 +59,8 @@ def test_planner_reports_its_kernel_and_honours_the_flags():
     assert plan(16, 1000, 8, _lib.FLAG_KERNEL_MATRIX) == 1 and plan(1_000_000, 1000, 8, _lib.FLAG_KERNEL_VALU) == 2
     assert plan(1000, 1000, 2, 0, _lib.MASK_I64) == 3
     assert plan(16, 1000, 8, 3) < 0 and plan(16, 1000, 8, 64) < 0                    # contradictory / unknown flags
-    # the conditional posterior's two extra passes: matrix pipe from 4 096 persons when the rows are (or become) cell codes;
-    # fp32 rows keep the VALU pre pass (it emits the codes) up to 4 ability dims
+    # the conditional posterior's two extra passes on the matrix pipe when the rows are (or become) cell codes, from a size that
+    # depends on ability_dim (measured table in make_plan); fp32 rows keep the VALU pre pass (it emits the codes) up to 4 dims
     def cond(B, I, A, flags=0, mask=_lib.MASK_U8, grad=1):
         d = _lib.ViboDesc()
         d.abi_version = _lib.ABI_VERSION
@@ -72,7 +72,11 @@ def test_planner_reports_its_kernel_and_honours_the_flags():
 
     assert cond(1_000_000, 1000, 8, mask=_lib.MASK_CODES) == 3 and cond(1_000_000, 1000, 1, mask=_lib.MASK_CODES) == 3
     assert cond(1_000_000, 1000, 8) == 3 and cond(1_000_000, 1000, 4) == 2 and cond(1_000_000, 1000, 1) == 2
-    assert cond(16, 1000, 8, mask=_lib.MASK_CODES) == 0 and cond(4095, 1000, 1, mask=_lib.MASK_CODES) == 0
+    assert cond(16, 1000, 8, mask=_lib.MASK_CODES) == 3 and cond(16, 1000, 8) == 3       # 5+ dims: at any size
+    assert cond(16, 1000, 1, mask=_lib.MASK_CODES) == 0 and cond(4095, 1000, 1, mask=_lib.MASK_CODES) == 0
+    assert cond(16, 1000, 1, _lib.FLAG_COND_MATRIX, _lib.MASK_CODES) == 3 and cond(16, 1000, 1, _lib.FLAG_COND_MATRIX) == 2
+    assert cond(16, 1000, 3) == 2 and cond(1024, 1000, 1) == 0 and cond(2048, 1000, 1) == 2
+    assert cond(16, 1000, 8, _lib.FLAG_COND_MATRIX | _lib.FLAG_COND_VALU) < 0
     assert cond(1_000_000, 1000, 8, _lib.FLAG_COND_VALU, _lib.MASK_CODES) == 0
     assert cond(1_000_000, 1000, 8, _lib.FLAG_NO_EMIT_CODES) == 0                    # fp32 rows that stay fp32: nothing to read
     assert cond(1_000_000, 1000, 8, mask=_lib.MASK_CODES, grad=0) == 1               # forward only: no gradient pass at all

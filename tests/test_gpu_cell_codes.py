@@ -15,17 +15,18 @@ from vibo_amd.trainer import FusedTrainer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU,
-                        _lib.FLAG_KERNEL_VALU],
-                ids=['matrix-kernel', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-matrix-posterior'])
+@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU,
+                        _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_VALU],
+                ids=['matrix-kernels', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-planned-posterior'])
 def row_split_kernel_choice(request, monkeypatch):
     """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
     above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; vibo_desc.flags pins one for the whole test
     (ops.DESC_FLAGS: the library reads no environment variable).  Third run: the multi-pass paths (conditional posterior, more
     than 1024 items) re-read the fp32 rows in every pass instead of the 1-byte cell codes their first pass leaves behind
     (VIBO_FLAG_NO_EMIT_CODES).  The conditional posterior's two passes have a matrix-pipe form (vibo_cmean.hip, the default
-    for 4 096 persons or more whose rows are cell codes) and a VALU form (vibo_cond.hip, VIBO_FLAG_COND_VALU): the second and
-    third runs pin the VALU form, the fourth the VALU row-split kernel around whatever the planner picks."""
+    from a call size that depends on ability_dim when the rows are cell codes, VIBO_FLAG_COND_MATRIX pins it) and a VALU form
+    (vibo_cond.hip, VIBO_FLAG_COND_VALU): the first run pins the matrix-pipe form, the second and third the VALU form, the fourth
+    runs the VALU row-split kernel around whatever the planner picks."""
     monkeypatch.setattr(ops, 'DESC_FLAGS', request.param)
 dev = torch.device('cuda:0')
 
@@ -92,7 +93,7 @@ def test_codes_equal_reference_layout(irt, A, B, I, cond, n_flows, drop, gather,
     if drop:
         mask[:, 0] = True
         resp[:, 0] = resp[:, 0].clamp(min=0)
-    rows = torch.randperm(B + 6)[:B].to(dev) if gather else None
+    rows = torch.randperm(B + 6, generator=torch.Generator().manual_seed(B + I))[:B].to(dev) if gather else None
     if rows is None:
         resp, mask = resp[:B], mask[:B]
     reg = _lib.REG_SAMPLED if n_flows else _lib.REG_KL
@@ -107,12 +108,32 @@ def test_codes_equal_reference_layout(irt, A, B, I, cond, n_flows, drop, gather,
              (got.ability, ref.ability)]
     if n_flows:
         pairs += [(got.ability_k, ref.ability_k), (got.ability_ladj, ref.ability_ladj)]
+    # same fp8 code words, same fixed-order reductions: bit for bit -- except where the two calls take different forms of the
+    # conditional posterior's pre pass (cell codes: matrix pipe when pinned or planned; fp32 rows up to 4 dims: the VALU pass)
+    lib, ct = _lib.load(), __import__('ctypes')
+    forms = [0, 0]
+    if cond:
+        forms = [lib.vibo_plan_cond_passes(ct.byref(ops._make_desc(spec, B, I, code, reg, want_grad, r.stride(0), m.stride(0) if m is not None else 0))),
+                 lib.vibo_plan_cond_passes(ct.byref(ops._make_desc(spec, B, I, ccode, reg, want_grad, c.stride(0), cm.stride(0))))]
+        assert min(forms) >= 0
     for k, (x, y) in enumerate(pairs):
-        assert torch.equal(x, y), k          # same fp8 code words, same fixed-order reductions
+        if forms[0] == forms[1]:
+            if k == 0:       # (the two diagnostic sums log q(theta_0), log p(theta_K) of the KL-mode call: the gathered fp32 and the
+                             #  cell-code instantiation of the matrix kernel contract their per-person terms differently -- 1 ulp of
+                             #  the sum on ~6 % of row subsets, tools/scratch/stress_case.py; everything the loss uses is bit-identical)
+                keep = torch.ones_like(x, dtype=torch.bool)
+                keep[_lib.S_LOGQ0] = keep[_lib.S_LOGP] = False
+                assert torch.equal(x[keep], y[keep]), k
+                assert torch.allclose(x[~keep], y[~keep], rtol=1e-6, atol=0), k
+                continue
+            assert torch.equal(x, y), k
+        else:
+            assert (x - y).abs().max() <= 3e-6 * max(1.0, float(y.abs().max())), k
     # forward-only posterior (encode) and the multi-sample forward read the same rows
     emu, elv = ops._hip_encode(spec, c, cm, ccode, rows, table, B)
     rmu, rlv = ops._hip_encode(spec, r, m, code, rows, table, B)
-    assert torch.allclose(emu, rmu, rtol=0, atol=1e-6) and torch.allclose(elv, rlv, rtol=0, atol=1e-6)
+    # (the two calls may take different forms of the pre pass: a few ulps of log sigma^2 ~ -7)
+    assert torch.allclose(emu, rmu, rtol=0, atol=1e-6) and torch.allclose(elv, rlv, rtol=1e-6, atol=1e-6)
     if not cond and not want_grad:
         items = torch.stack([item, item * 0.5, item + 0.1]).contiguous()
         epss = torch.stack([eps, -eps, eps * 0.3]).contiguous()
@@ -149,7 +170,9 @@ def test_module_and_trainer_on_cell_codes(cls, A, I, kw):
     m_ref = cls(A, I, ability_merge='product', **kw).to(dev)
     m_cod = copy.deepcopy(m_ref)
     rows = torch.randperm(300, generator=g)[:64].to(dev)
-    tol = 0.0
+    # bit for bit -- except with the conditional posterior, whose extra passes take the form that is faster for the row format
+    # (fp32 rows: the VALU pre pass that also emits the codes; cell codes: the matrix pipe from a size that depends on ability_dim)
+    tol = 3e-6 if kw.get('conditional_posterior') else 0.0
     for model, (r, m) in ((m_ref, (resp, mask)), (m_cod, (codes, None))):
         torch.manual_seed(11)
         loss = model.elbo_step(r, m, annealing_factor=0.7, row_index=rows)
@@ -163,7 +186,7 @@ def test_module_and_trainer_on_cell_codes(cls, A, I, kw):
     for (k, a), (_, b) in zip(m_cod.named_parameters(), m_ref.named_parameters()):
         assert (a.grad - b.grad).abs().max() <= tol * max(1.0, float(b.grad.abs().max())) , k
     for a, b in zip(m_cod._enc, m_ref._enc):
-        assert torch.allclose(a, b, rtol=0, atol=1e-6)
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
     assert torch.allclose(m_cod._lm, m_ref._lm, rtol=1e-6, atol=1e-4)
     if not kw:
         t_ref, t_cod = FusedTrainer(m_ref, lr=5e-3), FusedTrainer(m_cod, lr=5e-3)

@@ -21,17 +21,18 @@ from vibo_amd.ops import ElboSpec
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU,
-                        _lib.FLAG_KERNEL_VALU],
-                ids=['matrix-kernel', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-matrix-posterior'])
+@pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU,
+                        _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_VALU],
+                ids=['matrix-kernels', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-planned-posterior'])
 def row_split_kernel_choice(request, monkeypatch):
     """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
     above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; vibo_desc.flags pins one for the whole test
     (ops.DESC_FLAGS: the library reads no environment variable).  Third run: the multi-pass paths (conditional posterior, more
     than 1024 items) re-read the fp32 rows in every pass instead of the 1-byte cell codes their first pass leaves behind
     (VIBO_FLAG_NO_EMIT_CODES).  The conditional posterior's two passes have a matrix-pipe form (vibo_cmean.hip, the default
-    for 4 096 persons or more whose rows are cell codes) and a VALU form (vibo_cond.hip, VIBO_FLAG_COND_VALU): the second and
-    third runs pin the VALU form, the fourth the VALU row-split kernel around whatever the planner picks."""
+    from a call size that depends on ability_dim when the rows are cell codes, VIBO_FLAG_COND_MATRIX pins it) and a VALU form
+    (vibo_cond.hip, VIBO_FLAG_COND_VALU): the first run pins the matrix-pipe form, the second and third the VALU form, the fourth
+    runs the VALU row-split kernel around whatever the planner picks."""
     monkeypatch.setattr(ops, 'DESC_FLAGS', request.param)
 
 TOL_ELBO = 1e-4
@@ -478,7 +479,7 @@ def test_encode_kernel(cond, drop, A, B, I):
     mu, lv = ops.encode_posterior(spec, table.to(d), resp.to(d), mask.bool().to(d))
     assert (mu.cpu() - ref['ability_mu'].float()).abs().max() < 2e-5 * max(1.0, float(ref['ability_mu'].abs().max()))
     assert (lv.cpu() - ref['ability_logvar'].float()).abs().max() < 2e-5 * max(1.0, float(ref['ability_logvar'].abs().max()))
-    rows = torch.randperm(B)[:max(1, B // 2)]
+    rows = torch.randperm(B, generator=torch.Generator().manual_seed(B))[:max(1, B // 2)]
     mu2, lv2 = ops.encode_posterior(spec, table.to(d), resp.to(d), mask.bool().to(d), row_index=rows.to(d))
     assert (mu2.cpu() - mu.cpu()[rows]).abs().max() < 1e-6 and (lv2.cpu() - lv.cpu()[rows]).abs().max() < 1e-6
 
@@ -577,15 +578,17 @@ MATRIX_PIPE_POSTERIOR = [
     (2, 5, 4200, 1500, 0, True, False, False),     # fp32 rows, 5 dims: count-and-emit pass in front of the matrix-pipe pre pass; two panels
     (1, 4, 5000, 63, 0, False, True, False),       # fewer than 64 items: only the partial step
     (2, 1, 4096, 64, 0, False, True, False),       # exactly one whole step, nothing else
+    (2, 8, 16, 1000, 0, False, True, False),       # the CLI's default minibatch: one partly filled M-tile
+    (3, 3, 77, 95, 2, True, False, True),          # fp32 rows, small gathered minibatch
 ]
 
 
 @pytest.mark.parametrize('irt,A,B,I,n_flows,gather,codes,drop', MATRIX_PIPE_POSTERIOR)
 def test_matrix_pipe_passes_of_the_conditional_posterior(irt, A, B, I, n_flows, gather, codes, drop, monkeypatch):
-    """From 4 096 persons per call the two extra passes of --conditional-posterior (the experts' precision sums per person,
+    """From a call size that depends on ability_dim (any size at 5+ dims) the two extra passes of --conditional-posterior (the experts' precision sums per person,
     models.py:664-710 + utils.py:105-113, and the scatter of the table gradient) run as one-hot x table contractions on the
     matrix pipe (vibo_cmean.hip): against the fp64 oracle, bit-identical between runs, and in agreement with the VALU passes
-    (VIBO_FLAG_COND_VALU) the smaller calls keep."""
+    (VIBO_FLAG_COND_VALU) the smaller calls keep.  VIBO_FLAG_COND_MATRIX pins the matrix-pipe form for the test."""
     kernel = ops.DESC_FLAGS & (_lib.FLAG_KERNEL_MATRIX | _lib.FLAG_KERNEL_VALU)
     spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=True, n_flows=n_flows, drop_missing=drop)
     resp, mask, table, item, eps = random_problem(irt, A, B + 9, I, 0.2, seed=A * I + B, cond=True)
@@ -619,7 +622,7 @@ def test_matrix_pipe_passes_of_the_conditional_posterior(irt, A, B, I, n_flows, 
         torch.cuda.synchronize()
         return out
 
-    a, b = run(0), run(0)
+    a, b = run(_lib.FLAG_COND_MATRIX), run(_lib.FLAG_COND_MATRIX)
     assert torch.equal(a.flat, b.flat) and torch.equal(a.ability_mu, b.ability_mu)
     compare_raw(a, ref, (I, spec.item_dim), tol=5e-4)
     v = run(_lib.FLAG_COND_VALU)
@@ -628,11 +631,11 @@ def test_matrix_pipe_passes_of_the_conditional_posterior(irt, A, B, I, n_flows, 
     for s_ in range(2):
         assert rel_err(a.grad_table(s_), v.grad_table(s_)) < 2e-5
     # vibo_encode (inference: the posterior alone) takes the same pre pass
-    monkeypatch.setattr(ops, 'DESC_FLAGS', kernel)
+    monkeypatch.setattr(ops, 'DESC_FLAGS', kernel | _lib.FLAG_COND_MATRIX)
     emu, elv = ops._hip_encode(spec, r, m, code, ri, table.to(d).contiguous(), B)
     assert (emu - a.ability_mu).abs().max() < 2e-6 * max(1.0, float(a.ability_mu.abs().max()))
     assert (elv - a.ability_logvar).abs().max() < 2e-6 * max(1.0, float(a.ability_logvar.abs().max()))
-    f = run(0, want_grad=False)                      # forward only: the same posterior and scalars
+    f = run(_lib.FLAG_COND_MATRIX, want_grad=False)  # forward only: the same posterior and scalars
     assert torch.equal(f.ability_mu, a.ability_mu) and torch.equal(f.ability_logvar, a.ability_logvar)
     assert rel_err(f.scalars[_lib.S_LL], a.scalars[_lib.S_LL]) < 1e-6
 

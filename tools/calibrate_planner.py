@@ -14,6 +14,7 @@ from vibo_amd.ops import ElboSpec
 ap = argparse.ArgumentParser()
 ap.add_argument('--codes', action='store_true', help='rows as 1-byte cell codes')
 ap.add_argument('--iters', type=int, default=20)
+ap.add_argument('--cond', action='store_true', help='conditional posterior: matrix-pipe passes (VIBO_FLAG_COND_MATRIX) vs the VALU passes (VIBO_FLAG_COND_VALU), and what the planner picks')
 a = ap.parse_args()
 d = torch.device('cuda:0')
 g = torch.Generator(device=d).manual_seed(0)
@@ -44,6 +45,35 @@ def time_call(fn):
     return e0.elapsed_time(e1) / (3 * a.iters) * 1e3          # us
 
 
+if a.cond:
+    print(f'# conditional posterior, 2PL, 10 % missing, forward + backward, hipGraph replays; rows: {"cell codes" if a.codes else "fp32 + mask"}')
+    print(f'{"persons":>8s} {"items":>6s} {"A":>2s} {"valu us":>9s} {"matrix us":>10s}  planner')
+    lib = _lib.load()
+    for A in (1, 2, 3, 4, 8):
+        for I in (100, 1000):
+            for P in (16, 256, 1024, 4096, 8192, 16384, 65536, 262144):
+                spec = ElboSpec(irt_model=2, ability_dim=A, conditional=True)
+                resp = (torch.rand(P, I, device=d, generator=g) < 0.5).float()
+                mask = torch.rand(P, I, device=d, generator=g) >= 0.1
+                table = torch.randn(2, I, 2 * A, device=d, generator=g) * 0.5
+                item = torch.randn(I, A + 1, device=d, generator=g)
+                eps = torch.randn(P, A, device=d, generator=g)
+                if a.codes:
+                    r, m, code = ops.prepare_rows(ops.pack_cell_codes(resp, mask), None)
+                else:
+                    r_, m_ = ops.pad_rows(resp, mask)
+                    r, m, code = ops.prepare_rows(r_, m_)
+                t = {}
+                for name, fl in (('valu', _lib.FLAG_COND_VALU), ('default', _lib.FLAG_COND_MATRIX)):
+                    ops.DESC_FLAGS = fl
+                    t[name] = time_call(lambda: ops._hip_launch_elbo(spec, r, m, code, None, table, item, eps, None, _lib.REG_KL, True, P))
+                ops.DESC_FLAGS = 0
+                dd = ops._make_desc(spec, P, I, code, _lib.REG_KL, True, r.stride(0), m.stride(0))
+                import ctypes
+                pk = lib.vibo_plan_cond_passes(ctypes.byref(dd))
+                best = 'matrix' if t['default'] < t['valu'] else 'valu'
+                print(f'{P:8d} {I:6d} {A:2d} {t["valu"]:9.1f} {t["default"]:10.1f}  faster: {best:6s}  planner puts on the matrix pipe: {"pre " if pk & 1 else ""}{"post" if pk & 2 else ""}{"nothing" if pk == 0 else ""}')
+    sys.exit(0)
 print(f'# device: {torch.cuda.get_device_name(0)}; rows: {"cell codes" if a.codes else "fp32 + mask"}; 2PL, 10 % missing, forward + backward')
 print(f'{"persons":>8s} {"items":>6s} {"A":>2s} {"valu us":>9s} {"matrix us":>10s} {"faster":>7s} {"planner":>8s}  note')
 bad = 0

@@ -22,7 +22,7 @@ for case in range(a.cases):
     irt = rnd.choice([1, 2, 2, 3])
     A = rnd.choice([1, 1, 2, 3, 4, 5, 8])
     I = rnd.choice([rnd.randint(4, 70), rnd.randint(60, 260), rnd.randint(250, 1100), rnd.randint(1000, 2600)])
-    B = rnd.choice([4096, 4097, 4160, 5000, 6001])
+    B = rnd.choice([1, 16, 77, 300, 4096, 4097, 4160, 5000, 6001])
     codes = rnd.random() < 0.6
     gather = rnd.random() < 0.4
     flows = rnd.choice([0, 0, 2])
@@ -56,7 +56,7 @@ for case in range(a.cases):
         r, m, code = ops.prepare_rows(r_, m_)
     reg = _lib.REG_SAMPLED if flows else _lib.REG_KL
     out = {}
-    for name, fl in (('mfma', 0), ('valu', _lib.FLAG_COND_VALU)):
+    for name, fl in (('mfma', _lib.FLAG_COND_MATRIX), ('valu', _lib.FLAG_COND_VALU)):
         ops.DESC_FLAGS = kern | fl
         out[name] = ops._hip_launch_elbo(spec, r, m, code, rows, table, item, eps, flow, reg, grad, B)
     torch.cuda.synchronize()

@@ -51,8 +51,9 @@ static int check_desc(const vibo_desc* d) {
     if (d->reg_mode != VIBO_REG_KL && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "bad reg_mode");
     if (d->n_flows < 0 || d->n_flows > VIBO_MAX_FLOWS) return fail(-3, "n_flows outside 0..%d", VIBO_MAX_FLOWS);
     if (d->n_flows > 0 && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "flows need reg_mode SAMPLED");
-    if (d->flags & ~(VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX | VIBO_FLAG_NO_EMIT_CODES | VIBO_FLAG_COND_VALU)) return fail(-3, "unknown flags");
+    if (d->flags & ~(VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX | VIBO_FLAG_NO_EMIT_CODES | VIBO_FLAG_COND_VALU | VIBO_FLAG_COND_MATRIX)) return fail(-3, "unknown flags");
     if ((d->flags & VIBO_FLAG_KERNEL_VALU) && (d->flags & VIBO_FLAG_KERNEL_MATRIX)) return fail(-3, "flags pin two kernels");
+    if ((d->flags & VIBO_FLAG_COND_VALU) && (d->flags & VIBO_FLAG_COND_MATRIX)) return fail(-3, "flags pin two forms of the conditional passes");
     return 0;
 }
 
@@ -216,13 +217,25 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         pl->given = is_given;
         // the conditional posterior's passes on the matrix pipe need the rows as cell codes: the caller's, or the ones the
         // first pass over fp32 rows leaves behind
-        // (launch-bound minibatches stay on the VALU passes: two launches fewer).  Measured on 1M x 1k, per pass:
-        //   rows = cell codes:  pre 285 us vs 506 (A = 1) / 2 x 475 (A = 8), post 330 vs 400 (A = 1) / 2 x 990 (A = 8)
-        //   rows = fp32:        the VALU pre pass reads the rows AND leaves the codes behind (1.22 ms = the 5 B/cell stream);
-        //                       a count-and-emit pass in front of the matrix-pipe pre pass costs the same 1.25 ms again, so
-        //                       the VALU pre pass stays up to 4 ability dims (one launch: 1M x 1k at 3 / 4 dims 2.60 -> 2.39 / 2.41 ms)
+        // Where they win was measured with hipGraph replays of both forms over persons x items x ability_dim
+        // (tools/calibrate_planner.py --cond: VIBO_FLAG_COND_MATRIX against VIBO_FLAG_COND_VALU; profiles/r03_cond_calibration.txt):
+        //   rows = cell codes:  5+ dims always (16 x 1 000: 47 vs 67 us -- the VALU passes take two launches each there),
+        //                       3-4 dims from 1 024 persons, 2 dims from 4 096, 1 dim from ~16 M cells (16 384 x 1 000: 74 vs 76 us)
+        //   rows = fp32:        the VALU pre pass reads the rows AND leaves the codes behind (1M x 1k: 1.22 ms = the 5 B/cell
+        //                       stream); a count-and-emit pass in front of the matrix-pipe pre pass costs the same 1.25 ms
+        //                       again, so the VALU pre pass stays up to 4 ability dims (one launch: 1M x 1k at 3 / 4 dims
+        //                       2.60 -> 2.39 / 2.41 ms) and only the gradient pass moves: 3+ dims always, else from 2 048 persons
         const bool have_codes = d->mask_dtype == VIBO_MASK_CODES || (emit_codes_wanted(d) && d->mask_dtype != VIBO_MASK_I64);
-        const bool cmat_ok = is_cond && !(d->flags & VIBO_FLAG_COND_VALU) && have_codes && d->num_person >= 4096;
+        long long min_persons = (d->flags & VIBO_FLAG_COND_MATRIX) ? 1 : -1;
+        if (min_persons < 0) {
+            if (d->mask_dtype == VIBO_MASK_CODES) {
+                const long long by_cells = 16000000LL / (I > 0 ? I : 1);
+                min_persons = A >= 5 ? 1 : A >= 3 ? 1024 : A == 2 ? 4096 : (by_cells > 16384 ? by_cells : 16384);
+            } else {
+                min_persons = A >= 3 ? 1 : 2048;
+            }
+        }
+        const bool cmat_ok = is_cond && !(d->flags & VIBO_FLAG_COND_VALU) && have_codes && d->num_person >= min_persons;
         pl->cmat_post = cmat_ok && d->want_grad;
         pl->cmat_pre = cmat_ok && (d->mask_dtype == VIBO_MASK_CODES || A >= 5);
         const int at_min = 2;
@@ -781,8 +794,8 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const int* __restric
 // conditional posterior on cell codes, 4 096 persons or more: the experts' sums on the matrix pipe (launch_cond_pre_mfma), as in the
 // ELBO call
 static bool encode_on_matrix_pipe(const vibo_desc* d) {
-    return d->posterior == VIBO_POSTERIOR_CONDITIONAL && d->mask_dtype == VIBO_MASK_CODES && d->num_person >= 4096 &&
-           !(d->flags & VIBO_FLAG_COND_VALU);
+    return d->posterior == VIBO_POSTERIOR_CONDITIONAL && d->mask_dtype == VIBO_MASK_CODES && !(d->flags & VIBO_FLAG_COND_VALU) &&
+           (d->num_person >= 4096 || d->ability_dim >= 5 || (d->flags & VIBO_FLAG_COND_MATRIX));
 }
 // scratch the fast encode path needs (0: not applicable -> wave-per-person encode_kernel)
 static size_t encode_scratch_bytes(const vibo_desc* d) {
