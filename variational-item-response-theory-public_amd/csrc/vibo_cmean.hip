@@ -392,6 +392,10 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
             q = q < B ? q : B - 1;
             if constexpr (GATHER) q = row_index[q];
             const uint8_t* rp = codes + q * stride;
+#ifdef CM_EXP_BWD_NOLOAD
+            w[mt] = uint4{(uint32_t)(q + lane) & 0x01010101u, (uint32_t)lane & 0x01010101u, 0u, 0x01000100u};
+            continue;
+#endif
             if constexpr (TAIL == 0) w[mt] = cm_load_full<AL>(rp, i0);
             else if constexpr (TAIL == 1) w[mt] = cm_load_padded<AL>(rp, I, i0);
             else w[mt] = cm_load_tail(rp, I, i0);
@@ -430,6 +434,11 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
             }
         __builtin_amdgcn_sched_barrier(0);
         fetch(wnext, p0 + 2 * PS);
+#ifdef CM_EXP_BWD_NOMFMA
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[0][0][0] += (float)__popc(w[mt].x ^ w[mt].y ^ w[mt].z ^ w[mt].w) + bg[0][0][0].x * 1e-30f;
+        return;
+#endif
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
             *reinterpret_cast<uint4*>(tile + wofs[mt][0]) = cm_onehot(w[mt].x);
