@@ -5,37 +5,42 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json: "person x item ELBO terms/sec on 1M x 1k 2PL", configs[2]'s shape per GPU):
-2PL, 1 000 000 persons x 1 000 items per GPU, ability_dim 8, synthetic Bernoulli responses with 10 % missing
-cells, device-resident (inputs are in HBM before the timed region).  `also` repeats the measurement at
-ability_dim 1 (configs[1]'s width, the reference default).  One step = one ELBO train step over the GPU's whole
-person shard, replayed from a hipGraph: reparameterisation noise (vibo_fill_normal), vibo_train_prologue (item
-sample, item KL, encoder table), the fused HIP forward+backward over the [B,I] response matrix + finalize, ONE
-all-reduce of the flat [scalars|grads] buffer when N > 1 (persons are sharded, weak scaling; two graphs around an
-eager RCCL all-reduce), vibo_train_epilogue (loss, encoder-MLP / item backward, Adam).
+Workload (BASELINE.json: "person x item ELBO terms/sec on 1M x 1k 2PL", configs[2] literally): 2PL, 1 000 000 persons x 1 000
+items, ability_dim 8, synthetic Bernoulli responses with 10 % missing cells, device-resident (inputs are in HBM before the
+timed region), the persons sharded over the N ranks (`--scaling strong`, the default: at N = 1 the one GPU holds the whole
+matrix; `--scaling weak` gives every rank 1M persons, and a run with N > 1 reports that too, under `also_weak`).  `also`
+repeats the measurement at ability_dim 1 (configs[1]'s width, the reference default).  One step = one ELBO train step over the
+rank's whole person shard, replayed from a hipGraph -- TWO launches (the folded step, vibo_amd/trainer.py):
+vibo_elbo_fwd_bwd_train (the row-split ELBO kernel; its own prologue forms the item sample, the item KL and the encoder
+table) and vibo_train_epilogue_fused (finalize, loss, encoder-MLP / item backward, Adam, the next step's Philox noise); with
+N > 1 the finalize stays with the first launch and ONE all-reduce of the flat [scalars | grads] buffer sits between the two
+(captured inside the step's graph by default, `--two-graphs` for an eager collective between two graphs).
 --torch-optimizer runs the O(I) part as PyTorch autograd + torch.optim.Adam instead.
 
 Adds to the contract line:
-  roofline      the fused kernel's achieved HBM GB/s = algorithmic bytes (5 + 12A/I per term) x terms
-                per launch / its average duration, measured with HIP events on the launch stream (an eager pass of
-                the same step right after the timed region when the step is graph-replayed); peak 8000 GB/s
-                (MI355X_MICROARCH.md), also as a fraction of the 6290 GB/s measured copy ceiling; traffic = the
-                2*FETCH_SIZE + WRITE_SIZE of the kernel PARSED from the committed rocprofv3 summary of this command
-                (profiles/r03_bench_profile.txt, written by tools/collect_profile.sh; null when the file or the kernel's
-                line is missing -- nothing is hard-coded here).
+  roofline      the fused kernel's achieved HBM GB/s = algorithmic bytes (5 + 12A/I per term) x terms per launch
+                / its duration INSIDE the replayed step: HIP events on the launch stream between the step's two launches (the
+                step captured as two graphs for this, replayed back to back after the timed region, mean over the replays) --
+                the number the committed rocprofv3 kernel-trace average of this command (profiles/, PROFILE_FILE) must agree
+                with.  peak 8000 GB/s (MI355X_MICROARCH.md), also as a fraction of the 6290 GB/s measured copy ceiling;
+                `bare_launch_ms` = the same call in a loop of bare eager launches (a note, not the claim);
+                traffic = the 2*FETCH_SIZE + WRITE_SIZE of the kernel PARSED from that profile's --pmc passes (null when the
+                file or the kernel's line is missing -- nothing is hard-coded here).
   elbo_rel_err  |ELBO_hip - ELBO_ref| / |ELBO_ref| on the first 4 096 persons of the benchmark matrix, same parameters
                 and noise, in the same run: ref = the CPU restatement of the reference op sequence (fp32, the
-                reference's arithmetic); also against its fp64 evaluation.  4 096 persons is above the planner's
-                2 048-person threshold: the call runs on the kernel the timed step runs on, and the line says so
+                reference's arithmetic); also against its fp64 evaluation.  The sample runs on the kernel the timed step
+                runs on (pinned through vibo_desc.flags where the planner would choose differently for 4 096 persons:
+                the matrix kernel starts at 4 096 persons / 32 768 at ability_dim <= 4), and the line says so
                 (elbo_rel_err_detail.kernel = vibo_plan_kernel's answer).  `also` and `format_p` carry their own.
   roofline.frac_step  the same algorithmic bytes over the whole timed step (ms_per_step), next to the kernel-only frac.
-  extra         config5_path: BASELINE configs[4]'s path (3PL, 10 000 items, conditional, 4 flows) on 100 000 persons; decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate); train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md §8d;
+  extra         config5_path: BASELINE configs[4]'s path (3PL, 10 000 items, conditional, 4 flows) on 100 000 persons;
+                decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate);
+                train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md 8d;
                 rows gathered in the kernel, hipGraph replay); the headline is the full shard.
   cpu_baseline  the CPU port of the reference op sequence (per-term MLP -> PoE -> link -> masked log-lik -> autograd ->
                 Adam, oracle/vibo_oracle.py) timed on this host's cores (rank 0, N = 1 only): B = 16 and B = 1024, 3
                 warm-ups + 20 steps each, CPU model and thread count stated; `validated_ratio` = port / REAL reference
                 throughput measured in the build container by tools/validate_cpu_port.py (profiles/r02_cpu_port_validation.json).
-  --scaling strong   divides --persons (the whole matrix) over the ranks instead of giving every rank --persons rows.
 """
 import argparse
 import json
@@ -57,7 +62,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--persons', type=int, default=1_000_000, help='persons per GPU (weak scaling)')
+    ap.add_argument('--persons', type=int, default=1_000_000, help='persons of the whole matrix (--scaling strong) / per GPU (--scaling weak)')
     ap.add_argument('--items', type=int, default=1000)
     ap.add_argument('--ability-dim', type=int, default=8)
     ap.add_argument('--also-ability-dim', type=int, default=1, help='second workload reported under "also" (0 = none)')
@@ -67,7 +72,8 @@ def parse():
     ap.add_argument('--seed', type=int, default=42)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=20)
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak', help="'strong': --persons is the whole matrix, split over the ranks (BASELINE configs[2]: 1M x 1k over 8 GPUs)")
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong', help="'strong' (default): --persons is the whole matrix, split over the ranks (BASELINE configs[2] literally: 1M x 1k over 8 GPUs); 'weak': every rank holds --persons rows")
+    ap.add_argument('--no-also-weak', action='store_true', help='N > 1 under strong scaling: skip the extra weak-scaling measurement (also_weak)')
     ap.add_argument('--no-extra', action='store_true', help='skip the minibatch-size sweep and the ELBO rel-err check')
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
     ap.add_argument('--ability-merge', choices=['product', 'mean'], default='product', help="'mean': the reference's other encoder (models.py:631-650) through VIBO_POSTERIOR_GIVEN + torch autograd / Adam (implies --torch-optimizer --no-graph)")
@@ -75,8 +81,8 @@ def parse():
     ap.add_argument('--torch-optimizer', action='store_true', help='PyTorch autograd + torch.optim.Adam for the O(I) part instead of the fused prologue/epilogue kernels')
     ap.add_argument('--rng', choices=['native', 'torch'], default='native', help='reparameterisation noise: vibo_fill_normal (Philox, in the C ABI) or torch.randn')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
-    ap.add_argument('--one-graph', action='store_true', help='multi-GPU: capture the RCCL all-reduce inside the step\'s hipGraph (one graph per step, no host round trip) instead of two hipGraphs around an EAGER all-reduce.  Both forms are pinned bitwise on a 1-rank nccl group (tests/test_gpu_rccl.py); the captured collective has not run on a real multi-rank node yet, so the eager collective -- which cannot hang a replay -- stays the default')
-    ap.add_argument('--two-graphs', action='store_true', help='(default for N > 1; kept for compatibility)')
+    ap.add_argument('--one-graph', action='store_true', help='(default for N > 1; kept for compatibility) the RCCL all-reduce captured inside the step\'s hipGraph: one graph per step, no host round trip')
+    ap.add_argument('--two-graphs', action='store_true', help='multi-GPU: two hipGraphs around an EAGER all-reduce instead of the captured collective (both forms are pinned bitwise on a 1-rank nccl group, tests/test_gpu_rccl.py; a failed capture falls back to this form by itself)')
     ap.add_argument('--force-dist', action='store_true', help='create the process group even for one rank (tests the RCCL path)')
     return ap.parse_args()
 
@@ -181,7 +187,7 @@ def cpu_baseline(args, irt):
     }
 
 
-PROFILE_FILE = 'r03_bench_profile.txt'      # rocprofv3 summary of this command on this round's build (tools/collect_profile.sh)
+PROFILE_FILE = 'r04_bench_profile.txt'      # rocprofv3 summary of this command on this round's build (tools/collect_profile.sh)
 
 
 def parse_traffic(kernel_tag):
@@ -192,14 +198,14 @@ def parse_traffic(kernel_tag):
     try:
         for ln in open(path):
             t = ln.split()
-            if len(t) >= 3 and kernel_tag in t[0] and t[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            if len(t) >= 3 and 'msplit_kernel' in t[0] and kernel_tag in t[0] and t[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
                 vals.setdefault(t[1], float(t[2]))
     except OSError:
-        return None, 'profiles/r03_bench_profile.txt not found'
+        return None, f'profiles/{PROFILE_FILE} not found'
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
-        return None, f'no FETCH_SIZE / WRITE_SIZE line for {kernel_tag} in profiles/r03_bench_profile.txt'
+        return None, f'no FETCH_SIZE / WRITE_SIZE line for {kernel_tag} in profiles/{PROFILE_FILE}'
     return (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, \
-        f'parsed from profiles/r03_bench_profile.txt: 2*FETCH_SIZE + WRITE_SIZE of {kernel_tag} (KiB counters, separate --pmc passes)'
+        f'parsed from profiles/{PROFILE_FILE}: 2*FETCH_SIZE + WRITE_SIZE of {kernel_tag} (KiB counters, separate --pmc passes)'
 
 
 def main():
@@ -216,6 +222,7 @@ def main():
     one_device = os.environ.get('VIBO_BENCH_ONE_DEVICE') == '1'
     if one_device:
         local_rank = 0
+        args.two_graphs = True          # (gloo's host-side collective cannot be captured into a hipGraph)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
@@ -235,11 +242,13 @@ def main():
     from vibo_amd import ops
     from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
 
-    persons_rank = args.persons if args.scaling == 'weak' else (args.persons * (rank + 1)) // world - (args.persons * rank) // world
+    def shard(scaling):
+        return args.persons if scaling == 'weak' else (args.persons * (rank + 1)) // world - (args.persons * rank) // world
+    persons_rank = shard(args.scaling)
 
-    def measure(A, codes=False, extra=False):
+    def measure(A, codes=False, extra=False, persons=None):
         """-> dict(dt, kern_ms, final_loss, graph) for ability_dim A on this rank's shard."""
-        P, I = persons_rank, args.items
+        P, I = (persons_rank if persons is None else persons), args.items
         resp, mask = synth_responses(irt, P, I, A, args.missing, dev, args.seed + 1000 * rank)
         if codes:           # Format P: the same matrix as one byte per cell (VIBO_MASK_CODES)
             resp, mask = ops.pack_cell_codes(resp, mask), None
@@ -347,7 +356,7 @@ def main():
 
                 launch_mode = 'hipGraph replay'
                 if dist is not None and trainer is not None:
-                    if not args.one_graph:
+                    if args.two_graphs:
                         step_g, launch_mode = capture_two(), 'two hipGraphs around an eager RCCL all-reduce'
                     else:
                         try:
@@ -389,9 +398,35 @@ def main():
             dt = float(t)
         final_loss = float(loss.detach())
 
-        if graph is not None:
-            # events cannot be recorded inside a replayed graph: time the native call on the same stream / inputs
-            # in an eager pass of the same step right after the timed region
+        bare_ms, instep = None, None
+        if graph is not None and trainer is not None and not args.eval_only:
+            # The fused call's duration INSIDE the replayed step.  Events cannot be recorded inside a replayed graph (torch:
+            # "external events are disallowed in rocm"), so the same step is captured once more as its two halves --
+            # forward_backward() = the fused ELBO call, update() = the epilogue -- and the halves are replayed back to back with
+            # HIP events on the launch stream between them: the queue never drains, the kernel runs in the regime of the timed
+            # region (steady replay, the epilogue in front of it), and e0 -> e1 is its launch-to-completion time there.
+            try:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=graph.pool()):
+                    raw_s = trainer.forward_backward(resp, mask)
+                with torch.cuda.graph(gb, pool=graph.pool()):
+                    if dist is not None:
+                        dist.all_reduce(raw_s.flat)
+                    trainer.update()
+                n_ev = max(10, min(args.steps, 50))
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev + 3)]
+                for e0, e1 in evs:
+                    e0.record(); ga.replay(); e1.record(); gb.replay()
+                torch.cuda.synchronize()
+                ks = [a.elapsed_time(b) for a, b in evs[3:]]
+                rs = [evs[k][1].elapsed_time(evs[k + 1][0]) for k in range(3, len(evs) - 1)]
+                instep = {'mean_ms': sum(ks) / len(ks), 'min_ms': min(ks), 'max_ms': max(ks), 'replays': len(ks),
+                          'rest_of_step_ms': sum(rs) / len(rs)}
+            except Exception as exc:
+                print(f'[bench] in-step kernel timing failed ({type(exc).__name__}: {exc})', file=sys.stderr)
+                torch.cuda.synchronize()
+        if graph is not None and instep is None:
+            # (--torch-optimizer / --eval-only: the native call timed in an eager pass of the same step right after the timed region)
             recording['on'] = True
             for _ in range(min(args.steps, 10)):
                 eager_step()
@@ -403,12 +438,10 @@ def main():
             dist.all_reduce(ph, op=dist.ReduceOp.MAX)
             phase_ms = {'forward_backward_graph': float(ph[0]), 'all_reduce': float(ph[1]), 'update_graph': float(ph[2]),
                         'note': 'max over ranks of the mean over 10 replayed steps, HIP events on the launch stream; '
-                                'forward_backward_graph = noise + prologue + fused ELBO kernel + finalize, update_graph = epilogue + Adam'}
+                                'forward_backward_graph = fused ELBO kernel (own prologue) + finalize, update_graph = epilogue + Adam + next noise'}
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
-        if last_call:
-            # sustained-load duration of the fused call: the same launch (item_prep + ELBO kernel + finalize) 10 times back to
-            # back between one pair of events -- single launches inside an eager step run ~10 % faster than under the
-            # steady load of the replayed graph (launch gaps let the clocks recover), and that is not the number to quote
+        if last_call and dist is None:
+            # a note next to the claim: the same call in a loop of bare eager launches (10 back to back between one pair of events)
             reps = 10
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             native(*last_call['a'], **last_call['k'])
@@ -417,7 +450,23 @@ def main():
                 native(*last_call['a'], **last_call['k'])
             e1.record()
             torch.cuda.synchronize()
-            kern_ms = max(kern_ms, e0.elapsed_time(e1) / reps)
+            bare_ms = e0.elapsed_time(e1) / reps
+            if instep is None:
+                kern_ms = max(kern_ms, bare_ms)
+        if instep is not None:
+            kern_ms = instep['mean_ms']
+            if dist is not None and phase_ms is None:
+                # the captured-collective step has no host-visible seams: the two-halves replay above is its breakdown
+                ph = torch.tensor([instep['mean_ms'], instep['rest_of_step_ms']], device=dev, dtype=torch.float64)
+                dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+                phase_ms = {'forward_backward_graph': float(ph[0]), 'all_reduce_and_update_graph': float(ph[1]),
+                            'note': 'max over ranks of the mean over the replays of the step captured as two halves (HIP events between them): '
+                                    'forward_backward_graph = fused ELBO kernel (own prologue) + finalize, '
+                                    'all_reduce_and_update_graph = captured all-reduce + epilogue + Adam + next noise'}
+            if dist is not None:
+                tk = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+                kern_ms = float(tk)
         bytes_per_term = 5.0 + 12.0 * A / I
         achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         ops._BACKEND['elbo'] = native
@@ -429,7 +478,7 @@ def main():
         del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()
         return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None, rel=rel, sweep=sweep,
-                    launch=launch_mode if graph is not None else 'eager', phase_ms=phase_ms)
+                    launch=launch_mode if graph is not None else 'eager', phase_ms=phase_ms, bare_ms=bare_ms, instep=instep)
 
     def elbo_rel_err(model, resp, mask, A, n=4096):
         """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64).
@@ -453,16 +502,14 @@ def main():
         kernel_timed = ops.plan_kernel(model.spec, resp.shape[0], I, mcode, not args.eval_only)
         # the sample is smaller than the timed call: pin the row-split kernel the timed call runs (vibo_desc.flags) where the
         # planner would pick the other one for 4 096 persons (ability_dim <= 4: the VALU kernel below 32 768 persons)
-        saved_flags = ops.DESC_FLAGS
+        pin = ops.DESC_FLAGS
         if ops.plan_kernel(model.spec, n, I, mcode, False) != kernel_timed:
-            ops.DESC_FLAGS = saved_flags | (_lib.FLAG_KERNEL_MATRIX if kernel_timed.startswith('matrix') else
-                                            _lib.FLAG_KERNEL_VALU if kernel_timed.startswith('VALU') else 0)
-        kernel = ops.plan_kernel(model.spec, n, I, mcode, False)
-        try:
+            pin |= (_lib.FLAG_KERNEL_MATRIX if kernel_timed.startswith('matrix') else
+                    _lib.FLAG_KERNEL_VALU if kernel_timed.startswith('VALU') else 0)
+        with ops.desc_flags(pin):
+            kernel = ops.plan_kernel(model.spec, n, I, mcode, False)
             with torch.no_grad():
                 hip = float(model.elbo(*model(hip_rows, hip_mask, eps_item=eps_i, eps_ability=eps_a)))
-        finally:
-            ops.DESC_FLAGS = saved_flags
         out = {}
         for name, dt_ in (('fp32', torch.float32), ('fp64', torch.float64)):
             params = {k: v.detach().cpu().to(dt_) for k, v in model.state_dict().items()}
@@ -530,8 +577,9 @@ def main():
         flop = Bd * I * 3 * 2 * H * H
         return {'workload': f'{Bd} persons x {I} items, per-term 64-64-64-1 decoder (deep), forward + backward, fp32-grade (f16 hi/lo MFMA, 3 passes per product)',
                 'ms': ms, 'terms_per_s': Bd * I / (ms * 1e-3), 'algorithmic_TFLOPs': flop / (ms * 1e-3) / 1e12,
-                'bound': 'mfma + valu', 'peak_fp32_TFLOPs': 157.3, 'frac_of_fp32_peak': flop / (ms * 1e-3) / 1e12 / 157.3,
-                'mfma_issued_TFLOPs': 3 * flop / (ms * 1e-3) / 1e12, 'mfma_util_profile': 'profiles/r02_decoder_pmc.txt (17 %)'}
+                'bound': 'mfma + valu', 'mfma_issued_TFLOPs': 3 * flop / (ms * 1e-3) / 1e12, 'mfma_peak_f16_dense_TFLOPs': 2500.0,
+                'mfma_issue_frac_of_f16_peak': 3 * flop / (ms * 1e-3) / 1e12 / 2500.0,
+                'mfma_util_profile': 'SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles: profiles/r02_decoder_pmc.txt (17 %)'}
 
     def config5_probe():
         """BASELINE configs[4]'s path on a slice of its shape (3PL, 10 000 items, conditional posterior, 4 planar flows, fp32 rows):
@@ -604,6 +652,12 @@ def main():
     bytes_per_term = 5.0 + 12.0 * A / I
     achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     total_persons = float(args.persons) * (world if args.scaling == 'weak' else 1)
+    also_weak = None
+    if world > 1 and args.scaling == 'strong' and not args.no_also_weak:
+        # the same step with --persons rows on EVERY rank (weak scaling), in the same run
+        mw = measure(A, persons=args.persons)
+        also_weak = {'scaling': 'weak', 'persons_per_rank': args.persons, 'value': float(args.persons) * world * I * args.steps / mw['dt'],
+                     'unit': 'terms/s', 'ms_per_step': mw['dt'] / args.steps * 1e3, 'kernel_ms': mw['kern_ms'], 'launch': mw['launch']}
     also = None
     if args.also_ability_dim and args.also_ability_dim != A:
         A2 = args.also_ability_dim
@@ -660,15 +714,22 @@ def main():
                        'persons_per_rank': P, 'phases_ms': m.get('phase_ms')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
-                         # the same bytes over the whole timed step (noise, prologue, kernel, finalize, [all-reduce], epilogue + Adam)
+                         # the same bytes over the whole timed step (kernel with its prologue, [finalize, all-reduce], epilogue + Adam + noise)
                          'frac_step': bytes_per_term * P * I / (dt / args.steps) / 1e9 / 8000.0,
-                         'frac_note': 'frac = algorithmic bytes / mean duration of the fused call by HIP events on its stream (10 back-to-back '
-                                      'calls after the timed region); frac_step = the same bytes / ms_per_step; the rocprofv3 kernel-trace '
-                                      f'average of the same command is in profiles/{PROFILE_FILE}',
+                         'frac_note': ('frac = algorithmic bytes / the fused call\'s duration INSIDE the replayed step: HIP events on the launch '
+                                       'stream between the step\'s two launches (captured as two graphs, replayed back to back after the timed '
+                                       'region; kernel_timing has mean / min / max over the replays' + (', max over ranks' if world > 1 else '') + '); '
+                                       if m.get('instep') else
+                                       'frac = algorithmic bytes / mean duration of the fused call by HIP events on its stream (eager pass after the timed region); ')
+                                      + 'bare_launch_ms = the same call in a loop of bare eager launches (a note, not the claim); frac_step = the same '
+                                        f'bytes / ms_per_step; the rocprofv3 kernel-trace average of the same command is in profiles/{PROFILE_FILE}',
                          'traffic': traffic, 'traffic_note': traffic_note,
-                         'kernel': 'vibo::msplit_kernel (+ the finalize helper inside the timed events)',
-                         'kernel_ms': kern_ms, 'bytes_per_term': bytes_per_term},
+                         'kernel': 'vibo::msplit_kernel (its own prologue forms the item sample and the encoder table)' + (' + the finalize helper' if world > 1 else ''),
+                         'kernel_ms': kern_ms, 'kernel_timing': m.get('instep'), 'bare_launch_ms': m.get('bare_ms'),
+                         'bytes_per_term': bytes_per_term},
         }
+        if also_weak is not None:
+            line['also_weak'] = also_weak
         if m.get('rel') is not None:
             line['elbo_rel_err'] = m['rel']['vs_reference_op_sequence_fp32']
             line['elbo_rel_err_detail'] = m['rel']

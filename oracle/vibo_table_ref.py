@@ -16,7 +16,7 @@ tensor ops (NO autograd), with exactly the kernel's inputs/outputs:
              g_table[2] (d ll / d table, d reg / d table), g_item (d ll / d item),
              g_flow[2]
 
-It is checked (tests/test_table_ref.py) against autograd through
+It is checked (tests/test_host_logic.py::test_table_ref_matches_autograd_oracle) against autograd through
 oracle/vibo_oracle.py, which is itself pinned to the reference goldens; it is
 then the small-shape checker for the kernel's raw outputs and the stand-in the
 CPU host-logic tests monkeypatch in place of the C-ABI call.

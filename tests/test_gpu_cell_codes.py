@@ -120,7 +120,7 @@ def test_codes_equal_reference_layout(irt, A, B, I, cond, n_flows, drop, gather,
         if forms[0] == forms[1]:
             if k == 0:       # (the two diagnostic sums log q(theta_0), log p(theta_K) of the KL-mode call: the gathered fp32 and the
                              #  cell-code instantiation of the matrix kernel contract their per-person terms differently -- 1 ulp of
-                             #  the sum on ~6 % of row subsets, tools/scratch/stress_case.py; everything the loss uses is bit-identical)
+                             #  the sum on ~6 % of row subsets; everything the loss uses is bit-identical)
                 keep = torch.ones_like(x, dtype=torch.bool)
                 keep[_lib.S_LOGQ0] = keep[_lib.S_LOGP] = False
                 assert torch.equal(x[keep], y[keep]), k

@@ -498,9 +498,10 @@ def test_decode_kernel(irt):
 # ---------------------------------------------------------------------------
 # (3) properties at BASELINE.json sizes
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize('A,P', [(1, 100_000), (8, 100_000)])
+@pytest.mark.parametrize('A,P', [(1, 100_000), (8, 100_000), (8, 1_000_000)])
 def test_full_size_shard_additivity_permutation_determinism(A, P):
-    """100k x 1k 2PL (BASELINE configs[1] shape; [2]'s ability_dim): the ELBO heads
+    """100k x 1k 2PL (BASELINE configs[1] shape; [2]'s ability_dim) and configs[2] at its FULL size, 1M x 1k at
+    ability_dim 8 (the benchmark's matrix): the ELBO heads
     and gradients of the whole batch equal the sum over two person shards (what
     the 8-GPU person sharding relies on), are invariant to permuting persons,
     and are bitwise reproducible."""
@@ -510,9 +511,14 @@ def test_full_size_shard_additivity_permutation_determinism(A, P):
     spec = ElboSpec(irt_model=irt, ability_dim=A)
     theta = torch.randn(P, A, device=d, generator=g)
     item_true = torch.randn(I, A + 1, device=d, generator=g)
-    probs = torch.sigmoid(-(theta @ item_true[:, :A].t()) + item_true[:, A])
-    resp = torch.bernoulli(probs, generator=g)
-    mask = torch.rand(P, I, device=d, generator=g) > 0.1
+    resp = torch.empty(P, I, device=d)
+    mask = torch.empty(P, I, dtype=torch.bool, device=d)
+    for s0 in range(0, P, 100_000):         # (in slices: the 1M-person case would hold three more 4 GB temporaries)
+        sl = slice(s0, min(P, s0 + 100_000))
+        probs = torch.sigmoid(-(theta[sl] @ item_true[:, :A].t()) + item_true[:, A])
+        resp[sl] = torch.bernoulli(probs, generator=g)
+        mask[sl] = torch.rand(probs.shape, device=d, generator=g) > 0.1
+    del probs
     table = (torch.randn(2, 2 * A, device=d, generator=g) * 0.5).contiguous()
     item = torch.randn(I, A + 1, device=d, generator=g)
     eps = torch.randn(P, A, device=d, generator=g)
@@ -538,6 +544,10 @@ def test_full_size_shard_additivity_permutation_determinism(A, P):
     assert rel_err(pf.flat[:7].cpu(), full.flat[:7].cpu()) < 1e-5
     assert rel_err(pf.flat[8:].cpu(), full.flat[8:].cpu()) < 1e-4
     assert (pf.ability_mu - full.ability_mu[perm]).abs().max() < 1e-6
+    # the same permutation through the in-kernel row gather (row_index) is the same call bit for bit
+    mm, code = ops.prepare_mask(mask)
+    pg = ops._hip_launch_elbo(spec, resp, mm, code, perm, table, item, eps[perm].contiguous(), None, _lib.REG_KL, True, P)
+    assert torch.equal(pg.flat, pf.flat) and torch.equal(pg.ability_mu, pf.ability_mu)
 
     # and the full-size ELBO agrees with the CPU oracle on a 512-person slice
     sl = allrows[:512]

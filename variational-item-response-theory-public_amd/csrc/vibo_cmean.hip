@@ -249,13 +249,8 @@ __global__ __launch_bounds__(320, NT == 1 ? 4 : 1) void cm_forward_kernel(const 
     // code rows of step S (clamped to the last whole step: the final prefetches re-read it)
     auto fetch = [&](uint4 (&w)[4], const int S) {
         const int i0 = 64 * (S < nFull ? S : nFull - 1) + 16 * lpiece;
-#ifdef CM_EXP_NOLOAD
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) w[mt] = uint4{(uint32_t)(i0 + mt) & 0x01010101u, (uint32_t)lane & 0x01010101u, 0u, 0x01000100u};
-#else
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) w[mt] = cm_load_full<AL>(rp[mt], i0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     // the partial last step's code words wait in LDS (wave-private: 16 registers less through the whole loop)
@@ -270,15 +265,6 @@ __global__ __launch_bounds__(320, NT == 1 ? 4 : 1) void cm_forward_kernel(const 
     __syncthreads();
     // one 64-item step on the code words w: NT chunks of the dense operand
     auto step = [&](const int S, const uint4 (&wl)[4]) {
-#ifdef CM_EXP_NOMFMA
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) cnt[mt] += __popc(wl[mt].x ^ wl[mt].y ^ wl[mt].z ^ wl[mt].w);
-#ifndef CM_EXP_NOSYNC
-#pragma unroll
-        for (int jc = 0; jc < NT; ++jc) __syncthreads();
-#endif
-        return;
-#endif
         uint4 w[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -392,10 +378,6 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
             q = q < B ? q : B - 1;
             if constexpr (GATHER) q = row_index[q];
             const uint8_t* rp = codes + q * stride;
-#ifdef CM_EXP_BWD_NOLOAD
-            w[mt] = uint4{(uint32_t)(q + lane) & 0x01010101u, (uint32_t)lane & 0x01010101u, 0u, 0x01000100u};
-            continue;
-#endif
             if constexpr (TAIL == 0) w[mt] = cm_load_full<AL>(rp, i0);
             else if constexpr (TAIL == 1) w[mt] = cm_load_padded<AL>(rp, I, i0);
             else w[mt] = cm_load_tail(rp, I, i0);
@@ -434,11 +416,6 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
             }
         __builtin_amdgcn_sched_barrier(0);
         fetch(wnext, p0 + 2 * PS);
-#ifdef CM_EXP_BWD_NOMFMA
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[0][0][0] += (float)__popc(w[mt].x ^ w[mt].y ^ w[mt].z ^ w[mt].w) + bg[0][0][0].x * 1e-30f;
-        return;
-#endif
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
             *reinterpret_cast<uint4*>(tile + wofs[mt][0]) = cm_onehot(w[mt].x);
@@ -516,14 +493,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     constexpr int NT = 4, WV = 1, PS = 64;
     CM_BACKWARD_KERNEL_BODY
 }
-#ifndef CM_BWD_PS
-#define CM_BWD_PS 64
-#endif
 template <int NT, bool AL, bool GATHER>
 __global__ __launch_bounds__(64) void cm_backward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
                                                              long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
                                                              long long per_r, int ntot) {
-    constexpr int PS = CM_BWD_PS;
+    constexpr int PS = 64;
     constexpr int WV = 1;       // (WV = 2, two waves sharing the tile at 4 waves per SIMD, measured slower: 336 -> 384 us at one N-tile)
     CM_BACKWARD_KERNEL_BODY
 }

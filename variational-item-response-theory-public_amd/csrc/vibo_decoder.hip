@@ -37,9 +37,6 @@ typedef _Float16 dh2 __attribute__((ext_vector_type(2)));
 typedef float df4 __attribute__((ext_vector_type(4)));
 typedef short ds4 __attribute__((ext_vector_type(4)));
 
-#ifndef DEC_MIN_WG
-#define DEC_MIN_WG 1
-#endif
 constexpr int kH = 64;             // hidden width of the per-term network (models.py:777, 824: hidden_dim = 64)
 constexpr int kXRow = 72;          // halfs per row of the transposition image (64 + 8 of padding: 144-byte rows)
 
@@ -86,7 +83,7 @@ __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : fast_exp2(z
 
 // HASL: the network sees the IRT logit l (link: through w1; residual: added to the output).
 template <bool GRAD, bool HASL>
-__global__ __launch_bounds__(256, DEC_MIN_WG) void decoder_kernel(const DecParams p) {
+__global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
     __shared__ DecLds sm;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;

@@ -45,4 +45,8 @@ hipError_t launch_elbo_msplit_fa(const ElboParams& p, int irt, bool grad, int nw
 hipError_t launch_elbo_msplit_fg(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 hipError_t launch_elbo_msplit_fc(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 
+// the folded train step's epilogue (vibo_trainer.hip): finalize + loss + MLP / item backward + Adam + the next step's noise
+hipError_t launch_train_epilogue_fused(const EpiParams& e, hipStream_t s);
+int train_epilogue_item_blocks(int n_item_entries);
+
 }  // namespace vibo

@@ -32,6 +32,7 @@
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
 #include "vibo_params.hpp"
+#include "vibo_train_hook.hpp"
 
 #ifdef VIBO_MS_TIMING
 // development build (make TIMING=1): shader-clock time per phase of the batch loop, summed per wave
@@ -149,17 +150,27 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int n4 = (I + 3) >> 2;
     const int i16 = lane & 15, g = lane >> 4;
 
-    if (tid < 16) {
-        const int c = tid >> 3, a = tid & 7;
-        float m = 0.f, s = 0.f;
-        if (a < A) { m = p.table[c * 2 * A + a]; s = p.table[c * 2 * A + A + a]; }
-        const float es = __expf(s);
-        const float tau = 1.0f / (es + kPoeEps);
-        cl.ctab[(0 * 2 + c) * 8 + a] = tau;
-        cl.ctab[(1 * 2 + c) * 8 + a] = m * tau;
-        cl.ctab[(2 * 2 + c) * 8 + a] = tau * tau * es;
-        cl.ctab[(3 * 2 + c) * 8 + a] = m;
-    }
+    // Train hook (vibo_train_hook.hpp): the 2-row expert table and the item sample are computed here, in three stages
+    // separated by this prologue's barriers (+ one of its own), and workgroup 0 writes what vibo_train_prologue would have
+    // written.  cl.st is free until the batch loop: scratch of the MLP activations.
+    const bool hook = p.th.mlp != nullptr;                    // (uniform over the launch)
+    float* const hook_s = &cl.st[0][0][0];
+    static_assert(sizeof(cl.st) >= kHookScratchFloats * sizeof(float), "MLP scratch does not fit the pair-state buffer");
+    auto put_ctab = [&](const float* table) {
+        if (tid < 16) {
+            const int c = tid >> 3, a = tid & 7;
+            float m = 0.f, s = 0.f;
+            if (a < A) { m = table[c * 2 * A + a]; s = table[c * 2 * A + A + a]; }
+            const float es = __expf(s);
+            const float tau = 1.0f / (es + kPoeEps);
+            cl.ctab[(0 * 2 + c) * 8 + a] = tau;
+            cl.ctab[(1 * 2 + c) * 8 + a] = m * tau;
+            cl.ctab[(2 * 2 + c) * 8 + a] = tau * tau * es;
+            cl.ctab[(3 * 2 + c) * 8 + a] = m;
+        }
+    };
+    if (!hook) put_ctab(p.table);
+    else hook_mlp_layer0(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
     if constexpr (FLOWS) {
         if (tid < kMsMF * 8) {
             const int f = tid >> 3, a = tid & 7;
@@ -208,15 +219,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int xl = 64 * h + lane;                                   // item of the wave, one per lane and pass
         const int il = kMsSpan * q + xl;
         const bool ok = il < I;
-        const float* ir = p.item_raw + (size_t)(p.item0 + (ok ? il : 0)) * p.D;
+        const size_t ir = (size_t)(p.item0 + (ok ? il : 0)) * p.D;     // (entry index: the sample is read, or formed from mu / logvar / eps)
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float na = 0.f;
-            if (ok && kk < A) na = IRT == 1 ? kLog2e : -ir[kk] * kLog2e;      // models.py:731 / 744,759
+            if (ok && kk < A) na = IRT == 1 ? kLog2e : -hook_item(p.th, p.item_raw, ir + kk) * kLog2e;      // models.py:731 / 744,759
             na_raw[h][kk] = na;
             amax = !(fabsf(na) <= 3.0e38f) ? 3.0e38f : fmaxf(amax, fabsf(na));       // (NaN / Inf: "too large", sticky)
         }
-        nb_raw[h] = ok ? ir[IRT == 1 ? 0 : A] * kLog2e : 0.f;
+        nb_raw[h] = ok ? hook_item(p.th, p.item_raw, ir + (IRT == 1 ? 0 : A)) * kLog2e : 0.f;
         bmax = !(fabsf(nb_raw[h]) <= 3.0e38f) ? 3.0e38f : fmaxf(bmax, fabsf(nb_raw[h]));
     }
     {
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if (lane == 0) { wl.red[1] = ma; wl.red[2] = mb; }
     }
     __syncthreads();
+    if (hook) hook_mlp_layer1(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
     float wg_amax = 0.f, wg_bmax = 0.f;
     for (int w = 0; w < nw; ++w) { wg_amax = fmaxf(wg_amax, wls[w].red[1]); wg_bmax = fmaxf(wg_bmax, wls[w].red[2]); }
     // frexp exponents e: max < 2^e
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         for (int t = 0; t < 4; ++t) {
             const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
             const bool ok = IRT == 3 && il < I;
-            const float gv = ok ? 1.0f / (1.0f + expf(-p.item_raw[(size_t)(p.item0 + il) * p.D + A + 1])) : 0.f;   // models.py:758
+            const float gv = ok ? 1.0f / (1.0f + expf(-hook_item(p.th, p.item_raw, (size_t)(p.item0 + il) * p.D + A + 1))) : 0.f;   // models.py:758
             gs[u][t] = gv;
             om[u][t] = 1.0f - gv;
         }
@@ -293,6 +305,17 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     float s_log = 0.f;
     int unobs = 0;
     __syncthreads();
+    if (hook) {
+        const bool writer = blockIdx.x == 0;
+        hook_mlp_layer2(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
+                        writer ? p.th.saved_h : nullptr);
+        if (writer) {
+            if (tid == 0) p.th.step_count[0] += 1;
+            hook_item_side(p.th, p.I_total * p.D, q, lane, nw);
+        }
+        __syncthreads();
+        put_ctab(hook_tab(hook_s));
+    }
     const int ed = lane & 7;
 
     // LDS image offsets (halfs): producer row 16 t + i16, piece g; consumer rows 32 kt + 4 g + (i16 >> 2) (+ 16), piece i16 & 3
@@ -451,11 +474,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // hipcc guard the register with an s_waitcnt vmcnt(0) -- behind the row loads that are in flight across the sync phase.
     // (on cell codes, RM == 2, the single-panel statistics of the conditional / given posterior come a batch ahead with
     //  eps -- prs -- and the plain variant serves them: the conditional posterior's matrix pass runs on emitted codes)
-#ifdef VIBO_MS_NO_PRS
-    constexpr bool kPrs = false;
-#else
     constexpr bool kPrs = RM == 2;
-#endif
     float prs0 = 0.f, prs1 = 0.f, prs2 = 0.f;
     // prior experts of the missing cells (models.py:613-620): weight 1 / (1 + eps) each, or dropped
     const float prior_w = p.missing_mode == 0 ? 1.0f / (1.0f + kPoeEps) : 0.f;
@@ -767,21 +786,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     const half8 bop, half8& bnx) {
         constexpr int u = decltype(uc)::value, t = decltype(tc)::value;
         constexpr bool last = u == 1 && t == 3;
-#ifndef VIBO_MS_NO_PRIO
         // The two waves of a SIMD (q and q + 4) run the same stream; the arbiter favours the older one, which then reaches the
         // batch's barrier ~4 000 cycles early while the other finishes alone at a single wave's issue rate (phase timing:
         // 12.4 k vs 16.2 k cycles per batch).  Swapping the leader every tile keeps the pair within a tile of each other.
         // (A/B on one box, ability_dim 8: 1.053 ms against 1.076 without; swapping every half tile 1.071, every two tiles 1.065)
         // (s_setprio takes an immediate: set one value, skip the other for half of the waves -- one short forward branch)
-#ifdef VIBO_MS_PRIO_SWAP
-        if constexpr (((u * 4 + t) & 1) == 0)
-#else
         if constexpr (((u * 4 + t) & 1) != 0)
-#endif
             asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio 0\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio 1\n.Lmsprio%=:" :: "s"(q) : "scc");
         else
             asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio 1\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio 0\n.Lmsprio%=:" :: "s"(q) : "scc");
-#endif
         if constexpr (!last) logits(bop, n0, n1);
         // (tile (u, t) reads the operand of tile + 2; the batch's last two tiles read those of the next batch's first two)
         {
@@ -819,7 +832,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 ee[k] = fast_exp2(uu[k]);
                 tt[k] = 1.0f + ee[k];
             }
-#ifndef VIBO_MS_RCP_EACH
             {
                 // products of four (one log2 per 4 terms, <= (1 + 2^23)^4) -- and ONE reciprocal per two cells: with
                 // p = t_a t_b,  1 / t_a = t_b / p  and  1 / t_b = t_a / p  (two packed multiplies instead of a second
@@ -836,24 +848,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     for (int k = 0; k < 8; ++k) gl[k] = fmaf(wc[k], rr[k], -wc[k]);
                 }
             }
-#else
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float& pr = (k & 1) ? pr1 : pr0;
-                pr *= tt[k];                                          // <= (1 + 2^23)^4: one log2 per 4 terms
-                if constexpr (GRAD) gl[k] = fmaf(wc[k], fast_rcp(tt[k]), -wc[k]);
-            }
-#endif
-#ifdef VIBO_MS_PRODCHK
-            // (A/B only: "some e > 2^23" from the products -- misses the likely-side band where the reference's gradient is an exact 0)
-            float lmax = fmaxf(pr0, pr1) < 8388608.0f ? 0.f : 1e30f;
-#else
             float lmax;
             asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(lmax) : "v"(uu[0]), "v"(uu[1]), "v"(uu[2]));
             asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(lmax) : "v"(lmax), "v"(uu[3]), "v"(uu[4]));
             asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(lmax) : "v"(lmax), "v"(uu[5]), "v"(uu[6]));
             asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(lmax) : "v"(lmax), "v"(uu[7]));
-#endif
             if (__any(!(lmax <= kLoS))) {                              // (wave-uniform, rare)
                 pr0 = pr1 = 1.0f;
 #pragma unroll
@@ -863,15 +862,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     // exponential; the gradient's zero band (l < -15.94 or l > 16.64) as "clamping l to it changes l".
                     // (A saturated item sends its wave through here in every batch and the other waves wait for it at the
                     //  barrier: a freshly initialised model has a few such items, ~10 % of the kernel before this was trimmed.)
-#ifndef VIBO_MS_OLDSLOW
                     const float tk = 1.0f + med3(ee[k], 0x1p-23f, 0x1p23f);
                     pr *= tk;
                     if constexpr (GRAD) gl[k] = (med3(lg[k], -kLoS, kHiS) != lg[k]) ? 0.f : fmaf(wc[k], fast_rcp(tk), -wc[k]);
-#else
-                    const float tk = 1.0f + fast_exp2(wc[k] * med3(lg[k], -kLoS, kLoS));
-                    pr *= tk;
-                    if constexpr (GRAD) gl[k] = (lg[k] < -kLoS || lg[k] > kHiS) ? 0.f : fmaf(wc[k], fast_rcp(tk), -wc[k]);
-#endif
                 }
             }
         } else {
@@ -1058,9 +1051,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1, bopB, bopA);     // (... of the next batch's (0, 0) into bopA)
         tile(IC1{}, IC3{}, db0, db1, da0, da1, cwA1, bopA, bopB);     // (not used: last; reads (0, 1) into bopB)
         MS_T(2)
-#ifdef VIBO_MS_PRIO_RESET
-        __builtin_amdgcn_s_setprio(0);
-#endif
         pack_half(nxt, 1, cwB0, cwB1, pk);
         asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));

@@ -28,6 +28,7 @@
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
 #include "vibo_params.hpp"
+#include "vibo_train_hook.hpp"
 
 namespace vibo {
 
@@ -155,16 +156,41 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
     // cells of the last chunk that lie past the row's end (they belong to the padding / the next columns)
     const uint32_t tail_mask = ((I & 3) && chunk == (I >> 2)) ? ((1u << (8 * (I & 3))) - 1u) : 0xFFFFFFFFu;
 
-    if (tid < 2 * AT) {
-        const int c = tid / AT, a = tid % AT;
-        float m = 0.f, s = 0.f;
-        if (a < A) { m = p.table[c * 2 * A + a]; s = p.table[c * 2 * A + A + a]; }
-        const float es = __expf(s);
-        const float tau = 1.0f / (es + kPoeEps);
-        cl.ctab[(0 * 2 + c) * AT + a] = tau;
-        cl.ctab[(1 * 2 + c) * AT + a] = m * tau;
-        cl.ctab[(2 * 2 + c) * AT + a] = tau * tau * es;
-        cl.ctab[(3 * 2 + c) * AT + a] = m;
+    // Train hook (vibo_train_hook.hpp): the 2-row expert table and the lane's item rows are computed here, in three stages
+    // separated by barriers, and workgroup 0 writes what vibo_train_prologue would have written.  Wave 0's transposition
+    // buffer is free until the batch loop: scratch of the MLP activations.
+    const bool hook = p.th.mlp != nullptr;                    // (uniform over the launch)
+    float* const hook_s = &wls[0].gtl[0][0][0];
+    static_assert(sizeof(wls[0].gtl) >= kHookScratchFloats * sizeof(float), "MLP scratch does not fit the transposition buffer");
+    auto put_ctab = [&](const float* table) {
+        if (tid < 2 * AT) {
+            const int c = tid / AT, a = tid % AT;
+            float m = 0.f, s = 0.f;
+            if (a < A) { m = table[c * 2 * A + a]; s = table[c * 2 * A + A + a]; }
+            const float es = __expf(s);
+            const float tau = 1.0f / (es + kPoeEps);
+            cl.ctab[(0 * 2 + c) * AT + a] = tau;
+            cl.ctab[(1 * 2 + c) * AT + a] = m * tau;
+            cl.ctab[(2 * 2 + c) * AT + a] = tau * tau * es;
+            cl.ctab[(3 * 2 + c) * AT + a] = m;
+        }
+    };
+    if (!hook) {
+        put_ctab(p.table);
+    } else {
+        const bool writer = blockIdx.x == 0;
+        hook_mlp_layer0(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+        __syncthreads();
+        hook_mlp_layer1(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+        __syncthreads();
+        hook_mlp_layer2(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
+                        writer ? p.th.saved_h : nullptr);
+        if (writer) {
+            if (tid == 0) p.th.step_count[0] += 1;
+            hook_item_side(p.th, p.I_total * p.D, q, lane, nq);
+        }
+        __syncthreads();
+        put_ctab(hook_tab(hook_s));
     }
     if constexpr (FLOWS) {
         if (tid < kMF * 8) {
@@ -197,16 +223,33 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float* ir = p.item_prep + (size_t)(p.item0 + 4 * chunk + j) * p.DP;
+        const int il = 4 * chunk + j;                          // item of the panel
+        const bool hk = hook && chunk_ok && il < I;            // (hook: the row item_prep_kernel would have written, formed here)
+        const size_t e0 = (size_t)(p.item0 + (hk ? il : 0)) * p.D;
 #pragma unroll
         for (int a = 0; a < AT; ++a) {
-            na2[j][a >> 1][a & 1] = chunk_ok ? ir[a] : 0.f;
+            float v = 0.f;
+            if (hook) {
+                if (hk && a < A) v = IRT == 1 ? kLog2e : -hook_item(p.th, nullptr, e0 + a) * kLog2e;
+            } else if (chunk_ok) {
+                v = ir[a];
+            }
+            na2[j][a >> 1][a & 1] = v;
             acc_a2[j][a >> 1][a & 1] = 0.f;
         }
-        nb[j] = chunk_ok ? ir[AT] : 0.f;
         acc_b[j] = 0.f;
-        gs[j] = (IRT == 3 && chunk_ok) ? ir[AT + 1] : 0.f;
-        om[j] = (IRT == 3 && chunk_ok) ? ir[AT + 2] : 1.f;
         acc_g[j] = 0.f;
+        if (hook) {
+            nb[j] = hk ? hook_item(p.th, nullptr, e0 + (IRT == 1 ? 0 : A)) * kLog2e : 0.f;
+            float gv = 0.f;
+            if (IRT == 3 && hk) gv = 1.0f / (1.0f + expf(-hook_item(p.th, nullptr, e0 + A + 1)));
+            gs[j] = gv;
+            om[j] = (IRT == 3 && hk) ? 1.0f - gv : (IRT == 3 && chunk_ok ? 0.f : 1.f);
+        } else {
+            nb[j] = chunk_ok ? ir[AT] : 0.f;
+            gs[j] = (IRT == 3 && chunk_ok) ? ir[AT + 1] : 0.f;
+            om[j] = (IRT == 3 && chunk_ok) ? ir[AT + 2] : 1.f;
+        }
     }
     // lane e = (er, ed): person er of the batch, ability dim ed
     const int er = (lane / AT) & (R - 1), ed = lane % AT;

@@ -5,22 +5,11 @@
 #include <stdint.h>
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
+#include "vibo_finalize.hpp"
 #include "vibo_philox.hpp"
+#include "vibo_train_hook.hpp"
 
 namespace vibo {
-
-constexpr int kMaxHidden = 256;
-
-struct MlpOffsets {
-    int w0, b0, w1, b1, w2, b2, total;
-};
-__host__ __device__ inline MlpOffsets mlp_offsets(int H, int O) {
-    MlpOffsets o;
-    o.w0 = 0; o.b0 = H; o.w1 = 2 * H; o.b1 = 2 * H + H * H; o.w2 = o.b1 + H; o.b2 = o.w2 + O * H; o.total = o.b2 + O;
-    return o;
-}
-
-__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
 
 __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n_item_entries, const float* __restrict__ P,
                                                              const float* __restrict__ mu, const float* __restrict__ lv,
@@ -33,36 +22,17 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
                                                              int gen, uint32_t seed_lo, uint32_t seed_hi, float* __restrict__ eps_w,
                                                              float* __restrict__ eps_ab, long long n_ab, uint32_t ab_stream,
                                                              int n_item_blocks) {
-    __shared__ float h1[2][kMaxHidden], h2[2][kMaxHidden];
+    __shared__ float scratch[kHookScratchFloats];
     __shared__ float red[4];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
+        // (the same three stages the row-split kernels run in their own prologue under a train hook: vibo_train_hook.hpp)
         if (tid == 0) *step_count += 1;
-        const MlpOffsets o = mlp_offsets(H, O);
-        for (int t = tid; t < 2 * H; t += 256) {          // layer 0: input is the response value c in {0,1}
-            const int r = t / H, j = t % H;
-            h1[r][j] = elu(P[o.w0 + j] * (float)r + P[o.b0 + j]);
-        }
+        hook_mlp_layer0(P, H, O, scratch, tid, 256);
         __syncthreads();
-        for (int t = tid; t < 2 * H; t += 256) {
-            const int r = t / H, j = t % H;
-            float a = P[o.b1 + j];
-#pragma unroll 16
-            for (int k = 0; k < H; ++k) a = fmaf(P[o.w1 + j * H + k], h1[r][k], a);
-            h2[r][j] = elu(a);
-        }
+        hook_mlp_layer1(P, H, O, scratch, tid, 256);
         __syncthreads();
-        for (int t = tid; t < 2 * O; t += 256) {
-            const int r = t / O, q = t % O;
-            float a = P[o.b2 + q];
-#pragma unroll 16
-            for (int k = 0; k < H; ++k) a = fmaf(P[o.w2 + q * H + k], h2[r][k], a);
-            table[r * O + q] = a;
-        }
-        for (int t = tid; t < 2 * H; t += 256) {
-            saved_h[t] = h1[t / H][t % H];
-            saved_h[2 * H + t] = h2[t / H][t % H];
-        }
+        hook_mlp_layer2(P, H, O, scratch, tid, 256, table, saved_h);
         return;
     }
     if ((int)blockIdx.x > n_item_blocks) {          // ability noise (stream ab_stream), 4 normals per thread
@@ -77,14 +47,13 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
         const float m = mu[idx], l = lv[idx];
         float e;
         if (gen) {                                   // entry idx of stream 0 (its group of 4 is recomputed by 4 threads: O(I) work)
-            const float4 z = philox_normal4(idx >> 2, (uint32_t)step_count[1], 0u, seed_lo, seed_hi);
-            e = (idx & 3) == 0 ? z.x : (idx & 3) == 1 ? z.y : (idx & 3) == 2 ? z.z : z.w;
+            e = philox_normal1(idx, (uint32_t)step_count[1], 0u, seed_lo, seed_hi);
             eps_w[idx] = e;
         } else {
             e = eps[idx];
         }
-        item_feat[idx] = fmaf(expf(0.5f * l), e, m);
-        kl = -0.5f * (1.0f + l - m * m - expf(l));
+        item_feat[idx] = item_sample(m, l, e);
+        kl = item_kl_term(m, l);
     }
     kl = wave_total(kl);
     if ((tid & 63) == 0) red[tid >> 6] = kl;
@@ -92,22 +61,143 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
     if (tid == 0) kl_parts[blockIdx.x - 1] = red[0] + red[1] + red[2] + red[3];
 }
 
+// torch.optim.Adam's update (betas 0.9 / 0.999, eps 1e-8).  Every product-sum is pinned to one fma: the two epilogue
+// kernels below must agree bit for bit, and the contraction hipcc picks for a sum of two products depends on the
+// surrounding code.
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, const float g, const float lr, const float bc1,
                                             const float bc2_sqrt) {
-    m = 0.9f * m + 0.1f * g;                       // torch: exp_avg.lerp_(grad, 1 - beta1)
-    v = 0.999f * v + 0.001f * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    m = fmaf(0.9f, m, 0.1f * g);                   // torch: exp_avg.lerp_(grad, 1 - beta1)
+    v = fmaf(0.999f, v, (0.001f * g) * g);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
     const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
     p -= (lr / bc1) * (m / denom);
 }
 
+// item entry idx: d loss / d item_feat = gf -> (item_mu, item_logvar) through the sample and the item KL, Adam in place
+__device__ __forceinline__ void epi_item_update(const int idx, const int n_item_entries, const float gf, const float e, const float beta,
+                                                const float lr, const float bc1, const float bc2_sqrt, float* mu, float* lv, float* im,
+                                                float* iv) {
+    const float m = mu[idx], l = lv[idx];
+    const float g_mu = fmaf(beta, m, gf);
+    const float half_sd = 0.5f * expf(0.5f * l);
+    const float klg = (0.5f * beta) * (1.0f - expf(l));
+    const float g_lv = fmaf(gf * half_sd, e, -klg);
+    float pm = m, pl = l;
+    adam_update(pm, im[idx], iv[idx], g_mu, lr, bc1, bc2_sqrt);
+    adam_update(pl, im[n_item_entries + idx], iv[n_item_entries + idx], g_lv, lr, bc1, bc2_sqrt);
+    mu[idx] = pm;
+    lv[idx] = pl;
+}
+
 constexpr int kEpiThreads = 1024;      // block 0's chain of small dependent stages is latency-bound: more lanes per stage, fewer passes
+struct EpiLds {
+    float h1[2][kMaxHidden], h2[2][kMaxHidden], gh2[2][kMaxHidden], gh1[2][kMaxHidden], gout[2][2 * VIBO_MAX_ABILITY_DIM];
+};
+
+// Block 0 of the epilogue: loss, the 2-row MLP backward by hand, Adam on the MLP parameters.
+//   sc: the 8 ELBO scalars (VIBO_S_*); gtab: d LL / d table [2][O] then d REG / d table [2][O]
+__device__ __forceinline__ void epi_mlp_block(EpiLds& L, const int H, const int O, const int n_kl_parts, const float* sc, const float* gtab,
+                                              const float* __restrict__ saved_h, const float* __restrict__ kl_parts, const float beta,
+                                              const float lr, const float bc1, const float bc2_sqrt, float* P, float* M, float* V,
+                                              float* loss_out, const int tid) {
+    constexpr int BS = kEpiThreads;
+    const int n_table = 2 * O;
+    const MlpOffsets o = mlp_offsets(H, O);
+    for (int k = tid; k < 2 * H; k += BS) {
+        L.h1[k / H][k % H] = saved_h[k];
+        L.h2[k / H][k % H] = saved_h[2 * H + k];
+    }
+    // d loss / d table = -dLL + beta dREG
+    for (int k = tid; k < n_table; k += BS) L.gout[k / O][k % O] = fmaf(beta, gtab[n_table + k], -gtab[k]);
+    if (tid < 64) {                  // item KL: the prologue's partial sums, fixed order (lane-strided, then the wave sum)
+        float kl = 0.f;
+        for (int k = tid; k < n_kl_parts; k += 64) kl += kl_parts[k];
+        kl = wave_total(kl);
+        if (tid == 0) *loss_out = fmaf(beta, sc[VIBO_S_REG] + kl, -sc[VIBO_S_LL]);
+    }
+    __syncthreads();
+    // g_h2 = W2^T g_out * elu'(pre2),  elu'(x) = x > 0 ? 1 : elu(x) + 1
+    for (int k = tid; k < 2 * H; k += BS) {
+        const int r = k / H, j = k % H;
+        float a = 0.f;
+#pragma unroll 16
+        for (int q = 0; q < O; ++q) a = fmaf(P[o.w2 + q * H + j], L.gout[r][q], a);      // 16 loads in flight
+        const float h = L.h2[r][j];
+        L.gh2[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
+    }
+    __syncthreads();
+    // g_h1 = W1^T g_h2 * elu'(pre1): each of the 2 H dot products over H is cut into 8 pieces (8 neighbouring lanes)
+    {
+        const int len = (H + 7) / 8;
+        for (int k0 = 0; k0 < 2 * H * 8; k0 += BS) {
+            const int k = k0 + tid;
+            const int out = k >> 3, part = k & 7;
+            const int r = out / H, j = out % H;
+            float a = 0.f;
+            if (out < 2 * H) {
+                const int q1 = min(H, (part + 1) * len);
+                for (int q = part * len; q < q1; ++q) a = fmaf(P[o.w1 + q * H + j], L.gh2[r][q], a);
+            }
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            if (out < 2 * H && part == 0) {
+                const float h = L.h1[r][j];
+                L.gh1[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
+            }
+        }
+    }
+    __syncthreads();      // all reads of the OLD weights are done: parameters may now be updated in place
+    // Adam over the MLP parameters: 8 independent elements per thread and pass, all loads issued before the
+    // first store (P, M, V are not restrict-qualified, so a store would otherwise fence the next loads)
+    constexpr int U = 8;
+    for (int k0 = tid; k0 < o.total; k0 += BS * U) {
+        float pv[U], mv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + BS * u;
+            const bool ok = k < o.total;
+            pv[u] = ok ? P[k] : 0.f;
+            mv[u] = ok ? M[k] : 0.f;
+            vv[u] = ok ? V[k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + BS * u;
+            if (k >= o.total) continue;
+            float g;
+            if (k < o.b0) {                         // W0[j]: input of row r is r
+                g = L.gh1[1][k - o.w0];
+            } else if (k < o.w1) {
+                const int j = k - o.b0;
+                g = L.gh1[0][j] + L.gh1[1][j];
+            } else if (k < o.b1) {
+                const int j = (k - o.w1) / H, q = (k - o.w1) % H;
+                g = fmaf(L.gh2[0][j], L.h1[0][q], L.gh2[1][j] * L.h1[1][q]);
+            } else if (k < o.w2) {
+                const int j = k - o.b1;
+                g = L.gh2[0][j] + L.gh2[1][j];
+            } else if (k < o.b2) {
+                const int q = (k - o.w2) / H, j = (k - o.w2) % H;
+                g = fmaf(L.gout[0][q], L.h2[0][j], L.gout[1][q] * L.h2[1][j]);
+            } else {
+                const int q = k - o.b2;
+                g = L.gout[0][q] + L.gout[1][q];
+            }
+            adam_update(pv[u], mv[u], vv[u], g, lr, bc1, bc2_sqrt);
+            P[k] = pv[u];
+            M[k] = mv[u];
+            V[k] = vv[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(kEpiThreads) void train_epilogue_kernel(int H, int O, int n_item_entries, int n_kl_parts,
                                                              const float* __restrict__ flat, const float* __restrict__ saved_h,
                                                              const float* __restrict__ kl_parts, const float* __restrict__ eps,
                                                              const float* __restrict__ beta_p, const float* __restrict__ lr_p,
                                                              const int32_t* __restrict__ step_count, float* P, float* M, float* V,
                                                              float* mu, float* lv, float* im, float* iv, float* loss_out) {
-    __shared__ float h1[2][kMaxHidden], h2[2][kMaxHidden], gh2[2][kMaxHidden], gh1[2][kMaxHidden], gout[2][2 * VIBO_MAX_ABILITY_DIM];
+    __shared__ EpiLds L;
     const int tid = threadIdx.x;
     const float beta = *beta_p, lr = *lr_p;
     const float t = (float)(*step_count);
@@ -116,107 +206,110 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_kernel(int H, int 
     constexpr int BS = kEpiThreads;
     if (blockIdx.x == 0) {
         if (tid == 0) const_cast<int32_t*>(step_count)[1] += 1;      // completed steps: the noise counter of the NEXT step
-        const MlpOffsets o = mlp_offsets(H, O);
-        for (int k = tid; k < 2 * H; k += BS) {
-            h1[k / H][k % H] = saved_h[k];
-            h2[k / H][k % H] = saved_h[2 * H + k];
-        }
-        // d loss / d table = -dLL + beta dREG     (flat: [8 scalars | grad_table set 0 | set 1 | grad_item])
-        for (int k = tid; k < n_table; k += BS) gout[k / O][k % O] = -flat[VIBO_NUM_SCALARS + k] + beta * flat[VIBO_NUM_SCALARS + n_table + k];
-        if (tid < 64) {                  // item KL: the prologue's partial sums, fixed order (lane-strided, then the wave sum)
-            float kl = 0.f;
-            for (int k = tid; k < n_kl_parts; k += 64) kl += kl_parts[k];
-            kl = wave_total(kl);
-            if (tid == 0) *loss_out = -flat[VIBO_S_LL] + beta * (flat[VIBO_S_REG] + kl);
-        }
-        __syncthreads();
-        // g_h2 = W2^T g_out * elu'(pre2),  elu'(x) = x > 0 ? 1 : elu(x) + 1
-        for (int k = tid; k < 2 * H; k += BS) {
-            const int r = k / H, j = k % H;
-            float a = 0.f;
-#pragma unroll 16
-            for (int q = 0; q < O; ++q) a = fmaf(P[o.w2 + q * H + j], gout[r][q], a);      // 16 loads in flight
-            const float h = h2[r][j];
-            gh2[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
-        }
-        __syncthreads();
-        // g_h1 = W1^T g_h2 * elu'(pre1): each of the 2 H dot products over H is cut into 8 pieces (8 neighbouring lanes)
-        {
-            const int len = (H + 7) / 8;
-            for (int k0 = 0; k0 < 2 * H * 8; k0 += BS) {
-                const int k = k0 + tid;
-                const int out = k >> 3, part = k & 7;
-                const int r = out / H, j = out % H;
-                float a = 0.f;
-                if (out < 2 * H) {
-                    const int q1 = min(H, (part + 1) * len);
-                    for (int q = part * len; q < q1; ++q) a = fmaf(P[o.w1 + q * H + j], gh2[r][q], a);
-                }
-                a += __shfl_xor(a, 1);
-                a += __shfl_xor(a, 2);
-                a += __shfl_xor(a, 4);
-                if (out < 2 * H && part == 0) {
-                    const float h = h1[r][j];
-                    gh1[r][j] = a * (h > 0.f ? 1.0f : h + 1.0f);
-                }
-            }
-        }
-        __syncthreads();      // all reads of the OLD weights are done: parameters may now be updated in place
-        // Adam over the MLP parameters: 8 independent elements per thread and pass, all loads issued before the
-        // first store (P, M, V are not restrict-qualified, so a store would otherwise fence the next loads)
-        constexpr int U = 8;
-        for (int k0 = tid; k0 < o.total; k0 += BS * U) {
-            float pv[U], mv[U], vv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + BS * u;
-                const bool ok = k < o.total;
-                pv[u] = ok ? P[k] : 0.f;
-                mv[u] = ok ? M[k] : 0.f;
-                vv[u] = ok ? V[k] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + BS * u;
-                if (k >= o.total) continue;
-                float g;
-                if (k < o.b0) {                         // W0[j]: input of row r is r
-                    g = gh1[1][k - o.w0];
-                } else if (k < o.w1) {
-                    const int j = k - o.b0;
-                    g = gh1[0][j] + gh1[1][j];
-                } else if (k < o.b1) {
-                    const int j = (k - o.w1) / H, q = (k - o.w1) % H;
-                    g = gh2[0][j] * h1[0][q] + gh2[1][j] * h1[1][q];
-                } else if (k < o.w2) {
-                    const int j = k - o.b1;
-                    g = gh2[0][j] + gh2[1][j];
-                } else if (k < o.b2) {
-                    const int q = (k - o.w2) / H, j = (k - o.w2) % H;
-                    g = gout[0][q] * h2[0][j] + gout[1][q] * h2[1][j];
-                } else {
-                    const int q = k - o.b2;
-                    g = gout[0][q] + gout[1][q];
-                }
-                adam_update(pv[u], mv[u], vv[u], g, lr, bc1, bc2_sqrt);
-                P[k] = pv[u];
-                M[k] = mv[u];
-                V[k] = vv[u];
-            }
-        }
+        // flat: [8 scalars | grad_table set 0 | set 1 | grad_item]
+        epi_mlp_block(L, H, O, n_kl_parts, flat, flat + VIBO_NUM_SCALARS, saved_h, kl_parts, beta, lr, bc1, bc2_sqrt, P, M, V, loss_out, tid);
         return;
     }
     const int idx = (blockIdx.x - 1) * BS + tid;
-    if (idx < n_item_entries) {
-        const float m = mu[idx], l = lv[idx];
-        const float gf = -flat[VIBO_NUM_SCALARS + 2 * n_table + idx];          // d loss / d item_feat = -dLL/ditem
-        const float g_mu = gf + beta * m;
-        const float g_lv = gf * 0.5f * expf(0.5f * l) * eps[idx] - 0.5f * beta * (1.0f - expf(l));
-        float pm = m, pl = l;
-        adam_update(pm, im[idx], iv[idx], g_mu, lr, bc1, bc2_sqrt);
-        adam_update(pl, im[n_item_entries + idx], iv[n_item_entries + idx], g_lv, lr, bc1, bc2_sqrt);
-        mu[idx] = pm;
-        lv[idx] = pl;
+    if (idx < n_item_entries)          // d loss / d item_feat = -dLL/ditem
+        epi_item_update(idx, n_item_entries, -flat[VIBO_NUM_SCALARS + 2 * n_table + idx], eps[idx], beta, lr, bc1, bc2_sqrt, mu, lv, im, iv);
+}
+
+// The epilogue of the folded train step.  One launch does what finalize_kernel + train_epilogue_kernel (+ the next step's
+// noise draw of vibo_train_prologue_noise) do:
+//   * e.partial != null ("fused finalize", one GPU): the fixed-order fp64 sums over the ELBO kernel's per-workgroup partial
+//     records happen here -- block 0 sums the 8 scalars and the table gradient, item block b the 64 item-gradient entries
+//     it then applies -- in finalize_kernel<64>'s order (16 slices, record_slice_sum), so the step agrees bit for bit with
+//     the three-launch form; the sums are also written to flat_out (what vibo_elbo_fwd_bwd would have returned).
+//     e.partial == null (person-sharded: finalize_kernel ran before the all-reduce): the sums are read from flat_in.
+//   * e.draw: the reparameterisation noise of the NEXT step -- eps_item entry idx is redrawn by the thread that just consumed
+//     it, the blocks past the item blocks fill eps_ab; counter = step_count[0], which is what the next step's
+//     vibo_train_prologue_noise would have read from step_count[1].
+constexpr int kEpiOut = 64, kEpiSlices = kEpiThreads / kEpiOut;
+
+__global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const EpiParams e) {
+    __shared__ EpiLds L;
+    __shared__ double part[kEpiSlices][kEpiOut];
+    __shared__ float sc[VIBO_NUM_SCALARS];
+    __shared__ float gt[8 * VIBO_MAX_ABILITY_DIM];
+    const int tid = threadIdx.x;
+    const int lane = tid % kEpiOut, slice = tid / kEpiOut;
+    const int n_table = 2 * e.O;                 // floats per table-gradient set
+    if ((int)blockIdx.x > e.n_item_blocks) {     // the next step's ability noise, 4 normals per thread
+        const long long g = (long long)(blockIdx.x - 1 - e.n_item_blocks) * kEpiThreads + tid;
+        if (4 * g < e.n_ab) store_normal4(e.eps_ab, e.n_ab, g, philox_normal4(g, (uint32_t)e.step_count[0], e.ab_stream, e.seed_lo, e.seed_hi));
+        return;
+    }
+    const float beta = *e.beta, lr = *e.lr;
+    const float t = (float)e.step_count[0];
+    const float bc1 = 1.0f - powf(0.9f, t), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t));
+    if (blockIdx.x == 0) {
+        if (tid == 0) e.step_count[1] += 1;      // completed steps (nothing in this launch reads it)
+        const float* scp = e.flat_in;
+        const float* gtp = e.flat_in + VIBO_NUM_SCALARS;
+        if (e.partial) {
+            // outputs [0, 8 + 2 n_table) of the logical vector: two passes of 64 outputs x 16 slices
+            double* scd = &part[0][0];           // (re-used below as 8 doubles, after the slice sums were consumed)
+            double keep = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                const int o = kEpiOut * pass + lane;
+                const bool live = o < VIBO_NUM_SCALARS + 2 * n_table;
+                part[slice][lane] = live ? record_slice_sum<kEpiSlices>(e.partial, (size_t)e.lay.stride, o, 0, e.nblk, slice) : 0.0;
+                __syncthreads();
+                double tsum = 0.0;
+                if (slice == 0 && live) {
+#pragma unroll
+                    for (int s = 0; s < kEpiSlices; ++s) tsum += part[s][lane];
+                    if (o >= VIBO_NUM_SCALARS) {
+                        gt[o - VIBO_NUM_SCALARS] = (float)tsum;
+                        e.flat_out[o] = (float)tsum;
+                    } else {
+                        keep = tsum;
+                    }
+                }
+                __syncthreads();
+            }
+            if (slice == 0 && lane < VIBO_NUM_SCALARS) scd[lane] = keep;
+            __syncthreads();
+            if (tid == 0) {
+                // partial scalars: 0 ll, 1 kl, 2 logq0, 3 logp, 4 ladj, 5 nobs  (reg_mode KL: REG = KL)
+                sc[VIBO_S_LL] = (float)scd[0]; sc[VIBO_S_REG] = (float)scd[1]; sc[VIBO_S_KL] = (float)scd[1];
+                sc[VIBO_S_LOGQ0] = (float)scd[2]; sc[VIBO_S_LOGP] = (float)scd[3]; sc[VIBO_S_LADJ] = (float)scd[4];
+                sc[VIBO_S_NOBS] = (float)scd[5]; sc[VIBO_S_RESERVED] = 0.f;
+#pragma unroll
+                for (int k = 0; k < VIBO_NUM_SCALARS; ++k) e.flat_out[k] = sc[k];
+            }
+            __syncthreads();
+            scp = sc;
+            gtp = gt;
+        }
+        epi_mlp_block(L, e.H, e.O, e.n_kl_parts, scp, gtp, e.saved_h, e.kl_parts, beta, lr, bc1, bc2_sqrt, e.P, e.M, e.V, e.loss_out, tid);
+        return;
+    }
+    // item block: entries k = 64 (block - 1) + lane in the records' order (dim-major: consecutive lanes = consecutive items)
+    const int k = kEpiOut * ((int)blockIdx.x - 1) + lane;
+    const bool live = k < e.n_item_entries;
+    const int dd = live ? k / e.I : 0, i = live ? k % e.I : 0;
+    const int idx = i * e.D + dd;
+    float g = 0.f;
+    if (e.partial) {
+        part[slice][lane] = live ? record_slice_sum<kEpiSlices>(e.partial, (size_t)e.lay.stride, e.lay.off_item + dd * e.lay.i_pad + i, 0,
+                                                                e.nblk, slice) : 0.0;
+        __syncthreads();
+        if (slice == 0 && live) {
+            double tsum = 0.0;
+#pragma unroll
+            for (int s = 0; s < kEpiSlices; ++s) tsum += part[s][lane];
+            g = (float)tsum;
+            e.flat_out[VIBO_NUM_SCALARS + 2 * n_table + idx] = g;
+        }
+    } else if (slice == 0 && live) {
+        g = e.flat_in[VIBO_NUM_SCALARS + 2 * n_table + idx];
+    }
+    if (slice == 0 && live) {
+        const float eps = e.eps_item[idx];
+        epi_item_update(idx, e.n_item_entries, -g, eps, beta, lr, bc1, bc2_sqrt, e.mu, e.lv, e.im, e.iv);
+        if (e.draw) e.eps_item[idx] = philox_normal1(idx, (uint32_t)e.step_count[0], 0u, e.seed_lo, e.seed_hi);
     }
 }
 
@@ -226,6 +319,13 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ ou
     if (4 * g >= n) return;
     store_normal4(out, n, g, philox_normal4(g, (uint32_t)(*step_count), stream_id, seed_lo, seed_hi));
 }
+
+hipError_t launch_train_epilogue_fused(const EpiParams& e, hipStream_t s) {
+    const long long ab_blocks = e.draw ? ((e.n_ab + 3) / 4 + kEpiThreads - 1) / kEpiThreads : 0;
+    hipLaunchKernelGGL(train_epilogue_fused_kernel, dim3((unsigned)(1 + e.n_item_blocks + ab_blocks)), dim3(kEpiThreads), 0, s, e);
+    return hipGetLastError();
+}
+int train_epilogue_item_blocks(int n_item_entries) { return (n_item_entries + kEpiOut - 1) / kEpiOut; }
 
 }  // namespace vibo
 

@@ -8,6 +8,7 @@ What stays in PyTorch (tiny, O(I) work): the 2-row (or 2xI-row) encoder MLP that
 produces the expert table, the item-side reparameterisation / flows / KL, the
 optimizer.  Everything O(B x I) is inside the HIP kernel.
 """
+import contextlib
 import ctypes
 import weakref
 from dataclasses import dataclass
@@ -64,6 +65,7 @@ class RawElbo:
     ability: torch.Tensor
     ability_k: Optional[torch.Tensor]
     ability_ladj: Optional[torch.Tensor]
+    workspace: Optional[torch.Tensor] = None      # folded train step: the partial records vibo_train_epilogue_fused sums
 
     @property
     def scalars(self):
@@ -219,6 +221,19 @@ def prepare_response(response):
 DESC_FLAGS = 0
 
 
+@contextlib.contextmanager
+def desc_flags(flags):
+    """`with ops.desc_flags(_lib.FLAG_KERNEL_MATRIX): ...` -- pin vibo_desc.flags for the calls inside and restore the
+    previous value on the way out, also when the body raises (a bare assignment would leave a kernel pinned for the
+    rest of the process)."""
+    global DESC_FLAGS
+    saved, DESC_FLAGS = DESC_FLAGS, int(flags)
+    try:
+        yield
+    finally:
+        DESC_FLAGS = saved
+
+
 def plan_kernel(spec, num_person, num_item, mask_code=_lib.MASK_U8, want_grad=True):
     """Name of the fused kernel the planner picks for a call of this shape (vibo_plan_kernel)."""
     d = _make_desc(spec, num_person, num_item, mask_code, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, want_grad,
@@ -258,15 +273,21 @@ def _require_device(*tensors):
 
 
 def _hip_launch_elbo(spec, response, mask, mask_code, row_index, table, item, eps, flow, reg_mode,
-                     want_grad, num_person):
-    """Single call into vibo_elbo_fwd_bwd on the current stream."""
+                     want_grad, num_person, train_hook=None):
+    """Single call into vibo_elbo_fwd_bwd on the current stream.
+    train_hook (a filled _lib.ViboTrainHook; table / item / flow = None): vibo_elbo_fwd_bwd_train instead -- the kernel forms
+    the expert table and the item sample itself (the folded train step, trainer.FusedTrainer); with hook.skip_finalize the
+    partial records stay in RawElbo.workspace for vibo_train_epilogue_fused and `flat` is filled by that call."""
     lib = _lib.load()
     _require_device(response, mask, table, item, eps)
     dev = response.device
     I = response.shape[1]
     B = int(num_person)
     A, D = spec.ability_dim, spec.item_dim
-    n_table = table.numel()
+    table_shape = tuple(table.shape) if table is not None else tuple(spec.table_shape(I))
+    n_table = 1
+    for n in table_shape:
+        n_table *= n
     n_flow = spec.n_flows * (2 * A + 1)
     n_item = I * D
     flat = torch.empty(_lib.NUM_SCALARS + 2 * n_table + n_item + 2 * n_flow, dtype=torch.float32, device=dev)
@@ -284,17 +305,28 @@ def _hip_launch_elbo(spec, response, mask, mask_code, row_index, table, item, ep
     o_item = o_tab + 2 * n_table
     o_flow = o_item + n_item
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    rc = lib.vibo_elbo_fwd_bwd(
-        ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(table), _ptr(item), _ptr(eps),
-        _ptr(flow),
-        ctypes.c_void_p(fbase), _ptr(post[0]), _ptr(post[1]), _ptr(post[2]), _ptr(ability_k), _ptr(ladj),
-        ctypes.c_void_p(fbase + esz * o_tab), ctypes.c_void_p(fbase + esz * o_item),
-        ctypes.c_void_p(fbase + esz * o_flow) if n_flow else ctypes.c_void_p(0),
-        _ptr(ws), ctypes.c_size_t(ws_bytes), stream)
-    _lib.check(rc, 'vibo_elbo_fwd_bwd')
-    return RawElbo(flat=flat, n_table=n_table, n_item=n_item, n_flow=n_flow, table_shape=tuple(table.shape),
-                   ability_mu=post[0], ability_logvar=post[1], ability=post[2],
-                   ability_k=ability_k, ability_ladj=ladj)
+    if train_hook is not None:
+        rc = lib.vibo_elbo_fwd_bwd_train(
+            ctypes.byref(d), ctypes.byref(train_hook), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(eps),
+            ctypes.c_void_p(fbase), _ptr(post[0]), _ptr(post[1]), _ptr(post[2]),
+            ctypes.c_void_p(fbase + esz * o_tab), ctypes.c_void_p(fbase + esz * o_item),
+            _ptr(ws), ctypes.c_size_t(ws_bytes), stream)
+        _lib.check(rc, 'vibo_elbo_fwd_bwd_train')
+    else:
+        rc = lib.vibo_elbo_fwd_bwd(
+            ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(table), _ptr(item), _ptr(eps),
+            _ptr(flow),
+            ctypes.c_void_p(fbase), _ptr(post[0]), _ptr(post[1]), _ptr(post[2]), _ptr(ability_k), _ptr(ladj),
+            ctypes.c_void_p(fbase + esz * o_tab), ctypes.c_void_p(fbase + esz * o_item),
+            ctypes.c_void_p(fbase + esz * o_flow) if n_flow else ctypes.c_void_p(0),
+            _ptr(ws), ctypes.c_size_t(ws_bytes), stream)
+        _lib.check(rc, 'vibo_elbo_fwd_bwd')
+    raw = RawElbo(flat=flat, n_table=n_table, n_item=n_item, n_flow=n_flow, table_shape=table_shape,
+                  ability_mu=post[0], ability_logvar=post[1], ability=post[2],
+                  ability_k=ability_k, ability_ladj=ladj)
+    if train_hook is not None and train_hook.skip_finalize:
+        raw.workspace = ws          # (kept alive until the epilogue has summed the partial records)
+    return raw
 
 
 def _hip_multi_forward(spec, response, mask, mask_code, row_index, table, items, eps, flow, reg_mode, num_person):
@@ -549,7 +581,7 @@ def _hip_cond_mean_sum(feature, response, mask, row_index):
     return CodeTableSumFn.apply(feature, cc), nobs
 
 
-# The three entry points of the native library.  tests/ swap these for the CPU# The three entry points of the native library.  tests/ swap these for the CPU
+# The entry points of the native library.  tests/ swap these for the CPU
 # oracle to exercise the host logic without a GPU (never done by product code).
 _BACKEND = {'elbo': _hip_launch_elbo, 'encode': _hip_encode, 'decode': _hip_decode, 'multi': _hip_multi_forward,
             'decode_mean': _hip_decode_mean, 'counts': _hip_row_counts, 'mean_fwd': _hip_mean_encoder_fwd,

@@ -121,10 +121,10 @@ class MeanAbilityEncoder(nn.Module):
         w0, b0, w2, b2 = l0.weight, l0.bias, l2.weight, l2.bias
         if reducer is not None:      # person-sharded: these see only this rank's persons
             h, w0, b0, w2, b2 = (_SumGradAcrossRanks.apply(t, reducer) for t in (h, w0, b0, w2, b2))
-        if h.shape[2] == 64:
+        if h.shape[2] == 64 and I <= 32767:      # (the native path's row counts are packed as n_correct << 16 | n_observed)
             hid_sum, nobs = ops._BACKEND['cond_mean_sum'](h, response, mask, row_index)
         else:
-            # other hidden widths: two dense GEMMs on the observed / correct indicator matrices (the GEMM library's job)
+            # other hidden widths, more than 32 767 items: two dense GEMMs on the observed / correct indicator matrices
             if isinstance(response, ops.CellCodes):
                 r, m = (response.rows(row_index) if row_index is not None else response).unpack()
             else:
@@ -601,6 +601,13 @@ class VIBO_1PL(nn.Module):
                 p.grad.copy_(g)
             off += n
         return flat[off] if loss is not None else None
+
+    def allreduce_loss(self, loss):
+        """The detached shard-local loss of a person-sharded MLP-decoder model summed over the ranks (evaluation loops,
+        vibo.py:291-312 under sharding: one scalar collective per step)."""
+        t = loss.detach().reshape(1).clone()
+        self._reducer(t)
+        return t[0]
 
     def log_marginal(self, response, mask, num_samples=100, eps_item=None, eps_ability=None):
         """Importance-weighted bound with batch-level weights (models.py:445-504).  eps_item [S,I,D] / eps_ability

@@ -309,7 +309,12 @@ def test_epoch(model, data, epoch, batch_size, n_steps=None):
     count = 0
     with torch.no_grad():
         for rows in data.batches(batch_size, shuffle=False, n_steps=n_steps):
-            wsum += model.elbo_step(data.response, data.mask, row_index=rows) * rows.numel()
+            loss = model.elbo_step(data.response, data.mask, row_index=rows)
+            if getattr(model, 'needs_grad_allreduce', False):
+                # person-sharded MLP-decoder model: its loss is shard-local (this rank's persons + 1 / world of the item terms),
+                # unlike the fused IRT path, which reduces inside the forward -- one scalar collective, same step count everywhere
+                loss = model.allreduce_loss(loss)
+            wsum += loss * rows.numel()
             count += rows.numel()
     avg = float(wsum) / max(1, count)
     print('====> Test Epoch: {} Loss: {:.4f}'.format(epoch, avg))

@@ -1,14 +1,23 @@
 """Fused train step: the whole `loss = model.elbo(*model(r, m), beta); loss.backward(); adam.step()` of the
-reference loop (vibo.py:243-268) as ~7 kernel launches instead of ~80.
+reference loop (vibo.py:243-268) as TWO kernel launches instead of ~80.
 
     trainer = FusedTrainer(model, lr=5e-3)
     loss = trainer.step(response, mask, beta=1.0, row_index=rows)      # device scalar, parameters updated in place
 
-What runs: torch.randn or vibo_fill_normal (item eps) -> vibo_train_prologue (item sample, item KL, encoder table) -> torch.randn
-(ability eps) -> vibo_elbo_fwd_bwd (fused ELBO forward+backward) -> [one all-reduce when person-sharded] ->
-vibo_train_epilogue (loss, encoder-MLP backward, item backward, Adam).  Same arithmetic as the PyTorch path
-(tests/test_gpu_trainer.py compares parameters after several steps); `.grad` fields are not populated.
-Applies to the unconditional posterior without flows; other configurations use the module + torch.optim path.
+What runs (the folded step, `fold=True`, the default):
+    vibo_elbo_fwd_bwd_train    the row-split ELBO kernel with the train hook: its own prologue forms the item sample, the item
+                               KL and the 2-row encoder table, then the fused ELBO forward + backward over the rows
+    [person-sharded: finalize inside that call, then ONE all-reduce of the flat buffer]
+    vibo_train_epilogue_fused  finalize (one GPU), loss, encoder-MLP / item backward, Adam -- and, with rng='native', the
+                               NEXT step's Philox noise (the first step's comes from two vibo_fill_normal calls)
+`fold=False` keeps the four-launch form (vibo_train_prologue[_noise] -> vibo_elbo_fwd_bwd = kernel + finalize ->
+vibo_train_epilogue): the two forms agree bit for bit (tests/test_gpu_trainer.py), and shapes the hook does not cover (more
+than 1024 items, int64 masks, unaligned rows) take it automatically.
+Same arithmetic as the PyTorch path (tests/test_gpu_trainer.py compares parameters after several steps); `.grad` fields are not
+populated.
+FusedTrainer covers the unconditional posterior without flows; `FusedTrainer(model)` returns its sibling
+FusedCondFlowTrainer (same interface, vibo_ctrain_* kernels) for --conditional-posterior / --n-norm-flows models.
+--ability-merge mean and the MLP decoders train through the module + torch.optim path (fused_trainer_covers()).
 """
 import ctypes
 
@@ -31,17 +40,22 @@ def fused_trainer_covers(model, hidden_dim=None):
 
 
 class FusedTrainer:
-    def __new__(cls, model, *args, **kwargs):
+    def __new__(cls, model=None, *args, **kwargs):
         # one entry point: the conditional posterior / planar flows are served by the sibling class below
-        if cls is FusedTrainer and (model.conditional_posterior or model.n_norm_flows > 0):
+        # (model=None: copy / pickle re-create the object through cls.__new__(cls) and fill __dict__ themselves)
+        if cls is FusedTrainer and model is not None and (model.conditional_posterior or model.n_norm_flows > 0):
             return super().__new__(FusedCondFlowTrainer)
         return super().__new__(cls)
 
-    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True):
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True):
         if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
             raise NotImplementedError('the fused trainers cover the product-of-experts encoder with the IRT decoder; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
         self.model = model
+        self.fold = bool(fold)                # two launches per step (train hook + fused epilogue) where the shape allows
+        self._primed_for = None               # folded step, rng='native': (capacity) the pre-drawn noise buffers are primed for
+        self._eps_cap = None                  # ... the ability-noise buffer [capacity] every step's epilogue refills
+        self._eps_keep = []                   # (outgrown buffers stay alive: a captured graph may still write to them)
         mlp = model.ability_encoder.mlp
         self.hidden = mlp[0].weight.shape[0]
         if self.hidden > 256:
@@ -114,8 +128,12 @@ class FusedTrainer:
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         d = ops._make_desc(spec, B, I, code, _lib.REG_KL, True, response.stride(0), mask.stride(0) if mask is not None else 0)
         p = ops._ptr
-        # reference draw order: item eps, then ability eps (models.py:361,368)
         ab_stream = 1 + getattr(model, '_shard_rank', 0)      # item noise: the same on every rank; ability noise: per rank
+        hook_bits = lib.vibo_train_hook_supported(ctypes.byref(d), self.hidden) if self.fold else 0
+        if hook_bits & 1 and (self.rng != 'native' or self.fused_noise):
+            return self._forward_backward_folded(d, hook_bits, response, mask, code, row_index, B, ab_stream, stream)
+        # ---- the four-launch form ----
+        # reference draw order: item eps, then ability eps (models.py:361,368)
         if self.rng == 'native':
             eps_item = self._eps_item
             # one buffer per batch size, never freed or replaced: a captured hipGraph keeps the pointer it was recorded
@@ -123,6 +141,7 @@ class FusedTrainer:
             eps_ab = self._eps_ab.get(B)
             if eps_ab is None:
                 eps_ab = self._eps_ab[B] = torch.empty(B, model.ability_dim, device=dev)
+            self._primed_for = None           # (these draws move on without refilling the folded step's buffers)
         else:
             eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
         if self.rng == 'native' and self.fused_noise:       # noise drawn inside the prologue launch
@@ -143,7 +162,49 @@ class FusedTrainer:
                 eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
         raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None,
                                    _lib.REG_KL, True, B)
-        self._pending = (d, eps_item, raw)
+        self._pending = (d, eps_item, raw, None)
+        self.last = raw
+        return raw
+
+    def _forward_backward_folded(self, d, hook_bits, response, mask, code, row_index, B, ab_stream, stream):
+        """The folded step's first launch: vibo_elbo_fwd_bwd_train (+ the stand-alone finalize when an all-reduce follows)."""
+        model, spec, lib, p = self.model, self.model.spec, _lib.load(), ops._ptr
+        dev = response.device
+        A = model.ability_dim
+        native = self.rng == 'native'
+        if native:
+            # The noise of a step is drawn by the previous step's epilogue into buffers that never move (a captured hipGraph
+            # keeps their pointers): eps_item in place, the ability noise into ONE buffer of fixed capacity -- the streams are
+            # indexed by element, so a step of fewer persons reads a prefix of the same values a fresh draw would give (the
+            # epoch's last, shorter minibatch between two replays).  Before the first step, and when a larger batch than ever
+            # before arrives, two vibo_fill_normal calls prime them for the current step counter.
+            need = B * A
+            if self._eps_cap is None or self._eps_cap.numel() < need:
+                if self._eps_cap is not None:
+                    self._eps_keep.append(self._eps_cap)
+                self._eps_cap = torch.empty(need, device=dev)
+                self._primed_for = None
+            if self._primed_for != self._eps_cap.numel():
+                noise_step = ctypes.c_void_p(self._steps.data_ptr() + 4)          # completed steps (step_count[1])
+                _lib.check(lib.vibo_fill_normal(p(self._eps_item), self._eps_item.numel(), self.seed, noise_step, 0, stream), 'vibo_fill_normal')
+                _lib.check(lib.vibo_fill_normal(p(self._eps_cap), self._eps_cap.numel(), self.seed, noise_step, ab_stream, stream), 'vibo_fill_normal')
+                self._primed_for = self._eps_cap.numel()
+            eps_item, eps_ab = self._eps_item, self._eps_cap[:need].view(B, A)
+        else:
+            # reference draw order: item eps, then ability eps (models.py:361,368)
+            eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
+            eps_ab = model._randn((B, A), self.item_mu, model._ability_gen)
+        hook = _lib.ViboTrainHook()
+        hook.hidden_dim = self.hidden
+        fused_finalize = bool(hook_bits & 2) and model._reducer is None
+        hook.skip_finalize = 1 if fused_finalize else 0
+        for name, t in (('mlp_params', self.mlp_flat), ('item_mu', self.item_mu), ('item_logvar', self.item_lv), ('eps_item', eps_item),
+                        ('item_feat', self.item_feat), ('table', self.table), ('saved_h', self.saved_h), ('kl_parts', self.kl_parts),
+                        ('step_count', self._steps)):
+            setattr(hook, name, t.data_ptr())
+        raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, None, None, eps_ab, None, _lib.REG_KL, True, B,
+                                   train_hook=hook)
+        self._pending = (d, eps_item, raw, ab_stream)
         self.last = raw
         return raw
 
@@ -155,9 +216,19 @@ class FusedTrainer:
     @torch.no_grad()
     def update(self):
         """Loss, encoder-MLP / item backward and Adam from the (all-reduced) flat buffer of forward_backward()."""
-        d, eps_item, raw = self._pending
+        d, eps_item, raw, folded_stream = self._pending
         lib, p = _lib.load(), ops._ptr
         stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
+        if folded_stream is not None:
+            native = self.rng == 'native'
+            rc = lib.vibo_train_epilogue_fused(ctypes.byref(d), self.hidden, p(raw.workspace), p(raw.flat), p(self.saved_h),
+                                               p(self.kl_parts), p(eps_item), p(self.beta), p(self.lr), p(self._steps),
+                                               p(self.mlp_flat), p(self.mlp_m), p(self.mlp_v), p(self.item_mu), p(self.item_lv),
+                                               p(self.item_m), p(self.item_v), p(self.loss), 1 if native else 0, self.seed,
+                                               p(self._eps_cap) if native else ctypes.c_void_p(0),
+                                               self._eps_cap.numel() if native else 0, folded_stream, stream)
+            _lib.check(rc, 'vibo_train_epilogue_fused')
+            return self.loss
         rc = lib.vibo_train_epilogue(ctypes.byref(d), self.hidden, p(raw.flat), p(self.saved_h), p(self.kl_parts),
                                      p(eps_item), p(self.beta), p(self.lr), p(self._steps), p(self.mlp_flat),
                                      p(self.mlp_m), p(self.mlp_v), p(self.item_mu), p(self.item_lv), p(self.item_m),
@@ -174,7 +245,8 @@ class FusedCondFlowTrainer(FusedTrainer):
     everything).  No PyTorch autograd node: the step replays from a hipGraph like FusedTrainer's.  Same interface
     (`FusedTrainer(model, ...)` returns this class for such models).  Hidden width 64 or 32."""
 
-    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True):
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True):
+        # (fold: FusedTrainer's two-launch form; this class's step is prologue / ELBO call / epilogue either way)
         if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
             raise NotImplementedError('the fused trainers cover the product-of-experts encoder with the IRT decoder; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
@@ -227,6 +299,9 @@ class FusedCondFlowTrainer(FusedTrainer):
         if rng not in ('torch', 'native'):
             raise ValueError("rng must be 'torch' or 'native'")
         self.rng, self.seed = rng, int(seed)
+        if not fused_noise:
+            raise NotImplementedError('FusedCondFlowTrainer draws the native noise inside vibo_ctrain_prologue (there is no '
+                                      'separate vibo_fill_normal form of this step): fused_noise=False is not available')
         self.fused_noise = True
         self._eps_item = torch.empty_like(self.item_mu)
         self._eps_ab = {}
