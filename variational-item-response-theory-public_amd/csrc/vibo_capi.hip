@@ -15,6 +15,7 @@
 #include "vibo_launch.hpp"
 #include "vibo_multi.hpp"
 #include "vibo_params.hpp"
+#include "vibo_split_kernel.hpp"      // (LDS sizes of the VALU row-split kernel)
 #include "vibo_train_hook.hpp"
 
 namespace vibo {
@@ -893,8 +894,17 @@ size_t vibo_workspace_bytes(const vibo_desc* d) {
 
 // the train hook applies to single-launch row-split calls of the plain model (what FusedTrainer trains)
 static bool hook_plan_ok(const vibo_desc* d, const Plan& pl) {
-    return d->posterior == VIBO_POSTERIOR_UNCONDITIONAL && d->n_flows == 0 && d->reg_mode == VIBO_REG_KL && d->want_grad &&
-           !pl.general && pl.panels == 0 && pl.split_ok;
+    if (!(d->posterior == VIBO_POSTERIOR_UNCONDITIONAL && d->n_flows == 0 && d->reg_mode == VIBO_REG_KL && d->want_grad &&
+          !pl.general && pl.panels == 0 && pl.split_ok))
+        return false;
+    if (!pl.msplit) {
+        // VALU kernel with fewer than 4 waves per workgroup: the MLP scratch is extra LDS -- only where every workgroup of the
+        // launch still fits the chip at once (narrow matrices at large minibatches keep the four-launch step)
+        const size_t per_wg = split_lds_bytes(pl.split_nq, false) + split_hook_extra_lds(true, pl.split_nq);
+        const long long resident = (long long)device_cus() * (long long)((160 * 1024) / per_wg);
+        if (split_hook_extra_lds(true, pl.split_nq) && pl.split_nblk > resident) return false;
+    }
+    return true;
 }
 
 static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, const float* response, const void* mask,
@@ -906,7 +916,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, co
     int rc = check_desc(d);
     if (rc) return rc;
     if (hook) {
-        if (hook->hidden_dim < 1 || hook->hidden_dim > kMaxHidden) return fail(-6, "train hook: hidden_dim outside 1..%d", kMaxHidden);
+        if (hook->hidden_dim < 1 || hook->hidden_dim > kHookMaxHidden) return fail(-6, "train hook: hidden_dim outside 1..%d", kHookMaxHidden);
         if (!hook->mlp_params || !hook->item_mu || !hook->item_logvar || !hook->eps_item || !hook->item_feat || !hook->table ||
             !hook->saved_h || !hook->kl_parts || !hook->step_count)
             return fail(-5, "train hook: null pointer");
@@ -1168,7 +1178,7 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
 
 int vibo_train_hook_supported(const vibo_desc* d, int hidden_dim) {
     if (check_desc(d) != 0) return 0;
-    if (hidden_dim < 1 || hidden_dim > kMaxHidden) return 0;
+    if (hidden_dim < 1 || hidden_dim > kHookMaxHidden) return 0;      // (the MLP weights are staged in LDS: 64 x 65 floats)
     Plan pl;
     if (make_plan(d, &pl) < 0) return 0;
     if (!hook_plan_ok(d, pl)) return 0;

@@ -154,8 +154,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // separated by this prologue's barriers (+ one of its own), and workgroup 0 writes what vibo_train_prologue would have
     // written.  cl.st is free until the batch loop: scratch of the MLP activations.
     const bool hook = p.th.mlp != nullptr;                    // (uniform over the launch)
-    float* const hook_s = &cl.st[0][0][0];
-    static_assert(sizeof(cl.st) >= kHookScratchFloats * sizeof(float), "MLP scratch does not fit the pair-state buffer");
+    float* const hook_s = &cl.tacc[0][0][0];                   // (the running sums are zeroed after the MLP is through)
+    static_assert(sizeof(cl.tacc) >= kHookLdsFloats * sizeof(float), "MLP scratch does not fit the running-sum buffer");
     auto put_ctab = [&](const float* table) {
         if (tid < 16) {
             const int c = tid >> 3, a = tid & 7;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
     };
     if (!hook) put_ctab(p.table);
-    else hook_mlp_layer0(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+    else hook_mlp_layer0<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
     if constexpr (FLOWS) {
         if (tid < kMsMF * 8) {
             const int f = tid >> 3, a = tid & 7;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if (lane == 0) { wl.red[1] = ma; wl.red[2] = mb; }
     }
     __syncthreads();
-    if (hook) hook_mlp_layer1(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+    if (hook) hook_mlp_layer1<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
     float wg_amax = 0.f, wg_bmax = 0.f;
     for (int w = 0; w < nw; ++w) { wg_amax = fmaxf(wg_amax, wls[w].red[1]); wg_bmax = fmaxf(wg_bmax, wls[w].red[2]); }
     // frexp exponents e: max < 2^e
@@ -301,20 +301,22 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
     f32x4 acc_gt[2];                    // d LL/d theta of the batch: [16 persons of M-tile][a_hi cols | a_lo cols]
     acc_gt[0] = acc_gt[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
+    if (!hook) {
+        for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
+    }
     float s_log = 0.f;
     int unobs = 0;
     __syncthreads();
     if (hook) {
         const bool writer = blockIdx.x == 0;
-        hook_mlp_layer2(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
-                        writer ? p.th.saved_h : nullptr);
-        if (writer) {
-            if (tid == 0) p.th.step_count[0] += 1;
-            hook_item_side(p.th, p.I_total * p.D, q, lane, nw);
-        }
+        hook_mlp_layer2<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
+                              writer ? p.th.saved_h : nullptr);
+        if (writer && tid == 0) p.th.step_count[0] += 1;
+        hook_item_side(p.th, p.I_total * p.D, (int)blockIdx.x * nw + q, lane, (int)gridDim.x * nw);
         __syncthreads();
-        put_ctab(hook_tab(hook_s));
+        put_ctab(hook_tab<true>(hook_s, p.th.mlp, p.th.hidden, 2 * A));
+        __syncthreads();                                       // (the table is read: its scratch becomes the running sums)
+        for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
     }
     const int ed = lane & 7;
 

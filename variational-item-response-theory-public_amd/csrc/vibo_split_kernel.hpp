@@ -100,8 +100,13 @@ struct alignas(16) SplitFlowAcc {
     float a[2][kMF][3][64];           // [set][flow][uhat | w | b][lane (r, d)]  (wave 0)
     float st[kMF][3][64];             // forward state of the batch for the backward: tanh, psi, flow input (wave 0)
 };
-inline size_t split_lds_bytes(int nq, bool flows) {
+__host__ __device__ inline size_t split_lds_bytes(int nq, bool flows) {
     return sizeof(SplitCommonLds) + (flows ? sizeof(SplitFlowAcc) : 0) + (size_t)nq * sizeof(SplitWaveLds);
+}
+// train hook (vibo_train_hook.hpp): its MLP scratch lives in the waves' records when they are large enough together, else in
+// this many extra bytes of dynamic LDS behind everything else
+__host__ __device__ inline size_t split_hook_extra_lds(bool hook, int nq) {
+    return (hook && (size_t)nq * sizeof(SplitWaveLds) < kHookLdsFloats * sizeof(float)) ? kHookLdsFloats * sizeof(float) : 0;
 }
 
 // AT = template ability width (2, 4 or 8; runtime p.A <= AT); blockDim.x = 64 nq, nq = ceil(I / 256).
@@ -160,8 +165,12 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
     // separated by barriers, and workgroup 0 writes what vibo_train_prologue would have written.  Wave 0's transposition
     // buffer is free until the batch loop: scratch of the MLP activations.
     const bool hook = p.th.mlp != nullptr;                    // (uniform over the launch)
-    float* const hook_s = &wls[0].gtl[0][0][0];
-    static_assert(sizeof(wls[0].gtl) >= kHookScratchFloats * sizeof(float), "MLP scratch does not fit the transposition buffer");
+    // LDS scratch: the waves' own records when they are large enough together (4 waves: the benchmark widths), else an
+    // extra piece of dynamic LDS behind everything else (the launch adds it: split_hook_extra_lds)
+    extern __shared__ __attribute__((aligned(16))) unsigned char split_dyn[];
+    float* hook_s = reinterpret_cast<float*>(wls);
+    if (hook && (size_t)nq * sizeof(SplitWaveLds) < kHookLdsFloats * sizeof(float))
+        hook_s = reinterpret_cast<float*>(split_dyn + (NQT > 0 ? 0 : split_lds_bytes(nq, FLOWS)));
     auto put_ctab = [&](const float* table) {
         if (tid < 2 * AT) {
             const int c = tid / AT, a = tid % AT;
@@ -179,18 +188,17 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
         put_ctab(p.table);
     } else {
         const bool writer = blockIdx.x == 0;
-        hook_mlp_layer0(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+        hook_mlp_layer0<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
         __syncthreads();
-        hook_mlp_layer1(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+        hook_mlp_layer1<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
         __syncthreads();
-        hook_mlp_layer2(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
-                        writer ? p.th.saved_h : nullptr);
-        if (writer) {
-            if (tid == 0) p.th.step_count[0] += 1;
-            hook_item_side(p.th, p.I_total * p.D, q, lane, nq);
-        }
+        hook_mlp_layer2<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
+                              writer ? p.th.saved_h : nullptr);
+        if (writer && tid == 0) p.th.step_count[0] += 1;
+        hook_item_side(p.th, p.I_total * p.D, (int)blockIdx.x * nq + q, lane, (int)gridDim.x * nq);
         __syncthreads();
-        put_ctab(hook_tab(hook_s));
+        put_ctab(hook_tab<true>(hook_s, p.th.mlp, p.th.hidden, 2 * A));
+        // (the scratch lives in the waves' records, which the batch loop writes only after its first barrier)
     }
     if constexpr (FLOWS) {
         if (tid < kMF * 8) {
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
 template <int AT, int IRT, bool GRAD, int RM>
 static hipError_t launch_split_flows(const ElboParams& p, int nq, int grid, hipStream_t s) {
     const bool flows = p.n_flows > 0;
-    const size_t lds = split_lds_bytes(nq, flows);
+    const size_t lds = split_lds_bytes(nq, flows) + split_hook_extra_lds(p.th.mlp != nullptr, nq);
     if (nq == 4) {
         if (flows) hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, true, 4, RM>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, false, 4, RM>), dim3(grid), dim3(256), 0, s, p);

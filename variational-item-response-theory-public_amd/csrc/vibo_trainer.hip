@@ -28,11 +28,11 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
     if (blockIdx.x == 0) {
         // (the same three stages the row-split kernels run in their own prologue under a train hook: vibo_train_hook.hpp)
         if (tid == 0) *step_count += 1;
-        hook_mlp_layer0(P, H, O, scratch, tid, 256);
+        hook_mlp_layer0<false>(P, H, O, scratch, tid, 256);
         __syncthreads();
-        hook_mlp_layer1(P, H, O, scratch, tid, 256);
+        hook_mlp_layer1<false>(P, H, O, scratch, tid, 256);
         __syncthreads();
-        hook_mlp_layer2(P, H, O, scratch, tid, 256, table, saved_h);
+        hook_mlp_layer2<false>(P, H, O, scratch, tid, 256, table, saved_h);
         return;
     }
     if ((int)blockIdx.x > n_item_blocks) {          // ability noise (stream ab_stream), 4 normals per thread
