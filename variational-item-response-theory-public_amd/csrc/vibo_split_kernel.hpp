@@ -184,22 +184,8 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
             cl.ctab[(3 * 2 + c) * AT + a] = m;
         }
     };
-    if (!hook) {
-        put_ctab(p.table);
-    } else {
-        const bool writer = blockIdx.x == 0;
-        hook_mlp_layer0<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
-        __syncthreads();
-        hook_mlp_layer1<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
-        __syncthreads();
-        hook_mlp_layer2<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
-                              writer ? p.th.saved_h : nullptr);
-        if (writer && tid == 0) p.th.step_count[0] += 1;
-        hook_item_side(p.th, p.I_total * p.D, (int)blockIdx.x * nq + q, lane, (int)gridDim.x * nq);
-        __syncthreads();
-        put_ctab(hook_tab<true>(hook_s, p.th.mlp, p.th.hidden, 2 * A));
-        // (the scratch lives in the waves' records, which the batch loop writes only after its first barrier)
-    }
+    if (!hook) put_ctab(p.table);
+    else hook_mlp_layer0<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);     // (the other stages follow the item loads)
     if constexpr (FLOWS) {
         if (tid < kMF * 8) {
             const int f = tid >> 3, a = tid & 7;
@@ -258,6 +244,19 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
             gs[j] = (IRT == 3 && chunk_ok) ? ir[AT + 1] : 0.f;
             om[j] = (IRT == 3 && chunk_ok) ? ir[AT + 2] : 1.f;
         }
+    }
+    if (hook) {
+        const bool writer = blockIdx.x == 0;
+        __syncthreads();
+        hook_mlp_layer1<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+        __syncthreads();
+        hook_mlp_layer2<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
+                              writer ? p.th.saved_h : nullptr);
+        if (writer && tid == 0) p.th.step_count[0] += 1;
+        hook_item_side(p.th, p.I_total * p.D, (int)blockIdx.x * nq + q, lane, (int)gridDim.x * nq);
+        __syncthreads();
+        put_ctab(hook_tab<true>(hook_s, p.th.mlp, p.th.hidden, 2 * A));
+        // (the scratch lives in the waves' records, which the batch loop writes only after the barrier below)
     }
     // lane e = (er, ed): person er of the batch, ability dim ed
     const int er = (lane / AT) & (R - 1), ed = lane % AT;

@@ -30,28 +30,31 @@ __host__ __device__ inline MlpOffsets mlp_offsets(int H, int O) {
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
 
 // LDS scratch of the 2-row MLP.
-//   STAGED (the row-split kernels, H <= kHookMaxHidden): W1 [H][H+1] | W2 [O][H+1] | h1 [2][H] | h2 [2][H] | table [2][O] -- the
+//   STAGED (the row-split kernels, H <= kHookMaxHidden): W1 [H][H+1] | W2 [O][H+1] | h1 [2][H] | h2 [2][H] | table [2][O] | b1 | b2 -- the
 //     weights are copied in coalesced first (rows padded by one float: the per-row reads below are conflict-free).  Read
 //     straight from global memory, thread j streams row j and every wave load touches 64 cache lines: ~8 k line requests per
 //     workgroup, which 256 workgroups at once turn into ~8 us of L2 queueing.
 //   not STAGED (train_prologue_kernel, one workgroup, H <= kMaxHidden): h1 | h2 | table only, weights read from global memory.
 // Either way row j's dot product is the same chain of fmaf's over k = 0 .. H-1: the two forms agree bit for bit.
 constexpr int kHookMaxHidden = 64;
-constexpr int kHookLdsFloats = (kHookMaxHidden + 2 * VIBO_MAX_ABILITY_DIM) * (kHookMaxHidden + 1) + 4 * kHookMaxHidden + 4 * VIBO_MAX_ABILITY_DIM;
+constexpr int kHookLdsFloats = (kHookMaxHidden + 2 * VIBO_MAX_ABILITY_DIM) * (kHookMaxHidden + 1) + 5 * kHookMaxHidden + 6 * VIBO_MAX_ABILITY_DIM;
 constexpr int kHookScratchFloats = 4 * kMaxHidden + 4 * VIBO_MAX_ABILITY_DIM;       // (not STAGED)
 template <bool STAGED>
 struct HookLds {
     float *w1, *w2, *h1, *h2, *tab;
+    const float *b1, *b2;
     int ld;
     __device__ __forceinline__ HookLds(float* s, const float* P, const int H, const int O) {
         const MlpOffsets o = mlp_offsets(H, O);
         if constexpr (STAGED) {
             ld = H + 1;
             w1 = s; w2 = s + H * ld; h1 = w2 + O * ld; h2 = h1 + 2 * H; tab = h2 + 2 * H;
+            b1 = tab + 2 * O; b2 = b1 + H;
         } else {
             ld = H;
             w1 = const_cast<float*>(P) + o.w1; w2 = const_cast<float*>(P) + o.w2;
             h1 = s; h2 = s + 2 * kMaxHidden; tab = s + 4 * kMaxHidden;
+            b1 = P + o.b1; b2 = P + o.b2;
         }
     }
 };
@@ -64,8 +67,28 @@ __device__ __forceinline__ void hook_mlp_layer0(const float* __restrict__ P, con
     const MlpOffsets o = mlp_offsets(H, O);
     const HookLds<STAGED> L(s, P, H, O);
     if constexpr (STAGED) {
-        for (int t = tid; t < H * H; t += nthr) L.w1[(t / H) * L.ld + t % H] = P[o.w1 + t];
-        for (int t = tid; t < O * H; t += nthr) L.w2[(t / H) * L.ld + t % H] = P[o.w2 + t];
+        // W1 | b1 | W2 | b2 are contiguous in P: one coalesced copy, eight loads in flight per thread before the first LDS store
+        // (a load-store pair per loop trip costs a memory round trip each: 16 us for 16 trips)
+        const int n = o.total - o.w1;
+        for (int t0 = 0; t0 < n; t0 += 8 * nthr) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * nthr + tid;
+                v[u] = t < n ? P[o.w1 + t] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * nthr + tid;
+                if (t >= n) continue;
+                float* dst;
+                if (t < H * H) dst = L.w1 + (t / H) * L.ld + t % H;
+                else if (t < H * H + H) dst = const_cast<float*>(L.b1) + (t - H * H);
+                else if (t < H * H + H + O * H) { const int k = t - H * H - H; dst = L.w2 + (k / H) * L.ld + k % H; }
+                else dst = const_cast<float*>(L.b2) + (t - H * H - H - O * H);
+                *dst = v[u];
+            }
+        }
     }
     for (int t = tid; t < 2 * H; t += nthr) {
         const int r = t / H, j = t % H;
@@ -79,7 +102,7 @@ __device__ __forceinline__ void hook_mlp_layer1(const float* __restrict__ P, con
     const HookLds<STAGED> L(s, P, H, O);
     for (int t = tid; t < 2 * H; t += nthr) {
         const int r = t / H, j = t % H;
-        float a = P[o.b1 + j];
+        float a = L.b1[j];
 #pragma unroll 16
         for (int k = 0; k < H; ++k) a = fmaf(L.w1[j * L.ld + k], L.h1[r * H + k], a);
         L.h2[r * H + j] = elu(a);
@@ -93,7 +116,7 @@ __device__ __forceinline__ void hook_mlp_layer2(const float* __restrict__ P, con
     const HookLds<STAGED> L(s, P, H, O);
     for (int t = tid; t < 2 * O; t += nthr) {
         const int r = t / O, q = t % O;
-        float a = P[o.b2 + q];
+        float a = L.b2[q];
 #pragma unroll 16
         for (int k = 0; k < H; ++k) a = fmaf(L.w2[q * L.ld + k], L.h2[r * H + k], a);
         L.tab[t] = a;
