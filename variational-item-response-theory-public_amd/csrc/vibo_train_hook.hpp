@@ -98,7 +98,6 @@ __device__ __forceinline__ void hook_mlp_layer0(const float* __restrict__ P, con
 template <bool STAGED>
 __device__ __forceinline__ void hook_mlp_layer1(const float* __restrict__ P, const int H, const int O, float* s, const int tid,
                                                 const int nthr) {
-    const MlpOffsets o = mlp_offsets(H, O);
     const HookLds<STAGED> L(s, P, H, O);
     for (int t = tid; t < 2 * H; t += nthr) {
         const int r = t / H, j = t % H;
@@ -112,7 +111,6 @@ __device__ __forceinline__ void hook_mlp_layer1(const float* __restrict__ P, con
 template <bool STAGED>
 __device__ __forceinline__ void hook_mlp_layer2(const float* __restrict__ P, const int H, const int O, float* s, const int tid,
                                                 const int nthr, float* __restrict__ table, float* __restrict__ saved_h) {
-    const MlpOffsets o = mlp_offsets(H, O);
     const HookLds<STAGED> L(s, P, H, O);
     for (int t = tid; t < 2 * O; t += nthr) {
         const int r = t / O, q = t % O;
