@@ -249,7 +249,7 @@ int vibo_decode_mean(const vibo_desc* d, int num_samples, const float* ability, 
  * vibo_train_prologue   (models.py:356-361, 575-582, 713-726, 506-510; utils.py:85-88)
  *     step_count += 1
  *     item_feat = item_mu + exp(0.5 * item_logvar) * eps_item                       [I][D]
- *     kl_parts[b] = partial sums of  -0.5 (1 + logvar - mu^2 - exp(logvar))         (summed by the epilogue)
+ *     kl_parts[g] = partial sums of  -0.5 (1 + logvar - mu^2 - exp(logvar)), one per 64 entries   (summed by the epilogue)
  *     table[c] = W2 . elu(W1 . elu(W0 * c + b0) + b1) + b2   for c in {0,1}          [2][2A]
  *     saved activations h1, h2 [2][H]
  * vibo_train_epilogue   (models.py:427-443; vibo.py:267-268 = loss.backward(); optimizer.step())
@@ -269,7 +269,7 @@ int vibo_decode_mean(const vibo_desc* d, int num_samples, const float* ability, 
  *     eps_item [I][D]  <- stream 0, eps_ability [B][A] <- stream `ability_stream_id`, both exactly the values
  *     vibo_fill_normal(out, n, seed, step_count + 1, stream_id) produces (torch.randn_like in models.py:506-510);
  *     two launches fewer per step, which is a quarter of a step at the reference's default batch size of 16.
- *  kl_parts: workspace of at least ceil(I*D/256) floats;  hidden_dim H <= 256
+ *  kl_parts: workspace of at least ceil(I*D/64) floats;  hidden_dim H <= 256
  */
 int vibo_train_prologue(const vibo_desc* d, int hidden_dim, const float* mlp_params, const float* item_mu,
                         const float* item_logvar, const float* eps_item, float* item_feat, float* table,
@@ -286,50 +286,43 @@ int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, c
                         void* stream);
 
 /*
- * The folded train step of the plain model (unconditional posterior, no flows): TWO launches instead of four.
+ * The folded train step of the plain model (unconditional posterior, no flows): TWO launches per step instead of four.
+ * The step is software-pipelined across its own iterations -- the epilogue of step t leaves everything the ELBO kernel of
+ * step t + 1 reads (noise, item sample, item KL parts, expert table) in memory:
  *
- * vibo_elbo_fwd_bwd_train = vibo_train_prologue + vibo_elbo_fwd_bwd in one launch: under the "train hook" the row-split ELBO
- *     kernel computes the 2-row expert table (the encoder MLP on the inputs 0 and 1) and its items (item_mu + exp(.5
- *     item_logvar) * eps_item) in its own prologue, and workgroup 0 writes what vibo_train_prologue writes (item_feat, table,
- *     saved_h, kl_parts, step_count[0] += 1) -- the same statements in the same order: bit-identical to the two-call form.
- *     Arguments as for vibo_elbo_fwd_bwd without table / item / flow.  hook->skip_finalize != 0: the per-workgroup partial
- *     records stay in `workspace` (out_scalars / grad_* are not written) for vibo_train_epilogue_fused.
- *     vibo_train_hook_supported(d, hidden_dim): bit 0 = this descriptor can take the hook (single-launch row-split path:
- *     4..1024 items, chunkable rows, no int64 mask, KL regulariser, gradients; otherwise -8), bit 1 = skip_finalize too.
- * vibo_train_epilogue_fused = [finalize] + vibo_train_epilogue + the NEXT step's noise in one launch.
- *     workspace != NULL: the workspace a vibo_elbo_fwd_bwd_train(skip_finalize) call with the same descriptor just filled;
+ * vibo_elbo_fwd_bwd_step = vibo_elbo_fwd_bwd (table / item as left behind by the previous epilogue, or by vibo_train_prime)
+ *     that also ticks step_count[0] += 1 (Adam's t; what vibo_train_prologue does in the four-launch form) and, with
+ *     skip_finalize != 0, leaves the per-workgroup partial records in `workspace` (out_scalars / grad_* are not written)
+ *     for vibo_train_epilogue_fused.  vibo_train_step_supported(d): bit 0 = this descriptor can take the folded step
+ *     (single-launch row-split path: 4..1024 items, chunkable rows, no int64 mask, KL regulariser, gradients; otherwise the
+ *     call returns -8), bit 1 = skip_finalize too.
+ * vibo_train_epilogue_fused = [finalize] + vibo_train_epilogue for THIS step + vibo_train_prologue_noise for the NEXT one.
+ *     workspace != NULL: the workspace a vibo_elbo_fwd_bwd_step(skip_finalize) call with the same descriptor just filled;
  *         the fixed-order sums over its partial records happen here (same order as the stand-alone finalize: bit-identical)
  *         and are also written to `flat` ([8 scalars | grad_table[2][2][2A] | grad_item[I][D]]).
  *     workspace == NULL: `flat` already holds the sums (person-sharded: finalize ran before the all-reduce).
- *     draw_next_noise != 0: eps_item (in place, after its use) and eps_ability[0 .. n_eps_ability) are redrawn with the
- *         vibo_fill_normal streams 0 / ability_stream_id at counter step_count[0], i.e. exactly what the next step's
- *         vibo_train_prologue_noise would draw: the caller primes the two buffers once (vibo_fill_normal with step_count + 1
- *         before the first step) and every step leaves the next one's noise behind.
- *     step_count[1] += 1 as in vibo_train_epilogue.
+ *     Then, from the updated parameters: eps_item (in place) and eps_ability[0 .. n_eps_ability) are redrawn with the
+ *     vibo_fill_normal streams 0 / ability_stream_id at counter step_count[0] (= what the next step's
+ *     vibo_train_prologue_noise would draw), item_feat / the next half of kl_parts / table / saved_h are recomputed --
+ *     the same statements in the same order as vibo_train_prologue: the two forms of the step agree bit for bit.
+ *     kl_parts: [2][ceil(I*D/64)] floats, double-buffered by the parity of step_count[0].  step_count[1] += 1.
+ * vibo_train_prime = the head of the FIRST folded step (and of the first one after the parameters were changed from
+ *     outside): vibo_train_prologue without the tick, writing the kl_parts half the coming step reads.  The caller fills
+ *     eps_item / eps_ability with vibo_fill_normal(step_count + 1) before it.
  */
-typedef struct vibo_train_hook {
-    int32_t hidden_dim;          /* H <= 256 */
-    int32_t skip_finalize;       /* leave the partial records for vibo_train_epilogue_fused */
-    const float* mlp_params;     /* W0[H] | b0[H] | W1[H][H] | b1[H] | W2[2A][H] | b2[2A] */
-    const float* item_mu;        /* [I][D] */
-    const float* item_logvar;    /* [I][D] */
-    const float* eps_item;       /* [I][D] */
-    float* item_feat;            /* out [I][D] */
-    float* table;                /* out [2][2A] */
-    float* saved_h;              /* out [4H] */
-    float* kl_parts;             /* out [ceil(I*D/256)] */
-    int32_t* step_count;         /* device int32[2], see vibo_train_prologue */
-} vibo_train_hook;
-int vibo_train_hook_supported(const vibo_desc* d, int hidden_dim);
-int vibo_elbo_fwd_bwd_train(const vibo_desc* d, const vibo_train_hook* hook, const float* response, const void* mask,
-                            const int64_t* row_index, const float* eps, float* out_scalars, float* ability_mu,
-                            float* ability_logvar, float* ability, float* grad_table, float* grad_item, void* workspace,
-                            size_t workspace_bytes, void* stream);
-int vibo_train_epilogue_fused(const vibo_desc* d, int hidden_dim, const void* workspace, float* flat, const float* saved_h,
-                              const float* kl_parts, float* eps_item, const float* beta, const float* lr, int32_t* step_count,
+int vibo_train_step_supported(const vibo_desc* d);
+int vibo_elbo_fwd_bwd_step(const vibo_desc* d, int32_t* step_count, int skip_finalize, const float* response, const void* mask,
+                           const int64_t* row_index, const float* table, const float* item, const float* eps, float* out_scalars,
+                           float* ability_mu, float* ability_logvar, float* ability, float* grad_table, float* grad_item,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int vibo_train_epilogue_fused(const vibo_desc* d, int hidden_dim, const void* workspace, float* flat, float* saved_h,
+                              float* kl_parts, float* eps_item, const float* beta, const float* lr, int32_t* step_count,
                               float* mlp_params, float* mlp_m, float* mlp_v, float* item_mu, float* item_logvar, float* item_m,
-                              float* item_v, float* loss_out, int draw_next_noise, uint64_t seed, float* eps_ability,
+                              float* item_v, float* loss_out, uint64_t seed, float* item_feat, float* table, float* eps_ability,
                               int64_t n_eps_ability, uint32_t ability_stream_id, void* stream);
+int vibo_train_prime(const vibo_desc* d, int hidden_dim, const float* mlp_params, const float* item_mu,
+                     const float* item_logvar, const float* eps_item, float* item_feat, float* table,
+                     float* saved_h, float* kl_parts, int32_t* step_count, void* stream);
 
 /*
  * The same two halves of a train step for --conditional-posterior and / or --n-norm-flows models (product-of-experts

@@ -98,20 +98,13 @@ def test_desc_struct_matches_header():
     assert fields == [f[0] for f in _lib.ViboDesc._fields_]
 
 
-def test_train_hook_struct_matches_header():
-    """struct vibo_train_hook: same field order (two int32, then pointers) in the header and the ctypes mirror; the host-side
-    checks of the folded-step entry points answer without a GPU."""
-    src = open(os.path.join(ROOT, 'include', 'vibo_hip.h')).read()
-    body = src[src.index('typedef struct vibo_train_hook {'):src.index('} vibo_train_hook;')]
-    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
-    fields = re.findall(r'(?:int32_t|const float\*|float\*|int32_t\*)\s+([a-z_]+)\s*;', body)
-    assert fields == [f[0] for f in _lib.ViboTrainHook._fields_]
-    assert [f[1] for f in _lib.ViboTrainHook._fields_[:2]] == [ctypes.c_int32, ctypes.c_int32]
-    assert all(f[1] is ctypes.c_void_p for f in _lib.ViboTrainHook._fields_[2:])
+def test_folded_step_entry_points_check_their_arguments():
+    """The host-side checks of the folded-step entry points answer without a GPU."""
     lib = _lib.load()
     d = _lib.ViboDesc()
-    assert lib.vibo_train_hook_supported(ctypes.byref(d), 64) == 0             # (zeroed descriptor: wrong abi_version)
-    assert lib.vibo_elbo_fwd_bwd_train(ctypes.byref(d), None, *([None] * 11), 0, None) == -5
+    assert lib.vibo_train_step_supported(ctypes.byref(d)) == 0                  # (zeroed descriptor: wrong abi_version)
+    assert lib.vibo_elbo_fwd_bwd_step(ctypes.byref(d), None, 0, *([None] * 13), 0, None) == -5
+    assert lib.vibo_train_prime(ctypes.byref(d), 64, *([None] * 10)) == -5
 
 
 def test_decoder_desc_struct_matches_header():

@@ -47,12 +47,12 @@ def test_fused_trainer_matches_torch_adam(cls, A, I, B, beta):
     (VIBO_1PL, 1, 512, 4100, 'native', 'matrix'), (VIBO_2PL, 4, 260, 16, 'native', 'valu'), (VIBO_2PL, 2, 1030, 64, 'native', 'valu')])
 @pytest.mark.parametrize('rows', ['all', 'gathered', 'codes'])
 def test_folded_step_equals_the_unfolded_step(cls, A, I, B, rng, kernel, rows):
-    """The two-launch train step (row-split kernel with the train hook -> vibo_train_epilogue_fused: finalize + Adam + the
-    next step's noise) against the four-launch form (vibo_train_prologue[_noise] -> vibo_elbo_fwd_bwd -> vibo_train_epilogue),
+    """The two-launch train step (vibo_elbo_fwd_bwd_step -> vibo_train_epilogue_fused: finalize + Adam + the next step's
+    noise, item sample and expert table) against the four-launch form (vibo_train_prologue[_noise] -> vibo_elbo_fwd_bwd -> vibo_train_epilogue),
     which test_fused_trainer_matches_torch_adam and the Adam-trajectory goldens pin to the reference: every parameter, Adam
     moment and loss BIT FOR BIT over six steps -- both row-split kernels, fp32 rows in order / gathered by row_index / cell
     codes, both noise sources, a shorter minibatch in between (the epoch's last one) -- and again as captured hipGraphs.
-    1 030 items do not take the hook (panel mode): fold=True silently runs the four-launch form there."""
+    1 030 items do not take the folded step (panel mode), nor does rng='torch': fold=True runs the four-launch form there."""
     from vibo_amd import _lib, ops
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(A * 1000 + I)
@@ -78,7 +78,7 @@ def test_folded_step_equals_the_unfolded_step(cls, A, I, B, rng, kernel, rows):
         t_b = FusedTrainer(m_b, lr=5e-3, rng=rng, seed=5, fold=False)
         lib = _lib.load()
         d = ops._make_desc(m_a.spec, B, I, _lib.MASK_CODES if rows == 'codes' else _lib.MASK_U8, _lib.REG_KL, True, (I + 3) & ~3, (I + 3) & ~3)
-        assert lib.vibo_train_hook_supported(__import__('ctypes').byref(d), t_a.hidden) == (3 if I <= 1024 else 0)
+        assert lib.vibo_train_step_supported(__import__('ctypes').byref(d)) == (3 if I <= 1024 else 0)
 
         def both(k, row_index, beta):
             out = []

@@ -15,7 +15,6 @@
 #include "vibo_launch.hpp"
 #include "vibo_multi.hpp"
 #include "vibo_params.hpp"
-#include "vibo_split_kernel.hpp"      // (LDS sizes of the VALU row-split kernel)
 #include "vibo_train_hook.hpp"
 
 namespace vibo {
@@ -892,22 +891,13 @@ size_t vibo_workspace_bytes(const vibo_desc* d) {
 
 }  // extern "C"
 
-// the train hook applies to single-launch row-split calls of the plain model (what FusedTrainer trains)
-static bool hook_plan_ok(const vibo_desc* d, const Plan& pl) {
-    if (!(d->posterior == VIBO_POSTERIOR_UNCONDITIONAL && d->n_flows == 0 && d->reg_mode == VIBO_REG_KL && d->want_grad &&
-          !pl.general && pl.panels == 0 && pl.split_ok))
-        return false;
-    if (!pl.msplit) {
-        // VALU kernel with fewer than 4 waves per workgroup: the MLP scratch is extra LDS -- only where every workgroup of the
-        // launch still fits the chip at once (narrow matrices at large minibatches keep the four-launch step)
-        const size_t per_wg = split_lds_bytes(pl.split_nq, false) + split_hook_extra_lds(true, pl.split_nq);
-        const long long resident = (long long)device_cus() * (long long)((160 * 1024) / per_wg);
-        if (split_hook_extra_lds(true, pl.split_nq) && pl.split_nblk > resident) return false;
-    }
-    return true;
+// the folded train step (vibo_elbo_fwd_bwd_step + vibo_train_epilogue_fused) covers single-launch row-split calls of the plain model
+static bool step_plan_ok(const vibo_desc* d, const Plan& pl) {
+    return d->posterior == VIBO_POSTERIOR_UNCONDITIONAL && d->n_flows == 0 && d->reg_mode == VIBO_REG_KL && d->want_grad &&
+           !pl.general && pl.panels == 0 && pl.split_ok;
 }
 
-static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, const float* response, const void* mask,
+static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_finalize, const float* response, const void* mask,
                              const int64_t* row_index, const float* table, const float* item, const float* eps, const float* flow,
                              float* out_scalars, float* ability_mu, float* ability_logvar, float* ability,
                              float* ability_k, float* ability_ladj, float* grad_table, float* grad_item,
@@ -915,14 +905,6 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, co
     const int num_cu = device_cus();
     int rc = check_desc(d);
     if (rc) return rc;
-    if (hook) {
-        if (hook->hidden_dim < 1 || hook->hidden_dim > kHookMaxHidden) return fail(-6, "train hook: hidden_dim outside 1..%d", kHookMaxHidden);
-        if (!hook->mlp_params || !hook->item_mu || !hook->item_logvar || !hook->eps_item || !hook->item_feat || !hook->table ||
-            !hook->saved_h || !hook->kl_parts || !hook->step_count)
-            return fail(-5, "train hook: null pointer");
-        table = hook->table;           // (outputs of workgroup 0 under the hook; the kernels do not read them)
-        item = hook->item_feat;
-    }
     if ((!response && d->mask_dtype != VIBO_MASK_CODES) || !table || !item || !eps || !out_scalars || !ability_mu || !ability_logvar || !ability)
         return fail(-5, "null required pointer");
     if ((d->mask_dtype == VIBO_MASK_NONE) != (mask == nullptr)) return fail(-5, "mask pointer / mask_dtype mismatch");
@@ -942,10 +924,9 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, co
     bool codes = d->mask_dtype == VIBO_MASK_CODES;      // (panel mode on fp32 rows: true from the second pass on, see off_codes)
     if (codes && !(vec && !pl.general && (pl.panels > 0 || pl.split_ok))) return codes_unsupported();
     if (pl.given && !vec) return fail(-8, "VIBO_POSTERIOR_GIVEN: rows must be aligned for 4-cell chunks (see vibo_amd.ops.pad_rows)");
-    if (hook && !(hook_plan_ok(d, pl) && vec))
-        return fail(-8, "train hook: single-launch row-split calls of the plain model only (unconditional posterior, no flows, KL "
-                        "regulariser, gradients, 4..1024 items, aligned rows): use vibo_train_prologue + vibo_elbo_fwd_bwd");
-
+    if ((step_count || skip_finalize) && !(step_plan_ok(d, pl) && vec))
+        return fail(-8, "vibo_elbo_fwd_bwd_step: single-launch row-split calls of the plain model only (unconditional posterior, no "
+                        "flows, KL regulariser, gradients, 4..1024 items, aligned rows): use vibo_train_prologue + vibo_elbo_fwd_bwd");
     if (pl.general || (d->n_flows > 0 && !(pl.split_ok && vec) && pl.panels == 0) || (pl.panels > 0 && !vec)) {
         const size_t n_table = (size_t)(d->posterior == VIBO_POSTERIOR_CONDITIONAL ? 2 * I * 2 * A : 2 * 2 * A);
         const size_t n_flow = (size_t)d->n_flows * (2 * A + 1);
@@ -975,7 +956,8 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, co
     float* item_prep = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_item_prep);
     float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + pl.off_partial);
     hipError_t e = hipSuccess;
-    if (!pl.msplit && !hook) {   // (the matrix row-split kernel reads the item sample itself; under the train hook both form it)
+    const bool row_split = pl.panels > 0 || (pl.split_ok && vec);
+    if (!row_split) {            // (the row-split kernels read the item sample themselves)
         hipLaunchKernelGGL(item_prep_kernel, dim3((I + 15 + 255) / 256), dim3(256), 0, s, item, item_prep, I, A, pl.AT, pl.D,
                            pl.DP, d->irt_model);
         e = hipGetLastError();
@@ -996,11 +978,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, co
     p.lay = pl.lay;
     p.vec_ok = (vec && I % 4 == 0) ? 1 : 0;      // the tiled / wave-per-row kernels' vector loads assume whole chunks
     p.row_cnt = nullptr; p.item0 = 0; p.I_total = I; p.primary = 1;
-    if (hook) {
-        p.th.mlp = hook->mlp_params; p.th.item_mu = hook->item_mu; p.th.item_lv = hook->item_logvar; p.th.eps_item = hook->eps_item;
-        p.th.item_feat = hook->item_feat; p.th.table = hook->table; p.th.saved_h = hook->saved_h; p.th.kl_parts = hook->kl_parts;
-        p.th.step_count = hook->step_count; p.th.hidden = hook->hidden_dim;
-    }
+    p.step_tick = step_count;
 
     const bool grad = d->want_grad != 0;
     int nblk_used = pl.nblk;
@@ -1147,7 +1125,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, const vibo_train_hook* hook, co
         default: e = launch_elbo_a8(p, d->irt_model, grad, pl.geom, s); break;
     }
     if (e != hipSuccess) return hip_fail(e, "elbo kernel launch");
-    if (hook && hook->skip_finalize) return 0;      // the partial records stay in the workspace for vibo_train_epilogue_fused
+    if (skip_finalize) return 0;      // the partial records stay in the workspace for vibo_train_epilogue_fused
 
     FinalizeParams f;
     memset(&f, 0, sizeof(f));
@@ -1172,32 +1150,31 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                       float* out_scalars, float* ability_mu, float* ability_logvar, float* ability,
                       float* ability_k, float* ability_ladj, float* grad_table, float* grad_item,
                       float* grad_flow, void* workspace, size_t workspace_bytes, void* stream) {
-    return elbo_fwd_bwd_impl(d, nullptr, response, mask, row_index, table, item, eps, flow, out_scalars, ability_mu, ability_logvar,
+    return elbo_fwd_bwd_impl(d, nullptr, 0, response, mask, row_index, table, item, eps, flow, out_scalars, ability_mu, ability_logvar,
                              ability, ability_k, ability_ladj, grad_table, grad_item, grad_flow, workspace, workspace_bytes, stream);
 }
 
-int vibo_train_hook_supported(const vibo_desc* d, int hidden_dim) {
+int vibo_train_step_supported(const vibo_desc* d) {
     if (check_desc(d) != 0) return 0;
-    if (hidden_dim < 1 || hidden_dim > kHookMaxHidden) return 0;      // (the MLP weights are staged in LDS: 64 x 65 floats)
     Plan pl;
     if (make_plan(d, &pl) < 0) return 0;
-    if (!hook_plan_ok(d, pl)) return 0;
+    if (!step_plan_ok(d, pl)) return 0;
     return 1 | (pl.split_nblk < 1024 ? 2 : 0);     // bit 1: vibo_train_epilogue_fused can also take over the finalize
 }
 
-int vibo_elbo_fwd_bwd_train(const vibo_desc* d, const vibo_train_hook* hook, const float* response, const void* mask,
-                            const int64_t* row_index, const float* eps, float* out_scalars, float* ability_mu,
-                            float* ability_logvar, float* ability, float* grad_table, float* grad_item, void* workspace,
-                            size_t workspace_bytes, void* stream) {
-    if (!hook) return fail(-5, "null train hook");
-    return elbo_fwd_bwd_impl(d, hook, response, mask, row_index, nullptr, nullptr, eps, nullptr, out_scalars, ability_mu, ability_logvar,
-                             ability, nullptr, nullptr, grad_table, grad_item, nullptr, workspace, workspace_bytes, stream);
+int vibo_elbo_fwd_bwd_step(const vibo_desc* d, int32_t* step_count, int skip_finalize, const float* response, const void* mask,
+                           const int64_t* row_index, const float* table, const float* item, const float* eps, float* out_scalars,
+                           float* ability_mu, float* ability_logvar, float* ability, float* grad_table, float* grad_item,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!step_count) return fail(-5, "null step_count");
+    return elbo_fwd_bwd_impl(d, step_count, skip_finalize, response, mask, row_index, table, item, eps, nullptr, out_scalars, ability_mu,
+                             ability_logvar, ability, nullptr, nullptr, grad_table, grad_item, nullptr, workspace, workspace_bytes, stream);
 }
 
-int vibo_train_epilogue_fused(const vibo_desc* d, int hidden_dim, const void* workspace, float* flat, const float* saved_h,
-                              const float* kl_parts, float* eps_item, const float* beta, const float* lr, int32_t* step_count,
+int vibo_train_epilogue_fused(const vibo_desc* d, int hidden_dim, const void* workspace, float* flat, float* saved_h,
+                              float* kl_parts, float* eps_item, const float* beta, const float* lr, int32_t* step_count,
                               float* mlp_params, float* mlp_m, float* mlp_v, float* item_mu, float* item_logvar, float* item_m,
-                              float* item_v, float* loss_out, int draw_next_noise, uint64_t seed, float* eps_ability,
+                              float* item_v, float* loss_out, uint64_t seed, float* item_feat, float* table, float* eps_ability,
                               int64_t n_eps_ability, uint32_t ability_stream_id, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -1205,31 +1182,29 @@ int vibo_train_epilogue_fused(const vibo_desc* d, int hidden_dim, const void* wo
     if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL || d->n_flows != 0 || d->reg_mode != VIBO_REG_KL)
         return fail(-6, "vibo_train_epilogue_fused: plain model only (unconditional posterior, no flows, KL regulariser)");
     if (!flat || !saved_h || !kl_parts || !eps_item || !beta || !lr || !step_count || !mlp_params || !mlp_m || !mlp_v || !item_mu ||
-        !item_logvar || !item_m || !item_v || !loss_out)
+        !item_logvar || !item_m || !item_v || !loss_out || !item_feat || !table || !eps_ability || n_eps_ability < 0)
         return fail(-5, "null required pointer");
-    if (draw_next_noise && (!eps_ability || n_eps_ability < 0)) return fail(-5, "draw_next_noise needs eps_ability");
     EpiParams e;
     memset(&e, 0, sizeof(e));
     const int I = d->num_item, A = d->ability_dim, D = item_feat_dim(d->irt_model, A);
-    e.H = hidden_dim; e.O = 2 * A; e.n_item_entries = I * D; e.n_kl_parts = (I * D + 255) / 256; e.I = I; e.D = D;
+    e.H = hidden_dim; e.O = 2 * A; e.n_item_entries = I * D; e.I = I; e.D = D;
     e.flat_in = flat; e.flat_out = flat; e.saved_h = saved_h; e.kl_parts = kl_parts; e.eps_item = eps_item; e.beta = beta; e.lr = lr;
     e.step_count = step_count; e.P = mlp_params; e.M = mlp_m; e.V = mlp_v; e.mu = item_mu; e.lv = item_logvar; e.im = item_m;
-    e.iv = item_v; e.loss_out = loss_out;
+    e.iv = item_v; e.loss_out = loss_out; e.item_feat = item_feat; e.table = table;
     if (workspace) {
-        // the partial records vibo_elbo_fwd_bwd_train(skip_finalize) left behind: same descriptor -> same plan
+        // the partial records vibo_elbo_fwd_bwd_step(skip_finalize) left behind: same descriptor -> same plan
         Plan pl;
         if (make_plan(d, &pl) < 0) return fail(-8, "no plan for this descriptor");
-        if (!hook_plan_ok(d, pl)) return fail(-8, "vibo_train_epilogue_fused: the descriptor is not a train-hook call");
+        if (!step_plan_ok(d, pl)) return fail(-8, "vibo_train_epilogue_fused: the descriptor is not a vibo_elbo_fwd_bwd_step call");
         if ((uintptr_t)workspace & 255) return fail(-7, "workspace must be 256-byte aligned");
         e.partial = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + pl.off_partial);
         e.nblk = pl.split_nblk;
         e.lay = pl.lay;
         if (e.nblk >= 1024) return fail(-8, "vibo_train_epilogue_fused: %d partial records (finalize order of many small records): "
-                                            "call vibo_elbo_fwd_bwd_train without skip_finalize", e.nblk);
+                                            "call vibo_elbo_fwd_bwd_step without skip_finalize", e.nblk);
     }
-    e.draw = draw_next_noise ? 1 : 0;
     e.seed_lo = (uint32_t)seed; e.seed_hi = (uint32_t)(seed >> 32);
-    e.eps_ab = eps_ability; e.n_ab = draw_next_noise ? (long long)n_eps_ability : 0; e.ab_stream = ability_stream_id;
+    e.eps_ab = eps_ability; e.n_ab = (long long)n_eps_ability; e.ab_stream = ability_stream_id;
     e.n_item_blocks = train_epilogue_item_blocks(e.n_item_entries);
     const hipError_t he = launch_train_epilogue_fused(e, (hipStream_t)stream);
     if (he != hipSuccess) return hip_fail(he, "train_epilogue_fused launch");

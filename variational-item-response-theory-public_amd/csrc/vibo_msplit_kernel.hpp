@@ -32,7 +32,6 @@
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
 #include "vibo_params.hpp"
-#include "vibo_train_hook.hpp"
 
 #ifdef VIBO_MS_TIMING
 // development build (make TIMING=1): shader-clock time per phase of the batch loop, summed per wave
@@ -150,12 +149,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int n4 = (I + 3) >> 2;
     const int i16 = lane & 15, g = lane >> 4;
 
-    // Train hook (vibo_train_hook.hpp): the 2-row expert table and the item sample are computed here, in three stages
-    // separated by this prologue's barriers (+ one of its own), and workgroup 0 writes what vibo_train_prologue would have
-    // written.  cl.st is free until the batch loop: scratch of the MLP activations.
-    const bool hook = p.th.mlp != nullptr;                    // (uniform over the launch)
-    float* const hook_s = &cl.tacc[0][0][0];                   // (the running sums are zeroed after the MLP is through)
-    static_assert(sizeof(cl.tacc) >= kHookLdsFloats * sizeof(float), "MLP scratch does not fit the running-sum buffer");
     auto put_ctab = [&](const float* table) {
         if (tid < 16) {
             const int c = tid >> 3, a = tid & 7;
@@ -169,8 +162,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             cl.ctab[(3 * 2 + c) * 8 + a] = m;
         }
     };
-    if (!hook) put_ctab(p.table);
-    else hook_mlp_layer0<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
+    put_ctab(p.table);
+    if (p.step_tick && blockIdx.x == 0 && tid == 0) *p.step_tick += 1;
     if constexpr (FLOWS) {
         if (tid < kMsMF * 8) {
             const int f = tid >> 3, a = tid & 7;
@@ -219,15 +212,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int xl = 64 * h + lane;                                   // item of the wave, one per lane and pass
         const int il = kMsSpan * q + xl;
         const bool ok = il < I;
-        const size_t ir = (size_t)(p.item0 + (ok ? il : 0)) * p.D;     // (entry index: the sample is read, or formed from mu / logvar / eps)
+        const size_t ir = (size_t)(p.item0 + (ok ? il : 0)) * p.D;     // (entry index into the caller's item sample)
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float na = 0.f;
-            if (ok && kk < A) na = IRT == 1 ? kLog2e : -hook_item(p.th, p.item_raw, ir + kk) * kLog2e;      // models.py:731 / 744,759
+            if (ok && kk < A) na = IRT == 1 ? kLog2e : -p.item_raw[ir + kk] * kLog2e;      // models.py:731 / 744,759
             na_raw[h][kk] = na;
             amax = !(fabsf(na) <= 3.0e38f) ? 3.0e38f : fmaxf(amax, fabsf(na));       // (NaN / Inf: "too large", sticky)
         }
-        nb_raw[h] = ok ? hook_item(p.th, p.item_raw, ir + (IRT == 1 ? 0 : A)) * kLog2e : 0.f;
+        nb_raw[h] = ok ? p.item_raw[ir + (IRT == 1 ? 0 : A)] * kLog2e : 0.f;
         bmax = !(fabsf(nb_raw[h]) <= 3.0e38f) ? 3.0e38f : fmaxf(bmax, fabsf(nb_raw[h]));
     }
     {
@@ -242,7 +235,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if (lane == 0) { wl.red[1] = ma; wl.red[2] = mb; }
     }
     __syncthreads();
-    if (hook) hook_mlp_layer1<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
     float wg_amax = 0.f, wg_bmax = 0.f;
     for (int w = 0; w < nw; ++w) { wg_amax = fmaxf(wg_amax, wls[w].red[1]); wg_bmax = fmaxf(wg_bmax, wls[w].red[2]); }
     // frexp exponents e: max < 2^e
@@ -282,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         for (int t = 0; t < 4; ++t) {
             const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
             const bool ok = IRT == 3 && il < I;
-            const float gv = ok ? 1.0f / (1.0f + expf(-hook_item(p.th, p.item_raw, (size_t)(p.item0 + il) * p.D + A + 1))) : 0.f;   // models.py:758
+            const float gv = ok ? 1.0f / (1.0f + expf(-p.item_raw[(size_t)(p.item0 + il) * p.D + A + 1])) : 0.f;   // models.py:758
             gs[u][t] = gv;
             om[u][t] = 1.0f - gv;
         }
@@ -301,23 +293,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
     f32x4 acc_gt[2];                    // d LL/d theta of the batch: [16 persons of M-tile][a_hi cols | a_lo cols]
     acc_gt[0] = acc_gt[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!hook) {
-        for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
-    }
+    for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
     float s_log = 0.f;
     int unobs = 0;
     __syncthreads();
-    if (hook) {
-        const bool writer = blockIdx.x == 0;
-        hook_mlp_layer2<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
-                              writer ? p.th.saved_h : nullptr);
-        if (writer && tid == 0) p.th.step_count[0] += 1;
-        hook_item_side(p.th, p.I_total * p.D, (int)blockIdx.x * nw + q, lane, (int)gridDim.x * nw);
-        __syncthreads();
-        put_ctab(hook_tab<true>(hook_s, p.th.mlp, p.th.hidden, 2 * A));
-        __syncthreads();                                       // (the table is read: its scratch becomes the running sums)
-        for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
-    }
     const int ed = lane & 7;
 
     // LDS image offsets (halfs): producer row 16 t + i16, piece g; consumer rows 32 kt + 4 g + (i16 >> 2) (+ 16), piece i16 & 3

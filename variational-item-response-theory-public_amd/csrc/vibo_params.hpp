@@ -44,22 +44,6 @@ inline PartialLayout partial_layout(int A, int D, int I, int n_flows) {
     return L;
 }
 
-// "Train hook" of the row-split kernels (vibo_train_hook.hpp): when mlp != null the kernel computes the 2-row expert table
-// from the encoder MLP and its items from (item_mu, item_logvar, eps_item) in its own prologue instead of reading
-// ElboParams::table / item_raw / item_prep, and workgroup 0 writes what vibo_train_prologue would have written.
-struct TrainHook {
-    const float* mlp;         // W0 [H] | b0 [H] | W1 [H][H] | b1 [H] | W2 [2A][H] | b2 [2A]; null = no hook
-    const float* item_mu;     // [I][D]
-    const float* item_lv;     // [I][D]
-    const float* eps_item;    // [I][D]
-    float* item_feat;         // out [I][D]   (workgroup 0)
-    float* table;             // out [2][2A]  (workgroup 0)
-    float* saved_h;           // out [4 H]    (workgroup 0)
-    float* kl_parts;          // out [ceil(I D / 256)] (workgroup 0)
-    int32_t* step_count;      // [0] += 1     (workgroup 0)
-    int hidden;
-};
-
 struct ElboParams {
     const float* response;
     const void* mask;
@@ -90,7 +74,7 @@ struct ElboParams {
     int n_tiles, lds_stride, lds_main;
     int mask_dtype, missing_mode, reg_mode, vec_ok, n_flows;
     PartialLayout lay;
-    TrainHook th;
+    int32_t* step_tick;       // non-null: workgroup 0 increments it (the train step's Adam counter, vibo_elbo_fwd_bwd_step)
 };
 
 struct FinalizeParams {
@@ -106,22 +90,23 @@ struct FinalizeParams {
 
 // launch parameters of train_epilogue_fused_kernel (vibo_trainer.hip; host side: vibo_train_epilogue_fused in vibo_capi.hip)
 struct EpiParams {
-    int H, O, n_item_entries, n_kl_parts, I, D;
-    const float* flat_in;
+    int H, O, n_item_entries, I, D;
+    const float* flat_in;     // person-sharded: the all-reduced [8 scalars | grads]; else == flat_out
     float* flat_out;
-    const float* saved_h;
-    const float* kl_parts;
-    float* eps_item;
+    float* saved_h;           // this step's activations in, the next step's out
+    float* kl_parts;          // [2][kl_part_count]: double-buffered by step parity
+    float* eps_item;          // this step's in, the next step's out (in place)
     const float* beta;
     const float* lr;
     int32_t* step_count;
     float *P, *M, *V, *mu, *lv, *im, *iv, *loss_out;
-    const float* partial;
+    const float* partial;     // non-null: the ELBO kernel's partial records (fused finalize)
     int nblk;
     PartialLayout lay;
-    int draw;
+    float* item_feat;         // out: the next step's item sample
+    float* table;             // out: the next step's expert table
     uint32_t seed_lo, seed_hi;
-    float* eps_ab;
+    float* eps_ab;            // out: the next step's ability noise [n_ab]
     long long n_ab;
     uint32_t ab_stream;
     int n_item_blocks;

@@ -28,7 +28,6 @@
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
 #include "vibo_params.hpp"
-#include "vibo_train_hook.hpp"
 
 namespace vibo {
 
@@ -100,13 +99,8 @@ struct alignas(16) SplitFlowAcc {
     float a[2][kMF][3][64];           // [set][flow][uhat | w | b][lane (r, d)]  (wave 0)
     float st[kMF][3][64];             // forward state of the batch for the backward: tanh, psi, flow input (wave 0)
 };
-__host__ __device__ inline size_t split_lds_bytes(int nq, bool flows) {
+inline size_t split_lds_bytes(int nq, bool flows) {
     return sizeof(SplitCommonLds) + (flows ? sizeof(SplitFlowAcc) : 0) + (size_t)nq * sizeof(SplitWaveLds);
-}
-// train hook (vibo_train_hook.hpp): its MLP scratch lives in the waves' records when they are large enough together, else in
-// this many extra bytes of dynamic LDS behind everything else
-__host__ __device__ inline size_t split_hook_extra_lds(bool hook, int nq) {
-    return (hook && (size_t)nq * sizeof(SplitWaveLds) < kHookLdsFloats * sizeof(float)) ? kHookLdsFloats * sizeof(float) : 0;
 }
 
 // AT = template ability width (2, 4 or 8; runtime p.A <= AT); blockDim.x = 64 nq, nq = ceil(I / 256).
@@ -161,16 +155,6 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
     // cells of the last chunk that lie past the row's end (they belong to the padding / the next columns)
     const uint32_t tail_mask = ((I & 3) && chunk == (I >> 2)) ? ((1u << (8 * (I & 3))) - 1u) : 0xFFFFFFFFu;
 
-    // Train hook (vibo_train_hook.hpp): the 2-row expert table and the lane's item rows are computed here, in three stages
-    // separated by barriers, and workgroup 0 writes what vibo_train_prologue would have written.  Wave 0's transposition
-    // buffer is free until the batch loop: scratch of the MLP activations.
-    const bool hook = p.th.mlp != nullptr;                    // (uniform over the launch)
-    // LDS scratch: the waves' own records when they are large enough together (4 waves: the benchmark widths), else an
-    // extra piece of dynamic LDS behind everything else (the launch adds it: split_hook_extra_lds)
-    extern __shared__ __attribute__((aligned(16))) unsigned char split_dyn[];
-    float* hook_s = reinterpret_cast<float*>(wls);
-    if (hook && (size_t)nq * sizeof(SplitWaveLds) < kHookLdsFloats * sizeof(float))
-        hook_s = reinterpret_cast<float*>(split_dyn + (NQT > 0 ? 0 : split_lds_bytes(nq, FLOWS)));
     auto put_ctab = [&](const float* table) {
         if (tid < 2 * AT) {
             const int c = tid / AT, a = tid % AT;
@@ -184,8 +168,8 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
             cl.ctab[(3 * 2 + c) * AT + a] = m;
         }
     };
-    if (!hook) put_ctab(p.table);
-    else hook_mlp_layer0<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);     // (the other stages follow the item loads)
+    put_ctab(p.table);
+    if (p.step_tick && blockIdx.x == 0 && tid == 0) *p.step_tick += 1;
     if constexpr (FLOWS) {
         if (tid < kMF * 8) {
             const int f = tid >> 3, a = tid & 7;
@@ -208,7 +192,9 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
         }
     }
 
-    // ---- this lane's 4 items (log2 units: rows prepped by item_prep_kernel) ----
+    // ---- this lane's 4 items, read from the caller's [I][D] item sample and brought to the kernel's form here (log2 units:
+    //      na = -a_ia log2 e, or +log2 e for 1PL; nb = b_i log2 e; guess = sigmoid: what item_prep_kernel does for the fallback
+    //      kernels, without its launch) ----
     float2v na2[4][H];
     float nb[4];
     float2v acc_a2[4][H];
@@ -216,47 +202,23 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
     float gs[4], om[4], acc_g[4];       // 3PL: guess, 1 - guess, d / d guess-logit
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float* ir = p.item_prep + (size_t)(p.item0 + 4 * chunk + j) * p.DP;
         const int il = 4 * chunk + j;                          // item of the panel
-        const bool hk = hook && chunk_ok && il < I;            // (hook: the row item_prep_kernel would have written, formed here)
-        const size_t e0 = (size_t)(p.item0 + (hk ? il : 0)) * p.D;
+        const bool ok = chunk_ok && il < I;                    // (the last chunk of a padded row ends past the items)
+        const float* ir = p.item_raw + (size_t)(p.item0 + (ok ? il : 0)) * p.D;
 #pragma unroll
         for (int a = 0; a < AT; ++a) {
             float v = 0.f;
-            if (hook) {
-                if (hk && a < A) v = IRT == 1 ? kLog2e : -hook_item(p.th, nullptr, e0 + a) * kLog2e;
-            } else if (chunk_ok) {
-                v = ir[a];
-            }
+            if (ok && a < A) v = IRT == 1 ? kLog2e : -ir[a] * kLog2e;          // models.py:731 / 744,759
             na2[j][a >> 1][a & 1] = v;
             acc_a2[j][a >> 1][a & 1] = 0.f;
         }
+        nb[j] = ok ? ir[IRT == 1 ? 0 : A] * kLog2e : 0.f;
         acc_b[j] = 0.f;
         acc_g[j] = 0.f;
-        if (hook) {
-            nb[j] = hk ? hook_item(p.th, nullptr, e0 + (IRT == 1 ? 0 : A)) * kLog2e : 0.f;
-            float gv = 0.f;
-            if (IRT == 3 && hk) gv = 1.0f / (1.0f + expf(-hook_item(p.th, nullptr, e0 + A + 1)));
-            gs[j] = gv;
-            om[j] = (IRT == 3 && hk) ? 1.0f - gv : (IRT == 3 && chunk_ok ? 0.f : 1.f);
-        } else {
-            nb[j] = chunk_ok ? ir[AT] : 0.f;
-            gs[j] = (IRT == 3 && chunk_ok) ? ir[AT + 1] : 0.f;
-            om[j] = (IRT == 3 && chunk_ok) ? ir[AT + 2] : 1.f;
-        }
-    }
-    if (hook) {
-        const bool writer = blockIdx.x == 0;
-        __syncthreads();
-        hook_mlp_layer1<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x);
-        __syncthreads();
-        hook_mlp_layer2<true>(p.th.mlp, p.th.hidden, 2 * A, hook_s, tid, (int)blockDim.x, writer ? p.th.table : nullptr,
-                              writer ? p.th.saved_h : nullptr);
-        if (writer && tid == 0) p.th.step_count[0] += 1;
-        hook_item_side(p.th, p.I_total * p.D, (int)blockIdx.x * nq + q, lane, (int)gridDim.x * nq);
-        __syncthreads();
-        put_ctab(hook_tab<true>(hook_s, p.th.mlp, p.th.hidden, 2 * A));
-        // (the scratch lives in the waves' records, which the batch loop writes only after the barrier below)
+        float gv = 0.f;
+        if (IRT == 3 && ok) gv = 1.0f / (1.0f + expf(-ir[A + 1]));            // models.py:758
+        gs[j] = gv;
+        om[j] = (IRT == 3 && ok) ? 1.0f - gv : (IRT == 3 && chunk_ok ? 0.f : 1.f);
     }
     // lane e = (er, ed): person er of the batch, ability dim ed
     const int er = (lane / AT) & (R - 1), ed = lane % AT;
@@ -730,7 +692,7 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
 template <int AT, int IRT, bool GRAD, int RM>
 static hipError_t launch_split_flows(const ElboParams& p, int nq, int grid, hipStream_t s) {
     const bool flows = p.n_flows > 0;
-    const size_t lds = split_lds_bytes(nq, flows) + split_hook_extra_lds(p.th.mlp != nullptr, nq);
+    const size_t lds = split_lds_bytes(nq, flows);
     if (nq == 4) {
         if (flows) hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, true, 4, RM>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((split_kernel<AT, IRT, GRAD, false, 4, RM>), dim3(grid), dim3(256), 0, s, p);

@@ -11,28 +11,30 @@
 
 namespace vibo {
 
-__global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n_item_entries, const float* __restrict__ P,
+__global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int I, int D, const float* __restrict__ P,
                                                              const float* __restrict__ mu, const float* __restrict__ lv,
                                                              const float* __restrict__ eps, float* __restrict__ item_feat,
                                                              float* __restrict__ table, float* __restrict__ saved_h,
                                                              float* __restrict__ kl_parts, int32_t* step_count,
+                                                             // tick: step_count[0] += 1 (the four-launch step); tick == 0 primes the
+                                                             // folded step (whose ELBO launch ticks) and selects the half of the
+                                                             // double-buffered kl_parts the coming step will read
+                                                             int tick,
                                                              // noise (gen != 0): eps is written here instead of read, and the
                                                              // blocks past the item blocks fill eps_ab [n_ab]; both draws are
                                                              // the streams vibo_fill_normal gives for step_count[1]
                                                              int gen, uint32_t seed_lo, uint32_t seed_hi, float* __restrict__ eps_w,
                                                              float* __restrict__ eps_ab, long long n_ab, uint32_t ab_stream,
                                                              int n_item_blocks) {
-    __shared__ float scratch[kHookScratchFloats];
-    __shared__ float red[4];
+    __shared__ float h1[2 * kMaxHidden], h2[2 * kMaxHidden];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
-        // (the same three stages the row-split kernels run in their own prologue under a train hook: vibo_train_hook.hpp)
-        if (tid == 0) *step_count += 1;
-        hook_mlp_layer0<false>(P, H, O, scratch, tid, 256);
+        if (tick && tid == 0) *step_count += 1;
+        mlp2_layer0(P, H, O, h1, tid, 256);
         __syncthreads();
-        hook_mlp_layer1<false>(P, H, O, scratch, tid, 256);
+        mlp2_layer1(P, H, O, h1, h2, tid, 256);
         __syncthreads();
-        hook_mlp_layer2<false>(P, H, O, scratch, tid, 256, table, saved_h);
+        mlp2_layer2(P, H, O, h1, h2, tid, 256, table, saved_h);
         return;
     }
     if ((int)blockIdx.x > n_item_blocks) {          // ability noise (stream ab_stream), 4 normals per thread
@@ -40,10 +42,12 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
         if (4 * g < n_ab) store_normal4(eps_ab, n_ab, g, philox_normal4(g, (uint32_t)step_count[1], ab_stream, seed_lo, seed_hi));
         return;
     }
-    // item side: 256 entries of [I][D] per workgroup
-    const int idx = (blockIdx.x - 1) * 256 + tid;
+    // item side: 256 entries per workgroup, dimension-major (item_entry_index); one KL part per wave
+    const int n_item_entries = I * D;
+    const int k = (blockIdx.x - 1) * 256 + tid;
     float kl = 0.f;
-    if (idx < n_item_entries) {
+    if (k < n_item_entries) {
+        const int idx = item_entry_index(k, I, D);
         const float m = mu[idx], l = lv[idx];
         float e;
         if (gen) {                                   // entry idx of stream 0 (its group of 4 is recomputed by 4 threads: O(I) work)
@@ -56,9 +60,9 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(int H, int O, int n
         kl = item_kl_term(m, l);
     }
     kl = wave_total(kl);
-    if ((tid & 63) == 0) red[tid >> 6] = kl;
-    __syncthreads();
-    if (tid == 0) kl_parts[blockIdx.x - 1] = red[0] + red[1] + red[2] + red[3];
+    // (tick == 0: the part buffer of the step that is about to run, step_count[0] + 1)
+    float* parts = kl_parts + (tick ? 0 : (((*step_count + 1) & 1) ? kl_part_count(n_item_entries) : 0));
+    if ((tid & 63) == 0 && 256 * ((int)blockIdx.x - 1) + (tid & ~63) < n_item_entries) parts[4 * (blockIdx.x - 1) + (tid >> 6)] = kl;
 }
 
 // torch.optim.Adam's update (betas 0.9 / 0.999, eps 1e-8).  Every product-sum is pinned to one fma: the two epilogue
@@ -75,13 +79,13 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, const 
 // item entry idx: d loss / d item_feat = gf -> (item_mu, item_logvar) through the sample and the item KL, Adam in place
 __device__ __forceinline__ void epi_item_update(const int idx, const int n_item_entries, const float gf, const float e, const float beta,
                                                 const float lr, const float bc1, const float bc2_sqrt, float* mu, float* lv, float* im,
-                                                float* iv) {
+                                                float* iv, float& pm, float& pl) {
     const float m = mu[idx], l = lv[idx];
     const float g_mu = fmaf(beta, m, gf);
     const float half_sd = 0.5f * expf(0.5f * l);
     const float klg = (0.5f * beta) * (1.0f - expf(l));
     const float g_lv = fmaf(gf * half_sd, e, -klg);
-    float pm = m, pl = l;
+    pm = m; pl = l;
     adam_update(pm, im[idx], iv[idx], g_mu, lr, bc1, bc2_sqrt);
     adam_update(pl, im[n_item_entries + idx], iv[n_item_entries + idx], g_lv, lr, bc1, bc2_sqrt);
     mu[idx] = pm;
@@ -211,21 +215,26 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_kernel(int H, int 
         return;
     }
     const int idx = (blockIdx.x - 1) * BS + tid;
-    if (idx < n_item_entries)          // d loss / d item_feat = -dLL/ditem
-        epi_item_update(idx, n_item_entries, -flat[VIBO_NUM_SCALARS + 2 * n_table + idx], eps[idx], beta, lr, bc1, bc2_sqrt, mu, lv, im, iv);
+    if (idx < n_item_entries) {        // d loss / d item_feat = -dLL/ditem
+        float pm, pl;
+        epi_item_update(idx, n_item_entries, -flat[VIBO_NUM_SCALARS + 2 * n_table + idx], eps[idx], beta, lr, bc1, bc2_sqrt, mu, lv, im, iv, pm, pl);
+    }
 }
 
-// The epilogue of the folded train step.  One launch does what finalize_kernel + train_epilogue_kernel (+ the next step's
-// noise draw of vibo_train_prologue_noise) do:
+// The epilogue of the folded train step.  One launch does what finalize_kernel + train_epilogue_kernel do for THIS step and
+// what vibo_train_prologue_noise does for the NEXT one (the step is software-pipelined across its own iterations: everything
+// the ELBO kernel needs is already in memory when it starts):
 //   * e.partial != null ("fused finalize", one GPU): the fixed-order fp64 sums over the ELBO kernel's per-workgroup partial
 //     records happen here -- block 0 sums the 8 scalars and the table gradient, item block b the 64 item-gradient entries
 //     it then applies -- in finalize_kernel<64>'s order (16 slices, record_slice_sum), so the step agrees bit for bit with
-//     the three-launch form; the sums are also written to flat_out (what vibo_elbo_fwd_bwd would have returned).
+//     the four-launch form; the sums are also written to flat_out (what vibo_elbo_fwd_bwd would have returned).
 //     e.partial == null (person-sharded: finalize_kernel ran before the all-reduce): the sums are read from flat_in.
-//   * e.draw: the reparameterisation noise of the NEXT step -- eps_item entry idx is redrawn by the thread that just consumed
-//     it, the blocks past the item blocks fill eps_ab; counter = step_count[0], which is what the next step's
-//     vibo_train_prologue_noise would have read from step_count[1].
+//   * the next step's head: the thread that has just updated item entry idx redraws its noise (stream 0, counter
+//     step_count[0] = what the next step's prologue would read from step_count[1]) and forms the next item sample and KL
+//     term (kl_parts is double-buffered by step parity: this step's half is still being read by block 0); block 0, after
+//     Adam, runs the 2-row MLP forward on the NEW parameters (table, saved_h); the blocks past the item blocks fill eps_ab.
 constexpr int kEpiOut = 64, kEpiSlices = kEpiThreads / kEpiOut;
+static_assert(kEpiOut == kKlGroup, "one KL part per item block");
 
 __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const EpiParams e) {
     __shared__ EpiLds L;
@@ -235,14 +244,18 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const
     const int tid = threadIdx.x;
     const int lane = tid % kEpiOut, slice = tid / kEpiOut;
     const int n_table = 2 * e.O;                 // floats per table-gradient set
+    const int step = e.step_count[0];            // Adam's t of this step (ticked by the ELBO launch; nothing in this launch writes it)
     if ((int)blockIdx.x > e.n_item_blocks) {     // the next step's ability noise, 4 normals per thread
         const long long g = (long long)(blockIdx.x - 1 - e.n_item_blocks) * kEpiThreads + tid;
-        if (4 * g < e.n_ab) store_normal4(e.eps_ab, e.n_ab, g, philox_normal4(g, (uint32_t)e.step_count[0], e.ab_stream, e.seed_lo, e.seed_hi));
+        if (4 * g < e.n_ab) store_normal4(e.eps_ab, e.n_ab, g, philox_normal4(g, (uint32_t)step, e.ab_stream, e.seed_lo, e.seed_hi));
         return;
     }
     const float beta = *e.beta, lr = *e.lr;
-    const float t = (float)e.step_count[0];
+    const float t = (float)step;
     const float bc1 = 1.0f - powf(0.9f, t), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t));
+    const int n_parts = kl_part_count(e.n_item_entries);
+    const float* kl_now = e.kl_parts + ((step & 1) ? n_parts : 0);
+    float* kl_next = e.kl_parts + ((step & 1) ? 0 : n_parts);
     if (blockIdx.x == 0) {
         if (tid == 0) e.step_count[1] += 1;      // completed steps (nothing in this launch reads it)
         const float* scp = e.flat_in;
@@ -283,7 +296,16 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const
             scp = sc;
             gtp = gt;
         }
-        epi_mlp_block(L, e.H, e.O, e.n_kl_parts, scp, gtp, e.saved_h, e.kl_parts, beta, lr, bc1, bc2_sqrt, e.P, e.M, e.V, e.loss_out, tid);
+        epi_mlp_block(L, e.H, e.O, n_parts, scp, gtp, e.saved_h, kl_now, beta, lr, bc1, bc2_sqrt, e.P, e.M, e.V, e.loss_out, tid);
+        // the next step's expert table from the parameters just written (this workgroup's own stores: visible after the barrier)
+        __syncthreads();
+        float* h1 = &L.h1[0][0];
+        float* h2 = &L.h2[0][0];
+        mlp2_layer0(e.P, e.H, e.O, h1, tid, kEpiThreads);
+        __syncthreads();
+        mlp2_layer1(e.P, e.H, e.O, h1, h2, tid, kEpiThreads);
+        __syncthreads();
+        mlp2_layer2(e.P, e.H, e.O, h1, h2, tid, kEpiThreads, e.table, e.saved_h);
         return;
     }
     // item block: entries k = 64 (block - 1) + lane in the records' order (dim-major: consecutive lanes = consecutive items)
@@ -306,10 +328,18 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const
     } else if (slice == 0 && live) {
         g = e.flat_in[VIBO_NUM_SCALARS + 2 * n_table + idx];
     }
-    if (slice == 0 && live) {
-        const float eps = e.eps_item[idx];
-        epi_item_update(idx, e.n_item_entries, -g, eps, beta, lr, bc1, bc2_sqrt, e.mu, e.lv, e.im, e.iv);
-        if (e.draw) e.eps_item[idx] = philox_normal1(idx, (uint32_t)e.step_count[0], 0u, e.seed_lo, e.seed_hi);
+    if (slice == 0) {                            // (wave 0 of the block, all 64 lanes: the wave total below needs them)
+        float kl = 0.f;
+        if (live) {
+            float pm, pl;
+            epi_item_update(idx, e.n_item_entries, -g, e.eps_item[idx], beta, lr, bc1, bc2_sqrt, e.mu, e.lv, e.im, e.iv, pm, pl);
+            const float en = philox_normal1(idx, (uint32_t)step, 0u, e.seed_lo, e.seed_hi);
+            e.eps_item[idx] = en;
+            e.item_feat[idx] = item_sample(pm, pl, en);
+            kl = item_kl_term(pm, pl);
+        }
+        kl = wave_total(kl);
+        if (lane == 0) kl_next[blockIdx.x - 1] = kl;
     }
 }
 
@@ -321,7 +351,7 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ ou
 }
 
 hipError_t launch_train_epilogue_fused(const EpiParams& e, hipStream_t s) {
-    const long long ab_blocks = e.draw ? ((e.n_ab + 3) / 4 + kEpiThreads - 1) / kEpiThreads : 0;
+    const long long ab_blocks = ((e.n_ab + 3) / 4 + kEpiThreads - 1) / kEpiThreads;
     hipLaunchKernelGGL(train_epilogue_fused_kernel, dim3((unsigned)(1 + e.n_item_blocks + ab_blocks)), dim3(kEpiThreads), 0, s, e);
     return hipGetLastError();
 }
@@ -348,8 +378,21 @@ extern "C" int vibo_train_prologue(const vibo_desc* d, int hidden_dim, const flo
     if (!d || hidden_dim < 1 || hidden_dim > kMaxHidden || d->posterior != VIBO_POSTERIOR_UNCONDITIONAL || d->n_flows != 0) return -6;
     const int n = d->num_item * item_dim_of(d);
     const int blocks = 1 + (n + 255) / 256;
-    hipLaunchKernelGGL(train_prologue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hidden_dim, 2 * d->ability_dim, n,
-                       mlp_params, item_mu, item_logvar, eps_item, item_feat, table, saved_h, kl_parts, step_count, 0, 0u, 0u,
+    hipLaunchKernelGGL(train_prologue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hidden_dim, 2 * d->ability_dim, d->num_item,
+                       item_dim_of(d), mlp_params, item_mu, item_logvar, eps_item, item_feat, table, saved_h, kl_parts, step_count, 1, 0, 0u, 0u,
+                       (float*)nullptr, (float*)nullptr, 0LL, 0u, (n + 255) / 256);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vibo_train_prime(const vibo_desc* d, int hidden_dim, const float* mlp_params, const float* item_mu,
+                                const float* item_logvar, const float* eps_item, float* item_feat, float* table,
+                                float* saved_h, float* kl_parts, int32_t* step_count, void* stream) {
+    if (!d || hidden_dim < 1 || hidden_dim > kMaxHidden || d->posterior != VIBO_POSTERIOR_UNCONDITIONAL || d->n_flows != 0) return -6;
+    if (!mlp_params || !item_mu || !item_logvar || !eps_item || !item_feat || !table || !saved_h || !kl_parts || !step_count) return -5;
+    const int n = d->num_item * item_dim_of(d);
+    const int blocks = 1 + (n + 255) / 256;
+    hipLaunchKernelGGL(train_prologue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hidden_dim, 2 * d->ability_dim, d->num_item,
+                       item_dim_of(d), mlp_params, item_mu, item_logvar, eps_item, item_feat, table, saved_h, kl_parts, step_count, 0, 0, 0u, 0u,
                        (float*)nullptr, (float*)nullptr, 0LL, 0u, (n + 255) / 256);
     return (int)hipGetLastError();
 }
@@ -365,9 +408,9 @@ extern "C" int vibo_train_prologue_noise(const vibo_desc* d, int hidden_dim, con
     const long long n_ab = (long long)d->num_person * d->ability_dim;
     const long long ab_blocks = ((n_ab + 3) / 4 + 255) / 256;
     hipLaunchKernelGGL(train_prologue_kernel, dim3((unsigned)(1 + item_blocks + ab_blocks)), dim3(256), 0, (hipStream_t)stream,
-                       hidden_dim, 2 * d->ability_dim, n, mlp_params, item_mu, item_logvar, (const float*)eps_item, item_feat, table,
-                       saved_h, kl_parts, step_count, 1, (uint32_t)seed, (uint32_t)(seed >> 32), eps_item, eps_ability, n_ab,
-                       ability_stream_id, item_blocks);
+                       hidden_dim, 2 * d->ability_dim, d->num_item, item_dim_of(d), mlp_params, item_mu, item_logvar, (const float*)eps_item,
+                       item_feat, table, saved_h, kl_parts, step_count, 1, 1, (uint32_t)seed, (uint32_t)(seed >> 32), eps_item, eps_ability,
+                       n_ab, ability_stream_id, item_blocks);
     return (int)hipGetLastError();
 }
 
@@ -378,7 +421,7 @@ extern "C" int vibo_train_epilogue(const vibo_desc* d, int hidden_dim, const flo
                                    void* stream) {
     if (!d || hidden_dim < 1 || hidden_dim > kMaxHidden || d->posterior != VIBO_POSTERIOR_UNCONDITIONAL || d->n_flows != 0) return -6;
     const int n = d->num_item * item_dim_of(d);
-    const int parts = (n + 255) / 256;                       // the prologue's item-KL partial sums (256 entries each)
+    const int parts = kl_part_count(n);                      // the prologue's item-KL partial sums (one per 64 entries)
     hipLaunchKernelGGL(train_epilogue_kernel, dim3(1 + (n + kEpiThreads - 1) / kEpiThreads), dim3(kEpiThreads), 0, (hipStream_t)stream,
                        hidden_dim, 2 * d->ability_dim, n, parts, flat, saved_h, kl_parts, eps_item, beta, lr, step_count, mlp_params, mlp_m, mlp_v, item_mu,
                        item_logvar, item_m, item_v, loss_out);

@@ -62,23 +62,6 @@ class ViboDecoderDesc(ctypes.Structure):
     ]
 
 
-class ViboTrainHook(ctypes.Structure):
-    """struct vibo_train_hook (include/vibo_hip.h)."""
-    _fields_ = [
-        ('hidden_dim', ctypes.c_int32),
-        ('skip_finalize', ctypes.c_int32),
-        ('mlp_params', ctypes.c_void_p),
-        ('item_mu', ctypes.c_void_p),
-        ('item_logvar', ctypes.c_void_p),
-        ('eps_item', ctypes.c_void_p),
-        ('item_feat', ctypes.c_void_p),
-        ('table', ctypes.c_void_p),
-        ('saved_h', ctypes.c_void_p),
-        ('kl_parts', ctypes.c_void_p),
-        ('step_count', ctypes.c_void_p),
-    ]
-
-
 EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_bytes', 'vibo_plan_kernel', 'vibo_plan_cond_passes',
                     'vibo_elbo_fwd_bwd', 'vibo_encode', 'vibo_decode', 'vibo_train_prologue', 'vibo_train_epilogue', 'vibo_fill_normal', 'vibo_multi_workspace_bytes',
                     'vibo_elbo_multi_forward', 'vibo_decode_mean', 'vibo_pack_codes', 'vibo_row_counts', 'vibo_mean_encoder_partials',
@@ -86,7 +69,7 @@ EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_by
                     'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd', 'vibo_flow_stack_forward', 'vibo_flow_stack_backward',
                     'vibo_ctrain_param_floats', 'vibo_ctrain_scratch_floats', 'vibo_ctrain_prologue', 'vibo_ctrain_epilogue',
                     'vibo_code_table_scratch_bytes', 'vibo_code_table_sum_forward', 'vibo_code_table_sum_backward',
-                    'vibo_train_hook_supported', 'vibo_elbo_fwd_bwd_train', 'vibo_train_epilogue_fused')
+                    'vibo_train_step_supported', 'vibo_elbo_fwd_bwd_step', 'vibo_train_epilogue_fused', 'vibo_train_prime')
 
 _lib = None
 
@@ -173,15 +156,17 @@ def load():
     for fn in (lib.vibo_code_table_sum_forward, lib.vibo_code_table_sum_backward):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int64, fp, fp, vp, ctypes.c_size_t, vp]
-    lib.vibo_train_hook_supported.restype = ctypes.c_int
-    lib.vibo_train_hook_supported.argtypes = [dp, ctypes.c_int]
-    lib.vibo_elbo_fwd_bwd_train.restype = ctypes.c_int
-    lib.vibo_elbo_fwd_bwd_train.argtypes = [dp, ctypes.POINTER(ViboTrainHook), fp, vp, i64p, fp,      # inputs
-                                            fp, fp, fp, fp, fp, fp,                                  # scalars, posterior, grads
-                                            vp, ctypes.c_size_t, vp]                                 # workspace, stream
+    lib.vibo_train_step_supported.restype = ctypes.c_int
+    lib.vibo_train_step_supported.argtypes = [dp]
+    lib.vibo_elbo_fwd_bwd_step.restype = ctypes.c_int
+    lib.vibo_elbo_fwd_bwd_step.argtypes = [dp, vp, ctypes.c_int, fp, vp, i64p, fp, fp, fp,              # step counter, skip, inputs
+                                           fp, fp, fp, fp, fp, fp,                                   # scalars, posterior, grads
+                                           vp, ctypes.c_size_t, vp]                                  # workspace, stream
     lib.vibo_train_epilogue_fused.restype = ctypes.c_int
     lib.vibo_train_epilogue_fused.argtypes = ([dp, ctypes.c_int, vp] + [fp] * 6 + [vp] + [fp] * 8 +
-                                              [ctypes.c_int, ctypes.c_uint64, fp, ctypes.c_int64, ctypes.c_uint32, vp])
+                                              [ctypes.c_uint64, fp, fp, fp, ctypes.c_int64, ctypes.c_uint32, vp])
+    lib.vibo_train_prime.restype = ctypes.c_int
+    lib.vibo_train_prime.argtypes = [dp, ctypes.c_int] + [fp] * 8 + [vp, vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

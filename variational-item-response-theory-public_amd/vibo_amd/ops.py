@@ -273,11 +273,11 @@ def _require_device(*tensors):
 
 
 def _hip_launch_elbo(spec, response, mask, mask_code, row_index, table, item, eps, flow, reg_mode,
-                     want_grad, num_person, train_hook=None):
+                     want_grad, num_person, train_step=None):
     """Single call into vibo_elbo_fwd_bwd on the current stream.
-    train_hook (a filled _lib.ViboTrainHook; table / item / flow = None): vibo_elbo_fwd_bwd_train instead -- the kernel forms
-    the expert table and the item sample itself (the folded train step, trainer.FusedTrainer); with hook.skip_finalize the
-    partial records stay in RawElbo.workspace for vibo_train_epilogue_fused and `flat` is filled by that call."""
+    train_step = (step_count tensor, skip_finalize): vibo_elbo_fwd_bwd_step instead -- the same call that also ticks Adam's
+    step counter (the folded train step, trainer.FusedTrainer); with skip_finalize the partial records stay in
+    RawElbo.workspace for vibo_train_epilogue_fused and `flat` is filled by that call."""
     lib = _lib.load()
     _require_device(response, mask, table, item, eps)
     dev = response.device
@@ -305,13 +305,14 @@ def _hip_launch_elbo(spec, response, mask, mask_code, row_index, table, item, ep
     o_item = o_tab + 2 * n_table
     o_flow = o_item + n_item
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    if train_hook is not None:
-        rc = lib.vibo_elbo_fwd_bwd_train(
-            ctypes.byref(d), ctypes.byref(train_hook), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(eps),
+    if train_step is not None:
+        rc = lib.vibo_elbo_fwd_bwd_step(
+            ctypes.byref(d), _ptr(train_step[0]), 1 if train_step[1] else 0, _ptr(response), _ptr(mask), _ptr(row_index),
+            _ptr(table), _ptr(item), _ptr(eps),
             ctypes.c_void_p(fbase), _ptr(post[0]), _ptr(post[1]), _ptr(post[2]),
             ctypes.c_void_p(fbase + esz * o_tab), ctypes.c_void_p(fbase + esz * o_item),
             _ptr(ws), ctypes.c_size_t(ws_bytes), stream)
-        _lib.check(rc, 'vibo_elbo_fwd_bwd_train')
+        _lib.check(rc, 'vibo_elbo_fwd_bwd_step')
     else:
         rc = lib.vibo_elbo_fwd_bwd(
             ctypes.byref(d), _ptr(response), _ptr(mask), _ptr(row_index), _ptr(table), _ptr(item), _ptr(eps),
@@ -324,7 +325,7 @@ def _hip_launch_elbo(spec, response, mask, mask_code, row_index, table, item, ep
     raw = RawElbo(flat=flat, n_table=n_table, n_item=n_item, n_flow=n_flow, table_shape=table_shape,
                   ability_mu=post[0], ability_logvar=post[1], ability=post[2],
                   ability_k=ability_k, ability_ladj=ladj)
-    if train_hook is not None and train_hook.skip_finalize:
+    if train_step is not None and train_step[1]:
         raw.workspace = ws          # (kept alive until the epilogue has summed the partial records)
     return raw
 

@@ -4,15 +4,18 @@ reference loop (vibo.py:243-268) as TWO kernel launches instead of ~80.
     trainer = FusedTrainer(model, lr=5e-3)
     loss = trainer.step(response, mask, beta=1.0, row_index=rows)      # device scalar, parameters updated in place
 
-What runs (the folded step, `fold=True`, the default):
-    vibo_elbo_fwd_bwd_train    the row-split ELBO kernel with the train hook: its own prologue forms the item sample, the item
-                               KL and the 2-row encoder table, then the fused ELBO forward + backward over the rows
+What runs (the folded step, `fold=True` with rng='native', the default of the CLI and the benchmark):
+    vibo_elbo_fwd_bwd_step     the fused ELBO forward + backward over the rows (ticks Adam's step counter)
     [person-sharded: finalize inside that call, then ONE all-reduce of the flat buffer]
-    vibo_train_epilogue_fused  finalize (one GPU), loss, encoder-MLP / item backward, Adam -- and, with rng='native', the
-                               NEXT step's Philox noise (the first step's comes from two vibo_fill_normal calls)
-`fold=False` keeps the four-launch form (vibo_train_prologue[_noise] -> vibo_elbo_fwd_bwd = kernel + finalize ->
-vibo_train_epilogue): the two forms agree bit for bit (tests/test_gpu_trainer.py), and shapes the hook does not cover (more
-than 1024 items, int64 masks, unaligned rows) take it automatically.
+    vibo_train_epilogue_fused  finalize (one GPU), loss, encoder-MLP / item backward, Adam -- and the NEXT step's head: Philox
+                               noise, item sample, item KL, the 2-row encoder table from the parameters just updated
+The step is software-pipelined across its own iterations: when the ELBO kernel starts, everything it reads is in memory.  The
+first step's head comes from vibo_fill_normal x 2 + vibo_train_prime ("priming"), repeated whenever the parameters were
+changed from outside between two steps (load_state_dict: detected through the tensors' version counters) or a larger
+minibatch than ever before arrives.
+`fold=False`, rng='torch' (noise from torch's generators: not known a step ahead) and shapes the folded step does not cover
+(more than 1024 items, int64 masks, unaligned rows) take the four-launch form (vibo_train_prologue[_noise] ->
+vibo_elbo_fwd_bwd = kernel + finalize -> vibo_train_epilogue); the two forms agree bit for bit (tests/test_gpu_trainer.py).
 Same arithmetic as the PyTorch path (tests/test_gpu_trainer.py compares parameters after several steps); `.grad` fields are not
 populated.
 FusedTrainer covers the unconditional posterior without flows; `FusedTrainer(model)` returns its sibling
@@ -53,7 +56,7 @@ class FusedTrainer:
                                       'use model.elbo_step + torch.optim.Adam otherwise')
         self.model = model
         self.fold = bool(fold)                # two launches per step (train hook + fused epilogue) where the shape allows
-        self._primed_for = None               # folded step, rng='native': (capacity) the pre-drawn noise buffers are primed for
+        self._primed_for = None               # folded step: (noise capacity, parameter versions) the next step's head was prepared for
         self._eps_cap = None                  # ... the ability-noise buffer [capacity] every step's epilogue refills
         self._eps_keep = []                   # (outgrown buffers stay alive: a captured graph may still write to them)
         mlp = model.ability_encoder.mlp
@@ -74,6 +77,7 @@ class FusedTrainer:
         self.item_mu = model.item_encoder.mu_lookup.weight
         self.item_lv = model.item_encoder.logvar_lookup.weight
         assert self.item_mu.is_contiguous() and self.item_lv.is_contiguous()
+        self._watched = plist + [self.mlp_flat, self.item_mu, self.item_lv]
         n_item = self.item_mu.numel()
         self.item_m = torch.zeros(2 * n_item, device=dev)
         self.item_v = torch.zeros(2 * n_item, device=dev)
@@ -85,7 +89,7 @@ class FusedTrainer:
         self.item_feat = torch.empty_like(self.item_mu)
         self.table = torch.empty(2, 2 * A, device=dev)
         self.saved_h = torch.empty(4 * self.hidden, device=dev)
-        self.kl_parts = torch.empty((n_item + 255) // 256, device=dev)
+        self.kl_parts = torch.empty(2 * ((n_item + 63) // 64), device=dev)      # (two halves: the folded step double-buffers them)
         self.loss = torch.zeros((), device=dev)
         self.last = None                      # RawElbo of the last step (posterior outputs, scalars)
         self._pending = None
@@ -129,9 +133,9 @@ class FusedTrainer:
         d = ops._make_desc(spec, B, I, code, _lib.REG_KL, True, response.stride(0), mask.stride(0) if mask is not None else 0)
         p = ops._ptr
         ab_stream = 1 + getattr(model, '_shard_rank', 0)      # item noise: the same on every rank; ability noise: per rank
-        hook_bits = lib.vibo_train_hook_supported(ctypes.byref(d), self.hidden) if self.fold else 0
-        if hook_bits & 1 and (self.rng != 'native' or self.fused_noise):
-            return self._forward_backward_folded(d, hook_bits, response, mask, code, row_index, B, ab_stream, stream)
+        step_bits = lib.vibo_train_step_supported(ctypes.byref(d)) if (self.fold and self.rng == 'native' and self.fused_noise) else 0
+        if step_bits & 1:
+            return self._forward_backward_folded(d, step_bits, response, mask, code, row_index, B, ab_stream, stream)
         # ---- the four-launch form ----
         # reference draw order: item eps, then ability eps (models.py:361,368)
         if self.rng == 'native':
@@ -166,44 +170,40 @@ class FusedTrainer:
         self.last = raw
         return raw
 
-    def _forward_backward_folded(self, d, hook_bits, response, mask, code, row_index, B, ab_stream, stream):
-        """The folded step's first launch: vibo_elbo_fwd_bwd_train (+ the stand-alone finalize when an all-reduce follows)."""
+    def _param_versions(self):
+        # (torch bumps a tensor's version on every in-place write it knows of -- load_state_dict, optimizers, .copy_ -- while
+        #  this library's kernels update the same memory without touching it: a change means somebody else wrote)
+        return tuple(t._version for t in self._watched)
+
+    def _forward_backward_folded(self, d, step_bits, response, mask, code, row_index, B, ab_stream, stream):
+        """The folded step's first launch: vibo_elbo_fwd_bwd_step (+ the stand-alone finalize when an all-reduce follows)."""
         model, spec, lib, p = self.model, self.model.spec, _lib.load(), ops._ptr
         dev = response.device
         A = model.ability_dim
-        native = self.rng == 'native'
-        if native:
-            # The noise of a step is drawn by the previous step's epilogue into buffers that never move (a captured hipGraph
-            # keeps their pointers): eps_item in place, the ability noise into ONE buffer of fixed capacity -- the streams are
-            # indexed by element, so a step of fewer persons reads a prefix of the same values a fresh draw would give (the
-            # epoch's last, shorter minibatch between two replays).  Before the first step, and when a larger batch than ever
-            # before arrives, two vibo_fill_normal calls prime them for the current step counter.
-            need = B * A
-            if self._eps_cap is None or self._eps_cap.numel() < need:
-                if self._eps_cap is not None:
-                    self._eps_keep.append(self._eps_cap)
-                self._eps_cap = torch.empty(need, device=dev)
-                self._primed_for = None
-            if self._primed_for != self._eps_cap.numel():
-                noise_step = ctypes.c_void_p(self._steps.data_ptr() + 4)          # completed steps (step_count[1])
-                _lib.check(lib.vibo_fill_normal(p(self._eps_item), self._eps_item.numel(), self.seed, noise_step, 0, stream), 'vibo_fill_normal')
-                _lib.check(lib.vibo_fill_normal(p(self._eps_cap), self._eps_cap.numel(), self.seed, noise_step, ab_stream, stream), 'vibo_fill_normal')
-                self._primed_for = self._eps_cap.numel()
-            eps_item, eps_ab = self._eps_item, self._eps_cap[:need].view(B, A)
-        else:
-            # reference draw order: item eps, then ability eps (models.py:361,368)
-            eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
-            eps_ab = model._randn((B, A), self.item_mu, model._ability_gen)
-        hook = _lib.ViboTrainHook()
-        hook.hidden_dim = self.hidden
-        fused_finalize = bool(hook_bits & 2) and model._reducer is None
-        hook.skip_finalize = 1 if fused_finalize else 0
-        for name, t in (('mlp_params', self.mlp_flat), ('item_mu', self.item_mu), ('item_logvar', self.item_lv), ('eps_item', eps_item),
-                        ('item_feat', self.item_feat), ('table', self.table), ('saved_h', self.saved_h), ('kl_parts', self.kl_parts),
-                        ('step_count', self._steps)):
-            setattr(hook, name, t.data_ptr())
-        raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, None, None, eps_ab, None, _lib.REG_KL, True, B,
-                                   train_hook=hook)
+        # The head of a step (noise, item sample, item KL, expert table) is left behind by the previous step's epilogue in
+        # buffers that never move (a captured hipGraph keeps their pointers); the ability noise goes into ONE buffer of fixed
+        # capacity -- the streams are indexed by element, so a step of fewer persons reads a prefix of the same values a fresh
+        # draw would give (the epoch's last, shorter minibatch between two replays).  Before the first step, when a larger
+        # batch than ever before arrives, or when somebody else wrote the parameters, the head is (re)built here.
+        need = B * A
+        if self._eps_cap is None or self._eps_cap.numel() < need:
+            if self._eps_cap is not None:
+                self._eps_keep.append(self._eps_cap)
+            self._eps_cap = torch.empty(need, device=dev)
+            self._primed_for = None
+        state = (self._eps_cap.numel(),) + self._param_versions()
+        if self._primed_for != state:
+            noise_step = ctypes.c_void_p(self._steps.data_ptr() + 4)          # completed steps (step_count[1])
+            _lib.check(lib.vibo_fill_normal(p(self._eps_item), self._eps_item.numel(), self.seed, noise_step, 0, stream), 'vibo_fill_normal')
+            _lib.check(lib.vibo_fill_normal(p(self._eps_cap), self._eps_cap.numel(), self.seed, noise_step, ab_stream, stream), 'vibo_fill_normal')
+            rc = lib.vibo_train_prime(ctypes.byref(d), self.hidden, p(self.mlp_flat), p(self.item_mu), p(self.item_lv), p(self._eps_item),
+                                      p(self.item_feat), p(self.table), p(self.saved_h), p(self.kl_parts), p(self._steps), stream)
+            _lib.check(rc, 'vibo_train_prime')
+            self._primed_for = state
+        eps_item, eps_ab = self._eps_item, self._eps_cap[:need].view(B, A)
+        fused_finalize = bool(step_bits & 2) and model._reducer is None
+        raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None, _lib.REG_KL, True, B,
+                                   train_step=(self._steps, fused_finalize))
         self._pending = (d, eps_item, raw, ab_stream)
         self.last = raw
         return raw
@@ -220,13 +220,11 @@ class FusedTrainer:
         lib, p = _lib.load(), ops._ptr
         stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
         if folded_stream is not None:
-            native = self.rng == 'native'
             rc = lib.vibo_train_epilogue_fused(ctypes.byref(d), self.hidden, p(raw.workspace), p(raw.flat), p(self.saved_h),
                                                p(self.kl_parts), p(eps_item), p(self.beta), p(self.lr), p(self._steps),
                                                p(self.mlp_flat), p(self.mlp_m), p(self.mlp_v), p(self.item_mu), p(self.item_lv),
-                                               p(self.item_m), p(self.item_v), p(self.loss), 1 if native else 0, self.seed,
-                                               p(self._eps_cap) if native else ctypes.c_void_p(0),
-                                               self._eps_cap.numel() if native else 0, folded_stream, stream)
+                                               p(self.item_m), p(self.item_v), p(self.loss), self.seed, p(self.item_feat),
+                                               p(self.table), p(self._eps_cap), self._eps_cap.numel(), folded_stream, stream)
             _lib.check(rc, 'vibo_train_epilogue_fused')
             return self.loss
         rc = lib.vibo_train_epilogue(ctypes.byref(d), self.hidden, p(raw.flat), p(self.saved_h), p(self.kl_parts),
