@@ -86,4 +86,15 @@ e0.record()
 for _ in range(10): native(*last['a'], **last['k'])
 e1.record(); torch.cuda.synchronize()
 res['bare_back_to_back_ms'] = e0.elapsed_time(e1) / 10
+# the host + front-end cost of replaying a graph at all: one 1-element kernel
+xx = torch.zeros(1, device=dev)
+gr3 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr3):
+    xx.add_(1.0)
+for _ in range(5): gr3.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200): gr3.replay()
+torch.cuda.synchronize()
+res['one_tiny_kernel_graph_period_ms'] = (time.perf_counter() - t0) / 200 * 1e3
 print(res)

@@ -13,6 +13,18 @@ __device__ __forceinline__ double record_slice_sum(const float* __restrict__ par
                                                    const int b1, const int slice) {
     double a4[4] = {0.0, 0.0, 0.0, 0.0};
     int b = b0 + slice;
+    // sixteen records per trip, every load issued before the first add (the adds keep the order of the four-at-a-time loop
+    // below: chain u takes records u, 4 + u, 8 + u, 12 + u of the trip) -- with one load round trip per four records the 256
+    // records of a full launch cost four dependent memory latencies per output
+    for (; b + 15 * SLICES < b1; b += 16 * SLICES) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = partial[(size_t)(b + u * SLICES) * stride + src];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += (double)x[4 * i + u];
+    }
     for (; b + 3 * SLICES < b1; b += 4 * SLICES) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) a4[u] += (double)partial[(size_t)(b + u * SLICES) * stride + src];
