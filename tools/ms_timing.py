@@ -12,7 +12,8 @@ n = 1024 * 8 * 16
 buf = (ctypes.c_longlong * n)()
 lib.vibo_debug_ms_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = lib.vibo_debug_ms_timing(buf, n)
-t = np.frombuffer(buf, dtype=np.int64).reshape(1024, 8, 16)[:256, :, :12].astype(np.float64)
+raw = np.frombuffer(buf, dtype=np.int64).reshape(1024, 8, 16)[:256]
+t = raw[:, :, :12].astype(np.float64)
 nb = (P + 31) // 32 / 256
 names = ['tiles u0', 'pack0', 'tiles u1', 'pack1', 'counts+gth', 'barrier A', 'forward', 'barrier B', 'read ops', 'backward', 'wait loads x2', 'issue loads x2']
 print('rc', rc, 'batches per workgroup %.1f' % nb)
@@ -20,3 +21,13 @@ print('phase           ' + ''.join(f' wave{w:1d}  ' for w in range(8)) + '   (cy
 for k, nm in enumerate(names):
     print(f'{nm:14s}' + ''.join(f'{t[:, w, k].mean() / nb:8.0f}' for w in range(8)))
 print(f'{"total":14s}' + ''.join(f'{t[:, w, :].sum(axis=1).mean() / nb:8.0f}' for w in range(8)))
+
+# fixed cost of a launch: kernel prologue / epilogue in shader cycles, and the launch's wall-clock span (100 MHz real-time counter)
+print('prologue cycles (mean over workgroups, per wave):', ' '.join(f'{raw[:, w, 12].mean():8.0f}' for w in range(8)))
+print('epilogue cycles (mean over workgroups, per wave):', ' '.join(f'{raw[:, w, 13].mean():8.0f}' for w in range(8)))
+ent, ext = raw[:, :, 14].astype(np.float64), raw[:, :, 15].astype(np.float64)
+live = ent > 0
+t0 = ent[live].min()
+print(f'wall clock (us from the first wave\'s entry): entries {((ent[live] - t0) / 100).min():.2f} .. {((ent[live] - t0) / 100).max():.2f}, '
+      f'exits {((ext[live] - t0) / 100).min():.2f} .. {((ext[live] - t0) / 100).max():.2f}; loop cycles per workgroup (wave 0): '
+      f'mean {t[:, 0, :].sum(axis=1).mean():.0f}, min {t[:, 0, :].sum(axis=1).min():.0f}, max {t[:, 0, :].sum(axis=1).max():.0f}')

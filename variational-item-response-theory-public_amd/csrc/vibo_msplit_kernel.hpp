@@ -139,6 +139,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     MsCommonLds& cl = *reinterpret_cast<MsCommonLds*>(ms_smem);
     MsWaveLds* wls = reinterpret_cast<MsWaveLds*>(ms_smem + sizeof(MsCommonLds));
 
+#ifdef VIBO_MS_TIMING
+    long long t_entry, t_real_entry;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry), "=s"(t_real_entry) :: "memory");
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -964,8 +968,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     half8 bopA = item_op(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     half8 bopB = item_op(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
 #ifdef VIBO_MS_TIMING
-    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = (long long)__builtin_readcyclecounter();
+    long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+    tacc[12] = tlast - t_entry;                      // kernel prologue (operand images, first batch)
+    tacc[14] = t_real_entry;                         // wall clock (100 MHz) at entry
 #endif
     // One iteration = [request the first half of the next batch's rows] [sync phase of this batch: counts -> theta, with the
     // backward of the previous batch in the waves that have no forward slot] [math of this batch, with the next batch's rows
@@ -1048,9 +1055,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     }
 
 #ifdef VIBO_MS_TIMING
-    if (lane == 0 && blockIdx.x < 1024) {
-        for (int k = 0; k < 12; ++k) g_ms_timing[((size_t)blockIdx.x * 8 + q) * 16 + k] = tacc[k];
-    }
+    long long t_loop_end;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop_end) :: "memory");
 #endif
     // ================= workgroup reduction -> partial record =================
     float* out = p.partial + (size_t)blockIdx.x * p.lay.stride;
@@ -1127,6 +1133,17 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
     }
+#ifdef VIBO_MS_TIMING
+    {
+        long long t_exit, t_real_exit;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_exit), "=s"(t_real_exit) :: "memory");
+        tacc[13] = t_exit - t_loop_end;              // kernel epilogue (records)
+        tacc[15] = t_real_exit;
+        if (lane == 0 && blockIdx.x < 1024) {
+            for (int k = 0; k < 16; ++k) g_ms_timing[((size_t)blockIdx.x * 8 + q) * 16 + k] = tacc[k];
+        }
+    }
+#endif
 }
 
 template <int IRT, bool GRAD, int RM, bool FLOWS, bool NW8, bool EXTRA>

@@ -103,13 +103,17 @@ struct EpiLds {
 //   W / ow: where the backward reads the weights and their layout -- the caller's flat buffer P (ld = H), or the fused
 //   epilogue's padded LDS copy, which then also receives the updated values (Wout) for the next step's forward
 //   pv / mv / vv: parameter, first and second moment of elements tid + 1024 u, loaded by the caller (as early as it can)
+//   HC: the hidden width as a compile-time constant (64: the reference default), or 0 for a runtime width -- the Adam loop
+//   decodes six flat indices per thread with / H and % H, ~40 instructions each when H is not a constant (5 us of the chain)
 constexpr int kEpiU = 8;
-__device__ __forceinline__ void epi_mlp_block(EpiLds& L, const int H, const int O, const int n_kl_parts, const float* sc, const float* gtab,
+template <int HC>
+__device__ __forceinline__ void epi_mlp_block(EpiLds& L, const int H_, const int O, const int n_kl_parts, const float* sc, const float* gtab,
                                               const float* __restrict__ saved_h, const float* __restrict__ kl_parts, const float beta,
                                               const float lr, const float bc1, const float bc2_sqrt, const float* W, const MlpOffsets ow,
                                               float* Wout, float* P, float* M, float* V, float (&pv)[kEpiU], float (&mv)[kEpiU],
                                               float (&vv)[kEpiU], float* loss_out, const int tid) {
     constexpr int BS = kEpiThreads;
+    const int H = HC > 0 ? HC : H_;
     const int n_table = 2 * O;
     const MlpOffsets o = mlp_offsets(H, O);
     for (int k = tid; k < 2 * H; k += BS) {
@@ -197,7 +201,7 @@ __device__ __forceinline__ void epi_mlp_block(EpiLds& L, const int H, const int 
             P[k] = pv[u];
             M[k] = mv[u];
             V[k] = vv[u];
-            if (Wout) Wout[mlp_reindex(k, H, O, ow)] = pv[u];
+            if (Wout) Wout[mlp_reindex(k, H, O, ow)] = pv[u];      // (ow.ld = H + 1)
         }
     }
 }
@@ -233,8 +237,10 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_kernel(int H, int 
         float pv[kEpiU], mv[kEpiU], vv[kEpiU];
         const MlpOffsets o = mlp_offsets(H, O);
         epi_mlp_prefetch(o.total, P, M, V, pv, mv, vv, tid);
-        epi_mlp_block(L, H, O, n_kl_parts, flat, flat + VIBO_NUM_SCALARS, saved_h, kl_parts, beta, lr, bc1, bc2_sqrt, P, o, nullptr, P, M, V, pv, mv,
-                      vv, loss_out, tid);
+        if (H == 64) epi_mlp_block<64>(L, H, O, n_kl_parts, flat, flat + VIBO_NUM_SCALARS, saved_h, kl_parts, beta, lr, bc1, bc2_sqrt, P, o, nullptr,
+                                       P, M, V, pv, mv, vv, loss_out, tid);
+        else epi_mlp_block<0>(L, H, O, n_kl_parts, flat, flat + VIBO_NUM_SCALARS, saved_h, kl_parts, beta, lr, bc1, bc2_sqrt, P, o, nullptr, P, M, V,
+                              pv, mv, vv, loss_out, tid);
         return;
     }
     const int idx = (blockIdx.x - 1) * BS + tid;
@@ -262,6 +268,7 @@ constexpr int kEpiStageFloats = 3 * kEpiStageHidden + (kEpiStageHidden + 2 * VIB
 static_assert(kEpiStageFloats * 8 >= 0 && kEpiThreads * kEpiU >= kEpiStageFloats, "one prefetch pass covers the staged parameters");
 static_assert(kEpiOut == kKlGroup, "one KL part per item block");
 
+template <int HC>
 __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const EpiParams e) {
     __shared__ EpiLds L;
     __shared__ double part[kEpiSlices][kEpiOut], part2[kEpiSlices][kEpiOut];
@@ -288,9 +295,10 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const
         // Block 0 is one chain of small dependent stages: every global load it needs is issued up front (parameters and
         // Adam moments into registers, a padded copy of the parameters into LDS for the stages in between), so that the
         // chain pays memory latency once instead of per stage (25 -> ~12 us at 1 000 items).
-        const MlpOffsets og = mlp_offsets(e.H, e.O);
-        const bool staged = e.H <= kEpiStageHidden;                   // (wider encoders read the weights from global memory)
-        const MlpOffsets ow = staged ? mlp_offsets(e.H, e.O, e.H + 1) : og;
+        const int H = HC > 0 ? HC : e.H;
+        const MlpOffsets og = mlp_offsets(H, e.O);
+        const bool staged = H <= kEpiStageHidden;                   // (wider encoders read the weights from global memory)
+        const MlpOffsets ow = staged ? mlp_offsets(H, e.O, H + 1) : og;
         float pv[kEpiU], mv[kEpiU], vv[kEpiU];
         epi_mlp_prefetch(og.total, e.P, e.M, e.V, pv, mv, vv, tid);
         const float* scp = e.flat_in;
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const
 #pragma unroll
                 for (int u = 0; u < kEpiU; ++u) {
                     const int k = tid + kEpiThreads * u;
-                    if (k < og.total) Pl[mlp_reindex(k, e.H, e.O, ow)] = pv[u];
+                    if (k < og.total) Pl[mlp_reindex(k, H, e.O, ow)] = pv[u];
                 }
             }
             __syncthreads();
@@ -348,22 +356,22 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const
 #pragma unroll
             for (int u = 0; u < kEpiU; ++u) {
                 const int k = tid + kEpiThreads * u;
-                if (k < og.total) Pl[mlp_reindex(k, e.H, e.O, ow)] = pv[u];
+                if (k < og.total) Pl[mlp_reindex(k, H, e.O, ow)] = pv[u];
             }
             __syncthreads();
         }
         const float* W = staged ? Pl : e.P;
-        epi_mlp_block(L, e.H, e.O, n_parts, scp, gtp, e.saved_h, kl_now, beta, lr, bc1, bc2_sqrt, W, ow, staged ? Pl : nullptr, e.P, e.M, e.V,
+        epi_mlp_block<HC>(L, H, e.O, n_parts, scp, gtp, e.saved_h, kl_now, beta, lr, bc1, bc2_sqrt, W, ow, staged ? Pl : nullptr, e.P, e.M, e.V,
                       pv, mv, vv, e.loss_out, tid);
         // the next step's expert table from the parameters just written (this workgroup's own stores: visible after the barrier)
         __syncthreads();
         float* h1 = &L.h1[0][0];
         float* h2 = &L.h2[0][0];
-        mlp2_layer0(W, ow, e.H, e.O, h1, tid, kEpiThreads);
+        mlp2_layer0(W, ow, H, e.O, h1, tid, kEpiThreads);
         __syncthreads();
-        mlp2_layer1(W, ow, e.H, e.O, h1, h2, tid, kEpiThreads);
+        mlp2_layer1(W, ow, H, e.O, h1, h2, tid, kEpiThreads);
         __syncthreads();
-        mlp2_layer2(W, ow, e.H, e.O, h1, h2, tid, kEpiThreads, e.table, e.saved_h);
+        mlp2_layer2(W, ow, H, e.O, h1, h2, tid, kEpiThreads, e.table, e.saved_h);
         return;
     }
     // item block: entries k = 64 (block - 1) + lane in the records' order (dim-major: consecutive lanes = consecutive items)
@@ -410,7 +418,8 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ ou
 
 hipError_t launch_train_epilogue_fused(const EpiParams& e, hipStream_t s) {
     const long long ab_blocks = ((e.n_ab + 3) / 4 + kEpiThreads - 1) / kEpiThreads;
-    hipLaunchKernelGGL(train_epilogue_fused_kernel, dim3((unsigned)(1 + e.n_item_blocks + ab_blocks)), dim3(kEpiThreads), 0, s, e);
+    if (e.H == 64) hipLaunchKernelGGL(train_epilogue_fused_kernel<64>, dim3((unsigned)(1 + e.n_item_blocks + ab_blocks)), dim3(kEpiThreads), 0, s, e);
+    else hipLaunchKernelGGL(train_epilogue_fused_kernel<0>, dim3((unsigned)(1 + e.n_item_blocks + ab_blocks)), dim3(kEpiThreads), 0, s, e);
     return hipGetLastError();
 }
 int train_epilogue_item_blocks(int n_item_entries) { return (n_item_entries + kEpiOut - 1) / kEpiOut; }
