@@ -336,8 +336,8 @@ def test_graph_replay_survives_a_shorter_eager_minibatch_with_native_noise():
     torch.manual_seed(5)
     m1 = VIBO_2PL(A, I, ability_merge='product').to(dev)
     m2 = copy.deepcopy(m1)
-    t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=3)
-    t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=3)
+    t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=3)                    # the folded step: its noise buffer has a fixed capacity
+    t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=3, fold=False)        # the four-launch form, eager throughout
     rows = torch.arange(B, device=dev)
     tail = torch.arange(P - 40, P, device=dev)
     for _ in range(2):
@@ -346,7 +346,7 @@ def test_graph_replay_survives_a_shorter_eager_minibatch_with_native_noise():
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         lg = t1.step(resp, mask, row_index=rows)
-    ptr = t1._eps_ab[B].data_ptr()
+    ptr = t1._eps_cap.data_ptr()
     for it in range(4):
         graph.replay()
         l2 = t2.step(resp, mask, row_index=rows)
@@ -355,7 +355,7 @@ def test_graph_replay_survives_a_shorter_eager_minibatch_with_native_noise():
         junk = [torch.full((B, A), float('nan'), device=dev) for _ in range(4)]                   # allocator churn
         assert torch.equal(la, lb), it
         del junk
-    assert t1._eps_ab[B].data_ptr() == ptr
+    assert t1._eps_cap.data_ptr() == ptr and t1._eps_cap.numel() == B * A
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
 
