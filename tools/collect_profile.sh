@@ -24,7 +24,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_
   n=$(echo $pass | cut -d' ' -f1)
   echo; echo "# command: rocprofv3 --pmc $pass -- $B     (per-dispatch averages, vibo kernels only)"
   rocprofv3 --pmc $pass -d $W/$n -o p -- $B > /dev/null 2>&1
-  python $R/tools/rocpd_summary.py $W/$n/p_results.db vibo | grep -E "ElboParams|msplit_kernel|split_kernel|finalize|item_prep"
+  python $R/tools/rocpd_summary.py $W/$n/p_results.db vibo | grep -E "ElboParams|msplit_kernel|split_kernel|finalize|epilogue|prologue"
 done
 } > $S 2>&1
 rm -rf $W

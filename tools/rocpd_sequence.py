@@ -10,10 +10,10 @@ rows = con.execute(f'select k.kernel_name, d.start, d.end from "{tabs["rocpd_ker
                    f'"{tabs["rocpd_info_kernel_symbol"]}" k on d.kernel_id = k.id order by d.start').fetchall()
 idx = [i for i, r in enumerate(rows) if anchor in r[0]]
 # the replayed train step, not the back-to-back eager calls around it: among consecutive anchor launches take the last pair
-# whose dispatch count is the most common one above 2 (falls back to the last pair)
+# whose dispatch count is the most common one above 1 (falls back to the last pair)
 from collections import Counter
 pairs = [(idx[k], idx[k + 1]) for k in range(len(idx) - 1)]
-cnt = Counter(b - a for a, b in pairs if b - a > 2)
+cnt = Counter(b - a for a, b in pairs if b - a > 1)      # (the folded train step is two dispatches; bare loops are one)
 if cnt:
     mode = cnt.most_common(1)[0][0]
     a, b = [pr for pr in pairs if pr[1] - pr[0] == mode][-1]
