@@ -10,19 +10,20 @@ items, ability_dim 8, synthetic Bernoulli responses with 10 % missing cells, dev
 timed region), the persons sharded over the N ranks (`--scaling strong`, the default: at N = 1 the one GPU holds the whole
 matrix; `--scaling weak` gives every rank 1M persons, and a run with N > 1 reports that too, under `also_weak`).  `also`
 repeats the measurement at ability_dim 1 (configs[1]'s width, the reference default).  One step = one ELBO train step over the
-rank's whole person shard, replayed from hipGraphs -- TWO launches (the folded step, vibo_amd/trainer.py):
+rank's whole person shard, replayed from a hipGraph -- TWO launches (the folded step, vibo_amd/trainer.py):
 vibo_elbo_fwd_bwd_train (the row-split ELBO kernel; its own prologue forms the item sample, the item KL and the encoder
 table) and vibo_train_epilogue_fused (finalize, loss, encoder-MLP / item backward, Adam, the next step's Philox noise); with
 N > 1 the finalize stays with the first launch and ONE all-reduce of the flat [scalars | grads] buffer sits between the two
-(captured into the second graph by default, `--two-graphs` for an eager collective between the two graphs).
+(captured inside the step's graph by default, `--two-graphs` for an eager collective between two graphs).
 --torch-optimizer runs the O(I) part as PyTorch autograd + torch.optim.Adam instead.
 
 Adds to the contract line:
   roofline      the fused kernel's achieved HBM GB/s = algorithmic bytes (5 + 12A/I per term) x terms per launch
-                / its mean duration over the TIMED steps: the step is replayed as two hipGraphs (fused ELBO call | epilogue) with
-                a HIP event on the launch stream before and after the first -- events cannot be recorded inside a replayed
-                graph -- so the figure is the kernel inside the measured step, the number the committed rocprofv3
-                kernel-trace average of this command (profiles/, PROFILE_FILE) must agree with.  peak 8000 GB/s (MI355X_MICROARCH.md), also as a fraction of the 6290 GB/s measured copy ceiling;
+                / its mean duration INSIDE the replayed step: events cannot be recorded inside a replayed graph, so right after
+                the timed region the same step is replayed as two hipGraphs (fused ELBO call | epilogue) with a HIP event on the
+                launch stream before and after the first -- the kernel in the regime of the measured steps (an upper bound: the
+                event packets cost a few us), the number the committed rocprofv3 kernel-trace average of this command
+                (profiles/, PROFILE_FILE) must agree with.  peak 8000 GB/s (MI355X_MICROARCH.md), also as a fraction of the 6290 GB/s measured copy ceiling;
                 `bare_launch_ms` = the same call in a loop of bare eager launches (a note, not the claim);
                 traffic = the 2*FETCH_SIZE + WRITE_SIZE of the kernel PARSED from that profile's --pmc passes (null when the
                 file or the kernel's line is missing -- nothing is hard-coded here).
@@ -286,7 +287,6 @@ def main():
 
         graph = None
         launch_mode = 'eager'
-        halves = None            # the trainer's step as two replayed graphs with HIP events between them (see below)
 
         def step():
             if args.eval_only:
@@ -300,13 +300,12 @@ def main():
             opt.step()
             return loss.detach()
 
-        # The step is captured into hipGraphs and replayed (the eager PyTorch form of the O(I) part is ~80 tiny launches).
-        # Trainer steps (the default) are captured as their TWO halves -- forward_backward() = the fused ELBO call, update() =
-        # [the all-reduce +] the epilogue -- replayed back to back with a HIP event before and after the first: the events of
-        # the TIMED replays give the fused call's duration inside the measured step (events cannot be recorded inside a
-        # replayed graph: torch reports "external events are disallowed in rocm"), the queue never drains, and the step
-        # costs no more than as one graph (measured: 0.96 vs 1.05 ms on the same box).
+        # The step is captured into ONE hipGraph and replayed (the eager PyTorch form of the O(I) part is ~80 tiny launches; two
+        # graphs per step leave ~5 us of idle queue at every graph boundary: 154 vs 159 us on a 125 000-person shard).  The
+        # fused call's duration inside the step comes from a second capture of the same step as its two halves, replayed right
+        # after the timed region with HIP events between them (see below).
         eager_step = step
+        eager_collective = False
         if not args.no_graph:
             try:
                 side = torch.cuda.Stream()
@@ -322,55 +321,38 @@ def main():
                         g.register_generator_state(gen)
                 if opt is not None:
                     opt.zero_grad(set_to_none=False)
-                if trainer is not None:
+                eager_collective = dist is not None and trainer is not None and args.two_graphs
+                if not eager_collective:
+                    try:
+                        with torch.cuda.graph(g):
+                            static_loss = step()
+                        step = lambda: (g.replay(), static_loss)[1]
+                        launch_mode = ('one hipGraph per step' if dist is None else 'one hipGraph per step, RCCL all-reduce captured inside')
+                    except Exception as exc:
+                        if dist is None or trainer is None:
+                            raise
+                        print(f'[bench] capturing the collective failed ({type(exc).__name__}: {exc}); eager all-reduce between two graphs', file=sys.stderr)
+                        torch.cuda.synchronize()
+                        eager_collective = True
+                        g = torch.cuda.CUDAGraph()
+                if eager_collective:
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         static_raw = trainer.forward_backward(resp, mask)
-                    eager_collective = dist is not None and args.two_graphs
-                    if dist is not None and not eager_collective:
-                        try:
-                            with torch.cuda.graph(g2, pool=g.pool()):
-                                dist.all_reduce(static_raw.flat)
-                                static_loss = trainer.update()
-                        except Exception as exc:
-                            print(f'[bench] capturing the collective failed ({type(exc).__name__}: {exc}); eager all-reduce between the two graphs', file=sys.stderr)
-                            torch.cuda.synchronize()
-                            eager_collective = True
-                            g2 = torch.cuda.CUDAGraph()
-                    if dist is None or eager_collective:
-                        with torch.cuda.graph(g2, pool=g.pool()):
-                            static_loss = trainer.update()
-                    halves = {'ev': [], 'on': False}
+                    with torch.cuda.graph(g2, pool=g.pool()):
+                        static_loss = trainer.update()
 
-                    def step_halves():
-                        rec = halves['on']
-                        if rec:
-                            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 if eager_collective else 2)]
-                            ev[0].record()
+                    def step_two():
                         g.replay()
-                        if rec:
-                            ev[1].record()
-                        if eager_collective:
-                            dist.all_reduce(static_raw.flat)
-                            if rec:
-                                ev[2].record()
+                        dist.all_reduce(static_raw.flat)
                         g2.replay()
-                        if rec:
-                            halves['ev'].append(ev)
                         return static_loss
-                    step = step_halves
-                    launch_mode = ('two hipGraphs per step (fused ELBO call | epilogue), HIP events between them' if dist is None else
-                                   'two hipGraphs per step around an EAGER RCCL all-reduce' if eager_collective else
-                                   'two hipGraphs per step (fused ELBO call + finalize | captured RCCL all-reduce + epilogue), HIP events between them')
-                else:
-                    with torch.cuda.graph(g):
-                        static_loss = step()
-                    step = lambda: (g.replay(), static_loss)[1]
-                    launch_mode = 'hipGraph replay'
+                    step = step_two
+                    launch_mode = 'two hipGraphs per step around an EAGER RCCL all-reduce'
                 graph = g
             except Exception as exc:             # never lose the measurement to a capture problem
                 print(f'[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly', file=sys.stderr)
-                graph, halves = None, None
+                graph = None
                 step = eager_step
                 torch.cuda.synchronize()
 
@@ -381,8 +363,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         recording['on'] = graph is None
-        if halves is not None:
-            halves['on'] = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
@@ -392,8 +372,6 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         recording['on'] = False
-        if halves is not None:
-            halves['on'] = False
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -401,31 +379,59 @@ def main():
         final_loss = float(loss.detach())
 
         bare_ms, instep, phase_ms = None, None, None
-        if halves is not None and halves['ev']:
-            evs = halves['ev']
-            ks = [e[0].elapsed_time(e[1]) for e in evs]
-            rs = [evs[k][-1].elapsed_time(evs[k + 1][0]) for k in range(len(evs) - 1)] or [0.0]
-            instep = {'mean_ms': sum(ks) / len(ks), 'min_ms': min(ks), 'max_ms': max(ks), 'replays': len(ks),
-                      'epilogue_half_ms': sum(rs) / len(rs),
-                      'note': 'HIP events of the TIMED replays: before and after the first of the step\'s two graphs (the fused ELBO call); '
-                              'epilogue_half_ms = from there to the next step\'s first event'}
-            if dist is not None:
-                cols = [instep['mean_ms'], instep['epilogue_half_ms']]
-                if len(evs[0]) == 3:
-                    cols.append(sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs))
-                ph = torch.tensor(cols, device=dev, dtype=torch.float64)
-                dist.all_reduce(ph, op=dist.ReduceOp.MAX)
-                phase_ms = {'forward_backward_graph': float(ph[0]),
-                            'note': 'max over ranks of the mean over the timed replays, HIP events on the launch stream; forward_backward_graph = '
-                                    'fused ELBO kernel (own prologue) + finalize'}
-                if len(cols) == 3:
-                    phase_ms['all_reduce'] = float(ph[2])
-                    phase_ms['update_graph'] = float(ph[1])
-                    phase_ms['note'] += ', all_reduce = the eager collective, update_graph = epilogue + Adam + next noise (to the next step\'s start)'
-                else:
-                    phase_ms['all_reduce_and_update_graph'] = float(ph[1])
-                    phase_ms['note'] += ', all_reduce_and_update_graph = captured all-reduce + epilogue + Adam + next noise (to the next step\'s start)'
-                instep['mean_ms'] = float(ph[0])
+        if graph is not None and trainer is not None:
+            # The fused call's duration INSIDE the replayed step.  Events cannot be recorded inside a replayed graph (torch:
+            # "external events are disallowed in rocm"), so the same step is captured once more as its two halves --
+            # forward_backward() = the fused ELBO call (+ finalize when sharded), update() = [all-reduce +] epilogue -- and the
+            # halves are replayed back to back, right after the timed region, with a HIP event on the launch stream before and
+            # after the first: the queue never drains and the kernel runs in the regime of the timed steps.  The two event
+            # packets and the extra graph boundary cost the step ~10 us (measured: 169 vs 159 vs 154 us per step on a
+            # 125 000-person shard), a few of which fall between the events: the figure is an upper bound of the kernel's
+            # own duration (+ <= 1 % at 1M persons); the committed rocprofv3 trace has the kernel alone.
+            try:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=graph.pool()):
+                    raw_s = trainer.forward_backward(resp, mask)
+                with torch.cuda.graph(gb, pool=graph.pool()):
+                    if dist is not None and not eager_collective:
+                        dist.all_reduce(raw_s.flat)
+                    trainer.update()
+                n_ev = max(10, min(args.steps, 50))
+                evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3 if eager_collective else 2)] for _ in range(n_ev + 3)]
+                for ev in evs:
+                    ev[0].record(); ga.replay(); ev[1].record()
+                    if eager_collective:
+                        dist.all_reduce(raw_s.flat); ev[2].record()
+                    gb.replay()
+                torch.cuda.synchronize()
+                evs = evs[3:]
+                ks = [e[0].elapsed_time(e[1]) for e in evs]
+                rs = [evs[k][-1].elapsed_time(evs[k + 1][0]) for k in range(len(evs) - 1)]
+                instep = {'mean_ms': sum(ks) / len(ks), 'min_ms': min(ks), 'max_ms': max(ks), 'replays': len(ks),
+                          'epilogue_half_ms': sum(rs) / len(rs),
+                          'note': 'HIP events before and after the first of the step\'s two halves (the fused ELBO call), replayed back to '
+                                  'back right after the timed region; epilogue_half_ms = from there to the next step\'s first event'}
+                if dist is not None:
+                    cols = [instep['mean_ms'], instep['epilogue_half_ms']]
+                    if eager_collective:
+                        cols.append(sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs))
+                    ph = torch.tensor(cols, device=dev, dtype=torch.float64)
+                    dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+                    phase_ms = {'forward_backward_graph': float(ph[0]),
+                                'note': 'max over ranks of the mean over the replays of the step captured as two halves (HIP events on the launch '
+                                        'stream between them; each event costs a few us of its own); forward_backward_graph = fused ELBO kernel + finalize'}
+                    if eager_collective:
+                        phase_ms['all_reduce'] = float(ph[2])
+                        phase_ms['update_graph'] = float(ph[1])
+                        phase_ms['note'] += ', all_reduce = the eager collective, update_graph = epilogue + Adam + next step\'s head (to the next step\'s start)'
+                    else:
+                        phase_ms['all_reduce_and_update_graph'] = float(ph[1])
+                        phase_ms['note'] += ', all_reduce_and_update_graph = captured all-reduce + epilogue + Adam + next step\'s head (to the next step\'s start)'
+                    instep['mean_ms'] = float(ph[0])
+            except Exception as exc:
+                print(f'[bench] in-step kernel timing failed ({type(exc).__name__}: {exc})', file=sys.stderr)
+                torch.cuda.synchronize()
+                instep = None
         if graph is not None and instep is None:
             # (--torch-optimizer / --eval-only: the native call timed in an eager pass of the same step right after the timed region)
             recording['on'] = True
@@ -698,8 +704,9 @@ def main():
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
                          # the same bytes over the whole timed step (kernel with its prologue, [finalize, all-reduce], epilogue + Adam + noise)
                          'frac_step': bytes_per_term * P * I / (dt / args.steps) / 1e9 / 8000.0,
-                         'frac_note': ('frac = algorithmic bytes / the fused call\'s mean duration over the TIMED steps: HIP events on the launch '
-                                       'stream before and after the first of the step\'s two replayed graphs (kernel_timing has mean / min / max'
+                         'frac_note': ('frac = algorithmic bytes / the fused call\'s mean duration INSIDE the replayed step: the step captured as its two '
+                                       'halves and replayed back to back right after the timed region, HIP events on the launch stream around the first '
+                                       '(an upper bound: the event packets cost a few us; kernel_timing has mean / min / max'
                                        + (', mean = max over ranks' if world > 1 else '') + '); '
                                        if m.get('instep') else
                                        'frac = algorithmic bytes / mean duration of the fused call by HIP events on its stream (eager pass after the timed region); ')

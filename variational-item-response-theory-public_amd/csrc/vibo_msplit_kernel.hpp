@@ -153,6 +153,126 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int n4 = (I + 3) >> 2;
     const int i16 = lane & 15, g = lane >> 4;
 
+    const int ed = lane & 7;
+    // (the planner keeps num_person <= 2^31 - 2^16: row numbers and batch counters are 32-bit)
+    const int n_batches = (int)(((long long)p.B + R - 1) / R);
+    float4 x[CODES ? 1 : 8];                        // [2 j + u]: person j of the half, chunk u
+    uint32_t m[8];
+    int ridx[8];
+    auto fetch_idx = [&](const int bt) {
+        if constexpr (RM != 0) {
+            if (!p.row_index) return;
+            const int row0 = bt * R;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = row0 + 4 * g + (k & 3) + 16 * (k >> 2);
+                const int rc = min(row, p.B - 1);
+                ridx[k] = bt < n_batches ? (int)p.row_index[rc] : 0;
+            }
+        }
+    };
+    // Row loads.  The unit is a "half": the lane's 4 persons of one M-tile x BOTH chunks of the wave's item span, so
+    // that a wave asks for 512 contiguous bytes of a response row (128 of its mask row) back to back and neighbouring
+    // waves touch a row at the same time: segment-edge cache lines are fetched once (units of 32 rows x 64 items left them
+    // to be re-fetched half a batch later: 1.34x the algorithmic HBM traffic).
+    // In-order rows go through buffer loads: one resource per batch (scalar registers) whose record limit ends at the last
+    // row of the matrix (rows past the end read as zeros), per-lane offsets shared by all rows of the lane and the row step
+    // as a scalar offset -- no per-row address registers, and no branch in the load sequence: without a mask the mask
+    // resource has no records (its loads return zeros) and the cells are switched on when they are packed (`fillw`).
+    // Gathered rows compute their addresses at the load.  Chunks past the row's end read its last chunk; both cases are
+    // masked when the cells are packed.
+    const int cc0 = min(32 * q + i16, n4 - 1), cc1 = min(32 * q + 16 + i16, n4 - 1);
+    const unsigned rstride4 = (unsigned)p.resp_stride * 4u, mstride = (unsigned)p.mask_stride;      // bytes per row
+    const unsigned mvo0 = 4u * g * mstride + 4u * cc0, mvo1 = 4u * g * mstride + 4u * cc1;
+    const unsigned rvo0 = 4u * g * rstride4 + 16u * cc0, rvo1 = 4u * g * rstride4 + 16u * cc1;
+    const bool have_mask = CODES || p.mask_dtype == 0;        // (wave-uniform)
+    const uint32_t fillw = have_mask ? 0u : 0x01010101u;
+    struct RowSrc { __amdgpu_buffer_rsrc_t r, m; };
+    auto row_src = [&](const int bt) {
+        const int rows = min(p.B - bt * R, R);                // rows of this batch (<= 0 past the last batch: no records)
+        const unsigned br = rows > 0 ? (unsigned)(rows - 1) * rstride4 + 16u * n4 : 0u;
+        const unsigned bm = (rows > 0 && have_mask) ? (unsigned)(rows - 1) * mstride + 4u * n4 : 0u;
+        RowSrc rs;
+        rs.m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(static_cast<const uint8_t*>(p.mask) + (size_t)bt * R * p.mask_stride + p.item0),
+                                                 (short)0, (int)bm, 0x00020000);
+        if constexpr (!CODES) rs.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.response + (size_t)bt * R * p.resp_stride + p.item0),
+                                                                       (short)0, (int)br, 0x00020000);
+        else rs.r = rs.m;
+        return rs;
+    };
+    // quarter (h, j) = person 4 h + j of the lane (row 4 g + j + 16 h of the batch), both chunks: 2 x 16 B + 2 x 4 B
+    auto load_quarter = [&](const int bt, const RowSrc& rs, const int h, const int j) {
+        bool linear = RM == 0;
+        if constexpr (RM == 2) linear = p.row_index == nullptr;
+        if (linear) {
+            const int mso = (j + 16 * h) * (int)mstride;
+            m[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo0, mso, 0);
+            m[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo1, mso, 0);
+            if constexpr (!CODES) {
+                const int so = (j + 16 * h) * (int)rstride4;
+                x[2 * j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo0, so, 0));
+                x[2 * j + 1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo1, so, 0));
+            }
+        } else {
+            if (bt >= n_batches) return;
+            const long long src = (long long)ridx[4 * h + j];
+            if constexpr (CODES) {
+                const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
+                m[2 * j] = mp[cc0];
+                m[2 * j + 1] = mp[cc1];
+            } else {
+                const float4* rp = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0);
+                x[2 * j] = rp[cc0];
+                x[2 * j + 1] = rp[cc1];
+                if (p.mask_dtype == 0) {
+                    const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
+                    m[2 * j] = mp[cc0];
+                    m[2 * j + 1] = mp[cc1];
+                } else {
+                    m[2 * j] = m[2 * j + 1] = 0u;
+                }
+            }
+        }
+    };
+    constexpr bool kPrs = RM == 2;
+    float prs0 = 0.f, prs1 = 0.f, prs2 = 0.f;
+    // slots of this wave for a batch: [s0, s1) in steps of `step` (one slot at most with 4 or more waves)
+    auto my_slots = [&](const int par, int& s0, int& s1, int& step) {
+        if (NW8 || nw == 8) {
+            s0 = q - 4 * par; s1 = s0 + 1; step = 1;
+            if (s0 < 0 || s0 > 3) s1 = s0 = 0;
+        } else {
+            s0 = q; s1 = 4; step = nw;
+        }
+    };
+    float epn = 0.f;                                  // eps of this wave's slot of the next batch (4 or more waves), loaded a batch ahead
+    auto fetch_eps = [&](const int bt, const int par) {
+        if ((!NW8 && nw < 4) || bt >= n_batches) return;
+        int s0, s1, step;
+        my_slots(par, s0, s1, step);
+        if (s0 < s1) {
+            const int row = bt * R + ((64 * s0 + lane) >> 3);
+            epn = (ed < A && row < p.B) ? p.eps[(long long)row * A + ed] : 0.f;
+            if constexpr (EXTRA && kPrs) {
+                if (p.pre_stats && p.pre_panels == 1) {
+                    const bool lv = ed < A && row < p.B;
+                    const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
+                    prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
+                }
+            }
+        }
+    };
+    // ---- the first batch's rows (M-tile 0) and noise are requested before anything else: their HBM / TLB latency (the first
+    //      touch of this workgroup's pages) runs under the operand-image build below instead of after it
+    int bt = (int)blockIdx.x;
+    const RowSrc src_first = row_src(bt);
+    if (bt < n_batches) {
+        fetch_idx(bt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_quarter(bt, src_first, 0, j);
+        fetch_eps(bt, 0);
+    }
+
     auto put_ctab = [&](const float* table) {
         if (tid < 16) {
             const int c = tid >> 3, a = tid & 7;
@@ -301,92 +421,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     float s_log = 0.f;
     int unobs = 0;
     __syncthreads();
-    const int ed = lane & 7;
 
     // LDS image offsets (halfs): producer row 16 t + i16, piece g; consumer rows 32 kt + 4 g + (i16 >> 2) (+ 16), piece i16 & 3
     const int wofs = 16 * i16 + 4 * (g ^ (i16 >> 2));
     const int rofs = 64 * g + 16 * (i16 >> 2) + 4 * ((i16 & 3) ^ g);
 
-    // (the planner keeps num_person <= 2^31 - 2^16: row numbers and batch counters are 32-bit)
-    const int n_batches = (int)(((long long)p.B + R - 1) / R);
-    float4 x[CODES ? 1 : 8];                        // [2 j + u]: person j of the half, chunk u
-    uint32_t m[8];
-    int ridx[8];
-    auto fetch_idx = [&](const int bt) {
-        if constexpr (RM != 0) {
-            if (!p.row_index) return;
-            const int row0 = bt * R;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int row = row0 + 4 * g + (k & 3) + 16 * (k >> 2);
-                const int rc = min(row, p.B - 1);
-                ridx[k] = bt < n_batches ? (int)p.row_index[rc] : 0;
-            }
-        }
-    };
-    // Row loads.  The unit is a "half": the lane's 4 persons of one M-tile x BOTH chunks of the wave's item span, so
-    // that a wave asks for 512 contiguous bytes of a response row (128 of its mask row) back to back and neighbouring
-    // waves touch a row at the same time: segment-edge cache lines are fetched once (units of 32 rows x 64 items left them
-    // to be re-fetched half a batch later: 1.34x the algorithmic HBM traffic).
-    // In-order rows go through buffer loads: one resource per batch (scalar registers) whose record limit ends at the last
-    // row of the matrix (rows past the end read as zeros), per-lane offsets shared by all rows of the lane and the row step
-    // as a scalar offset -- no per-row address registers, and no branch in the load sequence: without a mask the mask
-    // resource has no records (its loads return zeros) and the cells are switched on when they are packed (`fillw`).
-    // Gathered rows compute their addresses at the load.  Chunks past the row's end read its last chunk; both cases are
-    // masked when the cells are packed.
-    const int cc0 = min(32 * q + i16, n4 - 1), cc1 = min(32 * q + 16 + i16, n4 - 1);
-    const unsigned rstride4 = (unsigned)p.resp_stride * 4u, mstride = (unsigned)p.mask_stride;      // bytes per row
-    const unsigned mvo0 = 4u * g * mstride + 4u * cc0, mvo1 = 4u * g * mstride + 4u * cc1;
-    const unsigned rvo0 = 4u * g * rstride4 + 16u * cc0, rvo1 = 4u * g * rstride4 + 16u * cc1;
-    const bool have_mask = CODES || p.mask_dtype == 0;        // (wave-uniform)
-    const uint32_t fillw = have_mask ? 0u : 0x01010101u;
-    struct RowSrc { __amdgpu_buffer_rsrc_t r, m; };
-    auto row_src = [&](const int bt) {
-        const int rows = min(p.B - bt * R, R);                // rows of this batch (<= 0 past the last batch: no records)
-        const unsigned br = rows > 0 ? (unsigned)(rows - 1) * rstride4 + 16u * n4 : 0u;
-        const unsigned bm = (rows > 0 && have_mask) ? (unsigned)(rows - 1) * mstride + 4u * n4 : 0u;
-        RowSrc rs;
-        rs.m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(static_cast<const uint8_t*>(p.mask) + (size_t)bt * R * p.mask_stride + p.item0),
-                                                 (short)0, (int)bm, 0x00020000);
-        if constexpr (!CODES) rs.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.response + (size_t)bt * R * p.resp_stride + p.item0),
-                                                                       (short)0, (int)br, 0x00020000);
-        else rs.r = rs.m;
-        return rs;
-    };
-    // quarter (h, j) = person 4 h + j of the lane (row 4 g + j + 16 h of the batch), both chunks: 2 x 16 B + 2 x 4 B
-    auto load_quarter = [&](const int bt, const RowSrc& rs, const int h, const int j) {
-        bool linear = RM == 0;
-        if constexpr (RM == 2) linear = p.row_index == nullptr;
-        if (linear) {
-            const int mso = (j + 16 * h) * (int)mstride;
-            m[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo0, mso, 0);
-            m[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs.m, mvo1, mso, 0);
-            if constexpr (!CODES) {
-                const int so = (j + 16 * h) * (int)rstride4;
-                x[2 * j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo0, so, 0));
-                x[2 * j + 1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs.r, rvo1, so, 0));
-            }
-        } else {
-            if (bt >= n_batches) return;
-            const long long src = (long long)ridx[4 * h + j];
-            if constexpr (CODES) {
-                const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
-                m[2 * j] = mp[cc0];
-                m[2 * j + 1] = mp[cc1];
-            } else {
-                const float4* rp = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0);
-                x[2 * j] = rp[cc0];
-                x[2 * j + 1] = rp[cc1];
-                if (p.mask_dtype == 0) {
-                    const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
-                    m[2 * j] = mp[cc0];
-                    m[2 * j + 1] = mp[cc1];
-                } else {
-                    m[2 * j] = m[2 * j + 1] = 0u;
-                }
-            }
-        }
-    };
     // pack a quarter: the code words of person 4 h + j for both u-steps and its counts
     const uint32_t tm_tail = (I & 3) ? ((1u << (8 * (I & 3))) - 1u) : 0xFFFFFFFFu;
     const uint32_t tm0 = (32 * q + i16) >= n4 ? 0u : ((I & 3) && (32 * q + i16) == (I >> 2)) ? tm_tail : 0xFFFFFFFFu;
@@ -459,8 +498,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // hipcc guard the register with an s_waitcnt vmcnt(0) -- behind the row loads that are in flight across the sync phase.
     // (on cell codes, RM == 2, the single-panel statistics of the conditional / given posterior come a batch ahead with
     //  eps -- prs -- and the plain variant serves them: the conditional posterior's matrix pass runs on emitted codes)
-    constexpr bool kPrs = RM == 2;
-    float prs0 = 0.f, prs1 = 0.f, prs2 = 0.f;
     // prior experts of the missing cells (models.py:613-620): weight 1 / (1 + eps) each, or dropped
     const float prior_w = p.missing_mode == 0 ? 1.0f / (1.0f + kPoeEps) : 0.f;
     const bool primary = EXTRA ? p.primary != 0 : true;
@@ -672,32 +709,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) lds_add(&cl.tacc[par][k][e], dt[k]);      // (one lane per address: order is program order)
-    };
-    // slots of this wave for a batch: [s0, s1) in steps of `step` (one slot at most with 4 or more waves)
-    auto my_slots = [&](const int par, int& s0, int& s1, int& step) {
-        if (NW8 || nw == 8) {
-            s0 = q - 4 * par; s1 = s0 + 1; step = 1;
-            if (s0 < 0 || s0 > 3) s1 = s0 = 0;
-        } else {
-            s0 = q; s1 = 4; step = nw;
-        }
-    };
-    float epn = 0.f;                                  // eps of this wave's slot of the next batch (4 or more waves), loaded a batch ahead
-    auto fetch_eps = [&](const int bt, const int par) {
-        if ((!NW8 && nw < 4) || bt >= n_batches) return;
-        int s0, s1, step;
-        my_slots(par, s0, s1, step);
-        if (s0 < s1) {
-            const int row = bt * R + ((64 * s0 + lane) >> 3);
-            epn = (ed < A && row < p.B) ? p.eps[(long long)row * A + ed] : 0.f;
-            if constexpr (EXTRA && kPrs) {
-                if (p.pre_stats && p.pre_panels == 1) {
-                    const bool lv = ed < A && row < p.B;
-                    const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
-                    prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
-                }
-            }
-        }
     };
     auto person_forward = [&](const int bt, const int par) {
         int s0, s1, step;
@@ -941,25 +952,17 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     };
 
     // ================= prologue: first batch =================
-    int bt = (int)blockIdx.x;
     uint32_t cwA0[8], cwA1[8], cwB0[8], cwB1[8];
     int pk[4];
     const int G = (int)gridDim.x;
     if (bt < n_batches) {
-        fetch_idx(bt);
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = 0;
-        {
-            const RowSrc s0 = row_src(bt);
+        pack_half(bt, 0, cwA0, cwA1, pk);             // (M-tile 0 was requested at the top of the kernel)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) load_quarter(bt, s0, h, j);
-                pack_half(bt, h, cwA0, cwA1, pk);
-            }
-        }
+        for (int j = 0; j < 4; ++j) load_quarter(bt, src_first, 1, j);
+        pack_half(bt, 1, cwA0, cwA1, pk);
         put_counts(pk, true);
-        fetch_eps(bt, 0);
         asm volatile("" : "+v"(epn));                 // (in before the loop: no wait on it behind the loop's own loads)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
     }
@@ -1078,12 +1081,17 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         out[4] = la; out[6] = 0.f; out[7] = 0.f;
     }
-    if (tid < 4) {                            // sums of the (person, dim) pairs' running terms, fixed order
-        const int k = 8 + tid;
-        float t = 0.f;
+    // sums of the (person, dim) pairs' running terms, fixed order: wave w takes term 8 + w (, 8 + w + nw, ...) -- every lane its
+    // eight values, then the wave total (one thread per term walked 512 LDS values in a row: ~10 k cycles at the end of
+    // every workgroup)
+    for (int k = 8 + q; k < 12; k += nw) {
+        float v = 0.f;
+#pragma unroll
         for (int par2 = 0; par2 < 2; ++par2)
-            for (int e = 0; e < 256; ++e) t += cl.tacc[par2][k][e];
-        out[k == 8 ? 1 : k == 9 ? 2 : k == 10 ? 3 : 5] = t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v += cl.tacc[par2][k][lane + 64 * j];
+        const float t = wave_total(v);
+        if (lane == 0) out[k == 8 ? 1 : k == 9 ? 2 : k == 10 ? 3 : 5] = t;
     }
     if constexpr (GRAD) {
         if (tid < 8 * A) {
