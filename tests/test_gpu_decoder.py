@@ -33,12 +33,14 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize('mode,B,I,missing', [('deep', 37, 130, 0.2), ('residual', 16, 64, 0.0), ('link', 33, 95, 0.3),
-                                             ('residual3', 50, 200, 0.1), ('link3', 7, 20, 0.0), ('deep', 300, 1000, 0.1)])
-def test_decoder_kernel_matches_float64_autograd(mode, B, I, missing):
+@pytest.mark.parametrize('mode,B,I,missing,H', [('deep', 37, 130, 0.2, 64), ('residual', 16, 64, 0.0, 64), ('link', 33, 95, 0.3, 64),
+                                               ('residual3', 50, 200, 0.1, 64), ('link3', 7, 20, 0.0, 64), ('deep', 300, 1000, 0.1, 64),
+                                               # --hidden-dim below 64 (vibo.py:72; models.py:771-781, 815-846): the same kernel on
+                                               # zero-padded weights, the padding sliced off the gradients again
+                                               ('deep', 37, 130, 0.2, 32), ('link3', 21, 95, 0.1, 16), ('residual', 40, 64, 0.2, 48)])
+def test_decoder_kernel_matches_float64_autograd(mode, B, I, missing, H):
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(B * 1000 + I)
-    H = 64
     rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).double()
     resp = (torch.rand(B, I, generator=g) < 0.5).double()
     mask = (torch.rand(B, I, generator=g) >= missing).double() if missing > 0 else None
@@ -154,3 +156,39 @@ def test_decoder_kernel_on_the_references_saturation_probe():
         # (the reference's own fp32 value is quantised through 1 - P for logits of 12..16 -- up to 5e-4 per cell; the kernel forms
         #  1 - P without that cancellation, so the sums agree to 1e-4, not to rounding)
         assert abs(float(ll.detach()) - float(ref_ll.sum())) < 1e-4 * abs(float(ref_ll.sum()))
+
+
+@pytest.mark.parametrize('A,I,B,prior,codes', [(2, 95, 77, True, False), (8, 1000, 300, True, True), (3, 260, 64, False, False)])
+def test_decoder_models_conditional_posterior_runs_on_the_code_table_sum_kernels(A, I, B, prior, codes):
+    """--conditional-posterior with an MLP decoder (models.py:695-710 product of experts, utils.py:105-113): the experts'
+    per-person sums come from vibo_code_table_sum_forward / _backward (one-hot x [tau | mu tau] on the matrix pipe) instead of a
+    gathered [B, I, 2A] tensor -- posterior and the gradients that reach the encoder MLP and the item sample against the
+    dense float64 statement of the same product."""
+    from oracle import vibo_oracle as O
+    from vibo_amd import ops
+    from vibo_amd.torch_core.models import VIBO_2PL
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(A * 100 + I)
+    resp, mask = O.simulate_responses(2, B, I, A, generator=g, missing_frac=0.2)
+    torch.manual_seed(3)
+    model = VIBO_2PL(A, I, ability_merge='product', conditional_posterior=True, generative_model='deep', replace_missing_with_prior=prior).to(dev)
+    item_feat = torch.randn(I, A + 1, generator=g).to(dev).requires_grad_(True)
+    r_in, m_in = (ops.pack_cell_codes(resp.to(dev), mask.bool().to(dev)), None) if codes else (resp.to(dev), mask.bool().to(dev))
+    amu, alv = model._conditional_posterior_poe(r_in, m_in, None, item_feat)
+    w = torch.randn(B, 2 * A, generator=g).to(dev)
+    (torch.cat([amu, alv], 1) * w).sum().backward()
+    got = [item_feat.grad.double().cpu()] + [p.grad.double().cpu() for p in model.ability_encoder.parameters()]
+    # dense float64 reference
+    m64 = __import__('copy').deepcopy(model).double()
+    it64 = item_feat.detach().double().requires_grad_(True)
+    table = m64.ability_encoder.expert_table(it64)                          # [2, I, 2A]
+    r, m = resp.to(dev).double(), mask.to(dev).double()
+    sel = table[(r == 1).long(), torch.arange(I, device=dev)]               # [B, I, 2A]
+    tau = m.unsqueeze(2) / (torch.exp(sel[..., A:]) + 1e-8)
+    lam = tau.sum(1) + ((I - m.sum(1, keepdim=True)) * (1.0 / (1.0 + 1e-8)) if prior else 0.0)
+    amu_r, alv_r = (sel[..., :A] * tau).sum(1) / lam, torch.log(1.0 / lam)
+    (torch.cat([amu_r, alv_r], 1) * w.double()).sum().backward()
+    ref = [it64.grad.cpu()] + [p.grad.cpu() for p in m64.ability_encoder.parameters()]
+    assert (amu.detach().double() - amu_r.detach()).abs().max() < 2e-5 and (alv.detach().double() - alv_r.detach()).abs().max() < 2e-5
+    for a_, b_ in zip(got, ref):
+        assert rel(a_, b_) < 2e-4

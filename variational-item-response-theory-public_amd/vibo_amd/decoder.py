@@ -11,6 +11,7 @@ import ctypes
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib, ops
 
@@ -125,10 +126,26 @@ def _rows(response, mask):
     return response.float(), mask
 
 
+def _pad_hidden(U, V, W2, b2, w3, w1):
+    """The kernel's per-term network is 64 units wide.  A narrower one (--hidden-dim < 64) is the same network with its extra
+    units switched off: zero rows / columns give z1 = 0 -> elu(0) = 0 -> no contribution to the second layer, whose padded
+    units see a zero bias and a zero output weight -- exact, and autograd slices the padding off the gradients again."""
+    H = W2.shape[0]
+    if H == HIDDEN:
+        return U, V, W2, b2, w3, w1
+    if H > HIDDEN:
+        raise NotImplementedError(f'hidden_dim = {H}: the per-term decoder kernel covers hidden widths up to {HIDDEN} '
+                                  '(its 64 x 64 weight-gradient tile lives in registers)')
+    k = HIDDEN - H
+    pad1 = lambda t: None if t is None else F.pad(t, (0, k))
+    return pad1(U), pad1(V), F.pad(W2, (0, k, 0, k)), pad1(b2), pad1(w3), pad1(w1)
+
+
 def decoder_log_lik(response, mask, *, U, V, W2, b2, w3, b3, logit=None, w1=None, guess=None, resid=0.0):
     """sum_{p,i} mask * log Bernoulli(response | P) of the per-term network (see the module docstring); differentiable in
     every tensor argument but response / mask.  response [B, I(, 1)] fp32, mask [B, I(, 1)] bool/u8 or None."""
     response, mask = _rows(response, mask)
+    U, V, W2, b2, w3, w1 = _pad_hidden(U, V, W2, b2, w3, w1)
     want_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (U, V, logit, guess, w1, W2, b2, w3, b3))
     return _DecoderLogLik.apply(response, mask, float(resid), want_grad, U, V, logit, guess, w1, W2, b2, w3, b3)
 
@@ -136,6 +153,7 @@ def decoder_log_lik(response, mask, *, U, V, W2, b2, w3, b3, logit=None, w1=None
 @torch.no_grad()
 def decoder_probs(B, I, *, U, V, W2, b2, w3, b3, logit=None, w1=None, guess=None, resid=0.0):
     """P(response = 1) [B, I] of the per-term network (decode(): models.py:373-378 with a non-IRT generative model)."""
+    U, V, W2, b2, w3, w1 = _pad_hidden(U, V, W2, b2, w3, w1)
     Up, Vp, Lp, gp, w1p, W2p, b2p, w3p, b3p = (_prep(t) for t in (U, V, logit, guess, w1, W2, b2, w3, b3))
     outs = []
     for s in range(0, B, PERSON_CHUNK):
@@ -175,8 +193,8 @@ class LinkedIRT(nn.Module):
 
     def __init__(self, irt_model=1, hidden_dim=HIDDEN):
         super().__init__()
-        if hidden_dim != HIDDEN:
-            raise NotImplementedError('the per-term decoder kernel is built for hidden_dim = 64')
+        if hidden_dim > HIDDEN:
+            raise NotImplementedError(f'hidden_dim = {hidden_dim}: the per-term decoder kernel covers hidden widths up to {HIDDEN}')
         self.irt_model, self.hidden_dim = irt_model, hidden_dim
         self.link = _mlp3(1, hidden_dim, 1, nn.Sigmoid())
         self.apply(_xavier)
@@ -201,8 +219,8 @@ class DeepIRT(nn.Module):
 
     def __init__(self, latent_dim, irt_model=1, hidden_dim=HIDDEN):
         super().__init__()
-        if hidden_dim != HIDDEN:
-            raise NotImplementedError('the per-term decoder kernel is built for hidden_dim = 64')
+        if hidden_dim > HIDDEN:
+            raise NotImplementedError(f'hidden_dim = {hidden_dim}: the per-term decoder kernel covers hidden widths up to {HIDDEN}')
         self.latent_dim = self.ability_dim = latent_dim
         self.irt_model, self.hidden_dim = irt_model, hidden_dim
         self.item_feat_dim = {1: 1, 2: latent_dim + 1, 3: latent_dim + 2}[irt_model]

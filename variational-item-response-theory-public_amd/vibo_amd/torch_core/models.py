@@ -433,31 +433,25 @@ class VIBO_1PL(nn.Module):
             lam = lam + (self.num_item - nobs) * (1.0 / (1.0 + 1e-8))
         return smu / lam, torch.log(1.0 / lam)
 
-    def _dense_rows(self, response, mask, row_index):
-        """(response fp32 [B, I], mask u8 [B, I] or None) of the minibatch as dense tensors."""
-        if isinstance(response, ops.CellCodes):
-            return (response.rows(row_index) if row_index is not None else response).unpack()
-        r = ops.prepare_response(response)
-        m = None if mask is None else ops.prepare_mask(mask)[0]
-        if row_index is not None:
-            r, m = r[row_index], (None if m is None else m[row_index])
-        return r, m
+    def _conditional_posterior_poe(self, response, mask, row_index, item_feat):
+        """Product of experts of the conditional encoder (models.py:695-710, utils.py:105-113) for the MLP-decoder models, where
+        the ability gradient does not come out of the fused ELBO kernel.  The experts' per-person sums
 
-    def _conditional_posterior_dense(self, response, mask, row_index, item_feat):
-        """Product of experts of the conditional encoder (models.py:695-710, utils.py:105-113) for the MLP-decoder models,
-        where the ability gradient does not come out of the fused ELBO kernel: the 2 x I-row expert table is gathered by
-        the rows' codes ([B, I, 2A], a minibatch-sized tensor) and reduced with autograd -- plain tensor ops, not a fused path."""
-        A = self.ability_dim
-        r, m = self._dense_rows(response, mask, row_index)
+            [lam | s][p, :] = sum_i [cell (p, i) observed] [tau | mu tau][code_pi, i, :]      = onehot(codes) [B, 2I] x X [2I, 2A]
+
+        are the one-hot x table contraction of csrc/vibo_cmean.hip, straight from the minibatch's cell codes on the matrix pipe
+        (ops.CodeTableSumFn: vibo_code_table_sum_forward, and its transpose vibo_code_table_sum_backward for the gradient that
+        reaches the 2 x I-row expert table -- and through it the encoder MLP and the item sample); X is 2 x I x 2A numbers
+        of plain autograd.  The kernels' table width is 64 columns: the 2A <= 16 used ones are padded with zeros."""
+        A, I = self.ability_dim, item_feat.shape[0]
         table = self.ability_encoder.expert_table(item_feat)                  # [2, I, 2A]
-        sel = table[(r == 1).long(), torch.arange(r.shape[1], device=r.device)]      # [B, I, 2A]
-        mu_set, lv_set = sel[..., :A], sel[..., A:]
-        obs = torch.ones_like(r) if m is None else (m != 0).to(r.dtype)
-        tau = obs.unsqueeze(2) / (torch.exp(lv_set) + 1e-8)
-        lam = tau.sum(1)
+        tau = 1.0 / (torch.exp(table[..., A:]) + 1e-8)
+        feature = torch.cat([tau, table[..., :A] * tau, table.new_zeros(2, I, 64 - 2 * A)], dim=2)      # [2, I, 64]
+        sums, nobs = ops._BACKEND['cond_mean_sum'](feature, response, mask, row_index)                  # [B, 64], [B]
+        lam, smu = sums[:, :A], sums[:, A:2 * A]
         if self.replace_missing_with_prior:
-            lam = lam + (r.shape[1] - obs.sum(1, keepdim=True)) * (1.0 / (1.0 + 1e-8))
-        return (mu_set * tau).sum(1) / lam, torch.log(1.0 / lam)
+            lam = lam + (I - nobs.unsqueeze(1)) * (1.0 / (1.0 + 1e-8))
+        return smu / lam, torch.log(1.0 / lam)
 
     def _run_decoder(self, response, mask, *, eps_item=None, eps_ability=None, row_index=None):
         """forward() with a per-term MLP decoder: item sample, posterior from the row counts, sample, flows."""
@@ -467,7 +461,7 @@ class VIBO_1PL(nn.Module):
             counts = None if self.conditional_posterior else ops.row_counts(response, mask, row_index)
             amu, alv = torch.chunk(self._mean_posterior(response, mask, row_index, item_feat, counts, reduce_in_backward=False), 2, dim=1)
         elif self.conditional_posterior:
-            amu, alv = self._conditional_posterior_dense(response, mask, row_index, item_feat)
+            amu, alv = self._conditional_posterior_poe(response, mask, row_index, item_feat)
         else:
             amu, alv = self._posterior_from_counts(ops.row_counts(response, mask, row_index))
         if eps_ability is None:
