@@ -54,7 +54,10 @@ enum { VIBO_REG_KL = 0,          /* elbo(use_kl_divergence=True): analytic KL (m
        VIBO_REG_SAMPLED = 1 };   /* use_kl_divergence=False / flows: log q - log p at the sample
                                     (models.py:406-424, 432-441)                             */
 
-#define VIBO_MAX_ABILITY_DIM 8
+#define VIBO_MAX_ABILITY_DIM 8          /* every row-split / matrix-pipe / trainer path */
+#define VIBO_MAX_ABILITY_DIM_WIDE 16    /* vibo_elbo_fwd_bwd / vibo_encode / vibo_decode[_mean]: ability_dim 9..16 run on the
+                                           wave-per-person kernel (fp32 rows, u8 / int64 / no mask; atomically reduced: not
+                                           bitwise reproducible, ~30x below the row-split kernels) */
 #define VIBO_MAX_FLOWS 8
 #define VIBO_NUM_SCALARS 8
 /* indices into out_scalars */
@@ -73,7 +76,7 @@ typedef struct vibo_desc {
     int32_t abi_version;      /* VIBO_ABI_VERSION */
     int32_t num_person;       /* B: rows processed by this call */
     int32_t num_item;         /* I */
-    int32_t ability_dim;      /* A, 1..VIBO_MAX_ABILITY_DIM                         */
+    int32_t ability_dim;      /* A, 1..VIBO_MAX_ABILITY_DIM_WIDE (9..16: see above)  */
     int32_t irt_model;        /* VIBO_IRT_*; item_feat_dim D = 1 | A+1 | A+2        */
     int32_t posterior;        /* VIBO_POSTERIOR_*                                    */
     int32_t missing_mode;     /* VIBO_MISSING_*                                      */
@@ -427,7 +430,7 @@ int vibo_elbo_multi_forward(const vibo_desc* d, int num_samples, const float* re
  * A stack of planar flows on the rows of z [n_rows][dim] (PlanarFlow.forward / NormalizingFlows.forward, flows.py:21-41,
  * 58-66; the item-side stack of models.py:342-348 and the ability-side stack of the MLP-decoder models):
  *     z <- z + uhat_k tanh(w_k . z + b_k),   ladj[row] = sum_k log(|1 + (1 - tanh^2)(w_k . uhat_k)| + 1e-8)
- * packed [n_flows][2 dim + 1] = uhat | w | b per flow (uhat from (u, w) by the caller, flows.py:24-26); dim <= 10,
+ * packed [n_flows][2 dim + 1] = uhat | w | b per flow (uhat from (u, w) by the caller, flows.py:24-26); dim <= 18,
  * n_flows <= VIBO_MAX_FLOWS.  forward: z_out [n_rows][dim], ladj [n_rows], tanh_out [n_rows][n_flows] (kept for backward).
  * backward: given d/d z_out and d/d ladj, writes d/d z [n_rows][dim] and ceil(n_rows / 256) partial records
  * [n_flows][2 dim + 1] = d/d uhat | d/d w | d/d b that the caller sums (fixed order).

@@ -33,10 +33,15 @@ def test_version_and_descriptor_validation():
     assert lib.vibo_workspace_bytes(ctypes.byref(d)) == 0          # abi_version 0 -> rejected
     assert b'abi_version' in lib.vibo_last_error_string()
     d.abi_version = _lib.ABI_VERSION
-    d.num_person, d.num_item, d.ability_dim, d.irt_model = 128, 100, 9, 2
-    assert lib.vibo_workspace_bytes(ctypes.byref(d)) == 0          # ability_dim 9 > 8
+    d.num_person, d.num_item, d.ability_dim, d.irt_model = 128, 100, 17, 2
+    assert lib.vibo_workspace_bytes(ctypes.byref(d)) == 0          # ability_dim 17 > VIBO_MAX_ABILITY_DIM_WIDE
     d.ability_dim = 8
     assert lib.vibo_workspace_bytes(ctypes.byref(d)) > 0
+    d.ability_dim = 12                                              # 9..16: the wave-per-person kernel, whatever the shape
+    assert lib.vibo_workspace_bytes(ctypes.byref(d)) > 0 and lib.vibo_plan_kernel(ctypes.byref(d)) == 5
+    d.posterior = _lib.POSTERIOR_GIVEN                              # ... but not a caller-supplied posterior, nor cell codes
+    assert lib.vibo_workspace_bytes(ctypes.byref(d)) == 0 and b'row-split' in lib.vibo_last_error_string()
+    assert _lib.MAX_ABILITY_DIM == 16 and _lib.MAX_ABILITY_DIM_FAST == 8
 
 
 def test_planner_reports_its_kernel_and_honours_the_flags():

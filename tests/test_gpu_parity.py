@@ -71,6 +71,33 @@ def test_golden_adam_trajectory(golden):
         assert (model.state_dict()[k].cpu() - v).abs().max() < 5e-4, k
 
 
+def test_golden_adam_trajectory_through_the_fused_trainers(golden):
+    """The reference's own recorded Adam steps (tools/gen_golden.py: parameters after 1 and 3 steps of vibo.py:243-268 with
+    the case's noise replayed) through the NATIVE train step -- FusedTrainer's kernels for the plain model,
+    FusedCondFlowTrainer's (vibo_ctrain_*: table MLP / flow backward + Adam by hand) for --conditional-posterior /
+    --n-norm-flows: no autograd, no torch.optim between the goldens and the kernels."""
+    from vibo_amd.trainer import FusedTrainer, fused_trainer_covers
+    m = golden.meta
+    model = build_model(golden)
+    if not fused_trainer_covers(model) or m.get('generative_model', 'irt') != 'irt':
+        pytest.skip('configuration trains through the module path')
+    if m['n_norm_flows'] == 0 and not m['use_kl_divergence']:
+        pytest.skip('the fused trainers use the analytic KL regulariser (the CLI default)')
+    d = dev()
+    model = model.to(d)
+    tr = FusedTrainer(model, lr=5e-3)
+    resp, mask = golden.response.to(d), golden.mask.to(d).bool()
+    eps_i, eps_a = golden.eps_item.to(d), golden.eps_ability.to(d)
+    for step in range(3):
+        loss = tr.step(resp, mask, beta=m['annealing_factor'], eps_item=eps_i, eps_ability=eps_a)
+        if step == 0:
+            assert rel_err(loss, golden.out['loss']) < TOL_ELBO
+            for k, v in golden.adam1.items():
+                assert (model.state_dict()[k].cpu() - v).abs().max() < 2e-4, (k, 'after one step')
+    for k, v in golden.adam3.items():
+        assert (model.state_dict()[k].cpu() - v).abs().max() < 5e-4, k
+
+
 # ---------------------------------------------------------------------------
 # (2) raw kernel outputs vs the CPU analytic oracle
 # ---------------------------------------------------------------------------
@@ -227,6 +254,12 @@ GENERAL_SHAPES = [
     (3, 1, 9, 10000, 0.2, True, 4),
     (2, 4, 15, 64, 0.1, True, 1),          # one-wave workgroups with 9 PoE sums per row (found by tools/fuzz_parity.py)
     (2, 3, 64, 8, 0.0, True, 0),
+    # ability_dim 9..16 (vibo.py:36-37 takes any int): the wave-per-person kernel's wide instantiation, every configuration
+    (2, 9, 70, 1000, 0.2, False, 0),
+    (2, 12, 33, 130, 0.1, True, 0),
+    (3, 16, 40, 95, 0.1, False, 2),
+    (1, 10, 50, 333, 0.0, True, 3),
+    (2, 16, 21, 1500, 0.3, True, 8),
 ]
 
 

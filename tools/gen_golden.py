@@ -89,6 +89,11 @@ CASES = [
     ('3pl_a1_cond_flows4',       3, 1, 16, 130, True, 0.0, False, 4, 1.0, False),
     ('3pl_a1_cond_flows4_miss',  3, 1, 37, 95, True, 0.2, False, 4, 1.0, False),
     ('2pl_a8_cond_miss_prior',   2, 8, 16, 20, True, 0.2, False, 0, 1.0, True),
+    # --ability-dim above 8 (vibo.py:36-37 takes any int): the wave-per-person kernel's wide instantiation
+    ('2pl_a12_uncond_miss_prior', 2, 12, 37, 130, False, 0.2, False, 0, 1.0, True),
+    ('2pl_a9_cond_miss_prior',    2, 9, 16, 20, True, 0.2, False, 0, 1.0, True),
+    ('2pl_a10_uncond_flows2',     2, 10, 16, 20, False, 0.0, False, 2, 1.0, False),
+    ('1pl_a16_uncond_miss_drop',  1, 16, 16, 20, False, 0.2, True, 0, 0.5, True),
     # --ability-merge mean (models.py:584-594, 631-650): 12th field
     ('2pl_a1_uncond_mean',           2, 1, 16, 20, False, 0.0, False, 0, 1.0, True, 'mean'),
     ('2pl_a2_uncond_mean_miss',      2, 2, 37, 95, False, 0.2, False, 0, 0.5, True, 'mean'),

@@ -42,8 +42,12 @@ static int check_desc(const vibo_desc* d) {
     if (d->abi_version != VIBO_ABI_VERSION) return fail(-2, "abi_version %d != %d", d->abi_version, VIBO_ABI_VERSION);
     if (d->num_person < 1) return fail(-3, "num_person must be >= 1");
     if (d->num_item < 1) return fail(-3, "num_item must be >= 1");
-    if (d->ability_dim < 1 || d->ability_dim > VIBO_MAX_ABILITY_DIM)
-        return fail(-3, "ability_dim %d outside 1..%d", d->ability_dim, VIBO_MAX_ABILITY_DIM);
+    if (d->ability_dim < 1 || d->ability_dim > VIBO_MAX_ABILITY_DIM_WIDE)
+        return fail(-3, "ability_dim %d outside 1..%d", d->ability_dim, VIBO_MAX_ABILITY_DIM_WIDE);
+    if (d->ability_dim > VIBO_MAX_ABILITY_DIM && d->posterior == VIBO_POSTERIOR_GIVEN)
+        return fail(-8, "VIBO_POSTERIOR_GIVEN needs the row-split path: ability_dim <= %d", VIBO_MAX_ABILITY_DIM);
+    if (d->ability_dim > VIBO_MAX_ABILITY_DIM && (d->mask_dtype == VIBO_MASK_CODES))
+        return fail(-8, "cell codes (VIBO_MASK_CODES) need the row-split paths: ability_dim <= %d", VIBO_MAX_ABILITY_DIM);
     if (d->irt_model < 1 || d->irt_model > 3) return fail(-3, "irt_model must be 1, 2 or 3");
     if (d->posterior != VIBO_POSTERIOR_UNCONDITIONAL && d->posterior != VIBO_POSTERIOR_CONDITIONAL &&
         d->posterior != VIBO_POSTERIOR_GIVEN)
@@ -188,6 +192,16 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
     const int num_cu = device_cus();
     const int I = d->num_item, A = d->ability_dim;
     pl->msplit = false;
+    if (A > VIBO_MAX_ABILITY_DIM) {
+        // ability_dim 9..16: the wave-per-person kernel's wide instantiation (every row-split / tiled kernel holds 8 dims)
+        memset(pl, 0, sizeof(*pl));
+        pl->general = true;
+        pl->AT = 8;
+        pl->D = item_feat_dim(d->irt_model, A);
+        pl->lay = partial_layout(A, pl->D, I, d->n_flows);
+        pl->total_bytes = 256;            // 8 scalar accumulators
+        return 16;
+    }
     pl->AT = padded_ability_dim(A);
     pl->D = item_feat_dim(d->irt_model, A);
     pl->DP = prepped_item_width(d->irt_model, pl->AT);
@@ -691,9 +705,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeParams p) {
     const long long src = p.row_index ? p.row_index[row] : row;
     const float* rp = p.response + src * p.resp_stride;
     const int A = p.A, I = p.I;
-    float lam[VIBO_MAX_ABILITY_DIM], smu[VIBO_MAX_ABILITY_DIM];
+    float lam[VIBO_MAX_ABILITY_DIM_WIDE], smu[VIBO_MAX_ABILITY_DIM_WIDE];
 #pragma unroll
-    for (int a = 0; a < VIBO_MAX_ABILITY_DIM; ++a) lam[a] = smu[a] = 0.f;
+    for (int a = 0; a < VIBO_MAX_ABILITY_DIM_WIDE; ++a) lam[a] = smu[a] = 0.f;
     const float tau_prior = 1.0f / (1.0f + kPoeEps);
     for (int i = lane; i < I; i += 64) {
         bool k;
@@ -703,7 +717,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeParams p) {
         const int c = (rp[i] == 1.0f) ? 1 : 0;
         const float* te = p.conditional ? p.table + ((size_t)c * I + i) * 2 * A : p.table + (size_t)c * 2 * A;
 #pragma unroll
-        for (int a = 0; a < VIBO_MAX_ABILITY_DIM; ++a) {
+        for (int a = 0; a < VIBO_MAX_ABILITY_DIM_WIDE; ++a) {
             if (a < A) {
                 if (k) {
                     const float tau = 1.0f / (__expf(te[A + a]) + kPoeEps);
@@ -716,7 +730,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeParams p) {
         }
     }
 #pragma unroll
-    for (int a = 0; a < VIBO_MAX_ABILITY_DIM; ++a) {
+    for (int a = 0; a < VIBO_MAX_ABILITY_DIM_WIDE; ++a) {
         if (a < A) {
             const float L = wave_total(lam[a]);
             const float S = wave_total(smu[a]);
@@ -794,6 +808,7 @@ static bool encode_on_matrix_pipe(const vibo_desc* d) {
 // scratch the fast encode path needs (0: not applicable -> wave-per-person encode_kernel)
 static size_t encode_scratch_bytes(const vibo_desc* d) {
     const int I = d->num_item, A = d->ability_dim;
+    if (A > VIBO_MAX_ABILITY_DIM) return 0;      // (wave-per-person encode kernel)
     if (I < 4 || I > 32767 || !rows_chunkable(d) || d->mask_dtype == VIBO_MASK_I64) return 0;
     if (d->posterior == VIBO_POSTERIOR_CONDITIONAL) {
         size_t pre = ((size_t)((I + 1023) / 1024) * d->num_person * (2 * A + 1) * 4 + 255) & ~(size_t)255;
@@ -817,9 +832,9 @@ __global__ __launch_bounds__(256) void decode_mean_kernel_strided(const float* _
     const bool ok = i < I;
     for (int s = 0; s < S; ++s) {
         const float* it = item + ((size_t)s * I + (ok ? i : 0)) * D;
-        float a[VIBO_MAX_ABILITY_DIM];
+        float a[VIBO_MAX_ABILITY_DIM_WIDE];
 #pragma unroll
-        for (int k = 0; k < VIBO_MAX_ABILITY_DIM; ++k) a[k] = (irt != 1 && k < A) ? it[k] : 0.f;
+        for (int k = 0; k < VIBO_MAX_ABILITY_DIM_WIDE; ++k) a[k] = (irt != 1 && k < A) ? it[k] : 0.f;
         const float bb = irt == 1 ? it[0] : it[A];
         float g = 0.f;
         if (irt == 3) g = 1.0f / (1.0f + expf(-it[A + 1]));
@@ -833,7 +848,7 @@ __global__ __launch_bounds__(256) void decode_mean_kernel_strided(const float* _
                 for (int k = 0; k < A; ++k) logit += th[k];
             } else {
 #pragma unroll
-                for (int k = 0; k < VIBO_MAX_ABILITY_DIM; ++k)
+                for (int k = 0; k < VIBO_MAX_ABILITY_DIM_WIDE; ++k)
                     if (k < A) logit = fmaf(-a[k], th[k], logit);
             }
             float pr = 1.0f / (1.0f + expf(-logit));

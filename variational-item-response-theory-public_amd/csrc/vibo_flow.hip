@@ -5,7 +5,7 @@
 //   z_{k+1} = z_k + uhat_k tanh(w_k . z_k + b_k),   ladj = sum_k log(|1 + (1 - tanh^2)(w_k . uhat_k)| + 1e-8)
 //
 // The module path runs this as ~35 tiny PyTorch kernels per flow and direction; here a thread owns a row and walks the whole
-// stack (dim <= 10 values in registers), the tanh values are kept for the backward, and the parameter gradients leave as
+// stack (dim <= 18 values in registers), the tanh values are kept for the backward, and the parameter gradients leave as
 // one partial record per workgroup in a fixed order (the caller sums them: bitwise reproducible).  uhat is formed from
 // (u, w) by the caller (autograd on 2 dim numbers per flow); `packed` is [n_flows][2 dim + 1] = uhat | w | b.
 #include <hip/hip_runtime.h>
@@ -15,7 +15,7 @@
 
 namespace vibo {
 
-constexpr int kFlowMaxDim = 10;        // item_feat_dim = ability_dim + 2 <= 10
+constexpr int kFlowMaxDim = 18;        // item_feat_dim = ability_dim + 2 <= VIBO_MAX_ABILITY_DIM_WIDE + 2
 
 __device__ __forceinline__ float flow_tanh(float a) {
     // tanh(x) = 1 - 2 / (1 + e^2x), |x| clamped so that e^2x stays finite (tanh(+-15) = +-1 in fp32)

@@ -24,7 +24,6 @@
 
 namespace vibo {
 
-constexpr int MA = VIBO_MAX_ABILITY_DIM;
 constexpr int MF = VIBO_MAX_FLOWS;
 
 __device__ __forceinline__ bool observed(const GeneralParams& p, long long src, int i) {
@@ -33,6 +32,9 @@ __device__ __forceinline__ bool observed(const GeneralParams& p, long long src, 
     return true;
 }
 
+// MA: the widest ability_dim the instantiation holds in registers -- 8 (every fast path's limit) or 16 (VIBO_MAX_ABILITY_DIM_WIDE:
+// ability_dim 9..16 runs here and only here)
+template <int MA>
 __global__ __launch_bounds__(256) void elbo_general_kernel(const GeneralParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
     float* lds_item = reinterpret_cast<float*>(smem_g);       // [I][D] when p.item_in_lds
@@ -393,17 +395,20 @@ hipError_t launch_elbo_general(const GeneralParams& p, int num_cu, hipStream_t s
     GeneralParams q = p;
     q.item_in_lds = (p.want_grad && item_bytes <= 150 * 1024) ? 1 : 0;
     const size_t lds = q.item_in_lds ? item_bytes : 0;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(elbo_general_kernel),
+    const bool wide = p.A > VIBO_MAX_ABILITY_DIM;
+    static bool attr_set[2] = {false, false};
+    if (lds > 48 * 1024 && !attr_set[wide]) {
+        hipError_t e = hipFuncSetAttribute(wide ? reinterpret_cast<const void*>(elbo_general_kernel<VIBO_MAX_ABILITY_DIM_WIDE>)
+                                                : reinterpret_cast<const void*>(elbo_general_kernel<VIBO_MAX_ABILITY_DIM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[wide] = true;
     }
     long long blocks = (p.B + 3) / 4;
     const long long cap = (long long)num_cu * (lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4);
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(elbo_general_kernel, dim3((unsigned)blocks), dim3(256), lds, s, q);
+    if (wide) hipLaunchKernelGGL(elbo_general_kernel<VIBO_MAX_ABILITY_DIM_WIDE>, dim3((unsigned)blocks), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL(elbo_general_kernel<VIBO_MAX_ABILITY_DIM>, dim3((unsigned)blocks), dim3(256), lds, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(general_scalars_kernel, dim3(1), dim3(64), 0, s, p.acc_scalars, p.out_scalars, p.reg_mode);

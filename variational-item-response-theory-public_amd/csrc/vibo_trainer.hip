@@ -95,7 +95,7 @@ __device__ __forceinline__ void epi_item_update(const int idx, const int n_item_
 
 constexpr int kEpiThreads = 1024;      // block 0's chain of small dependent stages is latency-bound: more lanes per stage, fewer passes
 struct EpiLds {
-    float h1[2][kMaxHidden], h2[2][kMaxHidden], gh2[2][kMaxHidden], gh1[2][kMaxHidden], gout[2][2 * VIBO_MAX_ABILITY_DIM];
+    float h1[2][kMaxHidden], h2[2][kMaxHidden], gh2[2][kMaxHidden], gh1[2][kMaxHidden], gout[2][2 * VIBO_MAX_ABILITY_DIM_WIDE];
 };
 
 // Block 0 of the epilogue: loss, the 2-row MLP backward by hand, Adam on the MLP parameters.
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_kernel(int H, int 
 //     Adam, runs the 2-row MLP forward on the NEW parameters (table, saved_h); the blocks past the item blocks fill eps_ab.
 constexpr int kEpiOut = 64, kEpiSlices = kEpiThreads / kEpiOut;
 constexpr int kEpiStageHidden = 64;
-constexpr int kEpiStageFloats = 3 * kEpiStageHidden + (kEpiStageHidden + 2 * VIBO_MAX_ABILITY_DIM) * (kEpiStageHidden + 1) + 2 * VIBO_MAX_ABILITY_DIM;
+constexpr int kEpiStageFloats = 3 * kEpiStageHidden + (kEpiStageHidden + 2 * VIBO_MAX_ABILITY_DIM_WIDE) * (kEpiStageHidden + 1) + 2 * VIBO_MAX_ABILITY_DIM_WIDE;
 static_assert(kEpiStageFloats * 8 >= 0 && kEpiThreads * kEpiU >= kEpiStageFloats, "one prefetch pass covers the staged parameters");
 static_assert(kEpiOut == kKlGroup, "one KL part per item block");
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kEpiThreads) void train_epilogue_fused_kernel(const
     __shared__ EpiLds L;
     __shared__ double part[kEpiSlices][kEpiOut], part2[kEpiSlices][kEpiOut];
     __shared__ float sc[VIBO_NUM_SCALARS];
-    __shared__ float gt[8 * VIBO_MAX_ABILITY_DIM];
+    __shared__ float gt[8 * VIBO_MAX_ABILITY_DIM_WIDE];
     __shared__ float Pl[kEpiStageFloats];        // block 0: padded copy of the MLP parameters (encoders up to kEpiStageHidden wide)
     const int tid = threadIdx.x;
     const int lane = tid % kEpiOut, slice = tid / kEpiOut;

@@ -38,7 +38,7 @@ def _model(args, num_item, state_dict, device):
 def _split(args, dataset, device):
     num_item = dataset.num_item
     fmt = getattr(args, 'row_format', 'auto')
-    ok = bool(args.cuda) and 4 <= num_item <= 32767
+    ok = bool(args.cuda) and 4 <= num_item <= 32767 and getattr(args, 'ability_dim', 1) <= 8
     fmt = ('codes' if ok else 'f32') if fmt == 'auto' else fmt
     return _cli.ResidentSplit(dataset, device, None, fmt)
 

@@ -117,6 +117,10 @@ def check_supported(args):
         problems.append("--ability-merge transformer (the reference asserts it away as well, models.py:262)")
     if args.generative_model != 'irt' and args.hidden_dim > 64:
         problems.append(f"--generative-model {args.generative_model} with --hidden-dim > 64 (the per-term decoder kernel covers widths up to 64)")
+    if args.ability_dim > 16:
+        problems.append("--ability-dim above 16 (1..8 on the row-split kernels, 9..16 on the wave-per-person kernel)")
+    if args.ability_dim > 8 and args.ability_merge == 'mean':
+        problems.append("--ability-merge mean with --ability-dim above 8 (its caller-supplied posterior needs the row-split kernels)")
     if args.response_dist != 'bernoulli':
         problems.append("--response-dist gaussian (the reference's loader has no *_continuous datasets either)")
     if args.dataset in ('duolingo', 'wordbank', 'pisa2015_science'):
@@ -438,11 +442,11 @@ def main(argv=None):
     def shard(n):
         return slice(rank * n // world, (rank + 1) * n // world) if world > 1 else None
     row_format = args.row_format
-    codes_ok = bool(args.cuda) and 4 <= num_item <= 32767
+    codes_ok = bool(args.cuda) and 4 <= num_item <= 32767 and args.ability_dim <= 8      # (9..16 ability dims: the wave-per-person kernel reads fp32 rows)
     if row_format == 'auto':
         row_format = 'codes' if codes_ok else 'f32'
     elif row_format == 'codes' and not codes_ok:
-        raise SystemExit('--row-format codes needs --cuda, 4..32767 items and ability dim <= 4 with --conditional-posterior')
+        raise SystemExit('--row-format codes needs --cuda, 4..32767 items and --ability-dim <= 8')
     train = ResidentSplit(train_dataset, device, shard(train_dataset.num_person), row_format)
     test = ResidentSplit(test_dataset, device, shard(test_dataset.num_person), row_format)
     local_bs = max(1, args.batch_size // world)
@@ -473,7 +477,7 @@ def main(argv=None):
     trainer = None
     plain = not args.conditional_posterior and args.n_norm_flows == 0
     if (args.cuda and args.ability_merge == 'product' and args.generative_model == 'irt' and not args.torch_optimizer
-            and (args.hidden_dim <= 256 if plain else args.hidden_dim in (32, 64))):      # (other widths: module + torch.optim.Adam)
+            and (args.hidden_dim <= 256 if plain else (args.hidden_dim in (32, 64) and args.ability_dim <= 8))):      # (else: module + torch.optim.Adam)
         # the whole step natively: FusedTrainer's kernels, or (conditional posterior / planar flows) FusedCondFlowTrainer's --
         # same Adam arithmetic, 4-12 launches per step, no PyTorch autograd inside the replayed graph
         from ..trainer import FusedTrainer

@@ -38,7 +38,7 @@ def fused_trainer_covers(model, hidden_dim=None):
         return False
     if model.conditional_posterior or model.n_norm_flows > 0:
         H = hidden_dim if hidden_dim is not None else model.ability_encoder.mlp[0].weight.shape[0]
-        return H in (32, 64)
+        return H in (32, 64) and model.ability_dim <= _lib.MAX_ABILITY_DIM_FAST      # (vibo_ctrain_*: 8 ability dims)
     return True
 
 
@@ -110,15 +110,17 @@ class FusedTrainer:
             self._beta_host = float(beta)
 
     @torch.no_grad()
-    def step(self, response, mask, beta=None, row_index=None):
-        """One train step; returns the loss (device scalar).  = forward_backward(); [all-reduce]; update()."""
-        raw = self.forward_backward(response, mask, beta=beta, row_index=row_index)
+    def step(self, response, mask, beta=None, row_index=None, eps_item=None, eps_ability=None):
+        """One train step; returns the loss (device scalar).  = forward_backward(); [all-reduce]; update().
+        eps_item [I, D] / eps_ability [B, A]: replay given reparameterisation noise instead of drawing it (parity tests against
+        the reference's recorded steps; takes the four-launch form)."""
+        raw = self.forward_backward(response, mask, beta=beta, row_index=row_index, eps_item=eps_item, eps_ability=eps_ability)
         if self.model._reducer is not None:
             self.model._reducer(raw.flat)     # person-sharded: ONE all-reduce per step
         return self.update()
 
     @torch.no_grad()
-    def forward_backward(self, response, mask, beta=None, row_index=None):
+    def forward_backward(self, response, mask, beta=None, row_index=None, eps_item=None, eps_ability=None):
         """Noise, prologue and the fused ELBO forward+backward of this rank's persons.  Returns the RawElbo whose
         `.flat` buffer [scalars | grads] a person-sharded caller all-reduces before `update()`.  (Split from
         `update()` so that a multi-GPU loop can replay the two halves as hipGraphs around an eager collective.)"""
@@ -133,10 +135,25 @@ class FusedTrainer:
         d = ops._make_desc(spec, B, I, code, _lib.REG_KL, True, response.stride(0), mask.stride(0) if mask is not None else 0)
         p = ops._ptr
         ab_stream = 1 + getattr(model, '_shard_rank', 0)      # item noise: the same on every rank; ability noise: per rank
-        step_bits = lib.vibo_train_step_supported(ctypes.byref(d)) if (self.fold and self.rng == 'native' and self.fused_noise) else 0
+        given = eps_item is not None or eps_ability is not None
+        if given and (eps_item is None or eps_ability is None):
+            raise ValueError('pass both eps_item and eps_ability, or neither')
+        step_bits = lib.vibo_train_step_supported(ctypes.byref(d)) if (self.fold and self.rng == 'native' and self.fused_noise and not given) else 0
         if step_bits & 1:
             return self._forward_backward_folded(d, step_bits, response, mask, code, row_index, B, ab_stream, stream)
         # ---- the four-launch form ----
+        if given:
+            eps_item, eps_ab = eps_item.contiguous().float(), eps_ability.contiguous().float()
+            self._primed_for = None
+            rc = lib.vibo_train_prologue(ctypes.byref(d), self.hidden, p(self.mlp_flat), p(self.item_mu), p(self.item_lv),
+                                         p(eps_item), p(self.item_feat), p(self.table), p(self.saved_h), p(self.kl_parts),
+                                         p(self._steps), stream)
+            _lib.check(rc, 'vibo_train_prologue')
+            raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None,
+                                       _lib.REG_KL, True, B)
+            self._pending = (d, eps_item, raw, None)
+            self.last = raw
+            return raw
         # reference draw order: item eps, then ability eps (models.py:361,368)
         if self.rng == 'native':
             eps_item = self._eps_item
@@ -305,7 +322,7 @@ class FusedCondFlowTrainer(FusedTrainer):
         self._eps_ab = {}
 
     @torch.no_grad()
-    def forward_backward(self, response, mask, beta=None, row_index=None):
+    def forward_backward(self, response, mask, beta=None, row_index=None, eps_item=None, eps_ability=None):
         if beta is not None:
             self.set_beta(beta)
         model, spec, lib = self.model, self.model.spec, _lib.load()
@@ -319,8 +336,14 @@ class FusedCondFlowTrainer(FusedTrainer):
         d = ops._make_desc(spec, B, I, code, reg_mode, True, response.stride(0), mask.stride(0) if mask is not None else 0)
         p = ops._ptr
         ab_stream = 1 + getattr(model, '_shard_rank', 0)
-        native = self.rng == 'native'
-        if native:
+        native = self.rng == 'native' and eps_item is None
+        given_ab = None
+        if eps_item is not None:
+            if eps_ability is None:
+                raise ValueError('pass both eps_item and eps_ability, or neither')
+            eps_item, given_ab = eps_item.contiguous().float(), eps_ability.contiguous().float()
+            eps_ab = None
+        elif native:
             eps_item = self._eps_item
             eps_ab = self._eps_ab.get(B)
             if eps_ab is None:
@@ -333,7 +356,9 @@ class FusedCondFlowTrainer(FusedTrainer):
                                       p(eps_item), self.seed, 1 if native else 0, p(eps_ab), ab_stream, p(self.item_feat),
                                       p(self.item_k), p(self.table), p(self.flow_packed), p(self.scratch), p(self._steps), stream)
         _lib.check(rc, 'vibo_ctrain_prologue')
-        if not native:
+        if given_ab is not None:
+            eps_ab = given_ab
+        elif not native:
             eps_ab = model._randn((B, model.ability_dim), self.item_mu, model._ability_gen)
         raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_k, eps_ab, self.flow_packed,
                                    reg_mode, True, B)
