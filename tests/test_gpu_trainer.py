@@ -302,7 +302,11 @@ def test_trained_model_matches_the_reference_cli_run(tmp_path, monkeypatch, gold
             col = 0 if a['irt'] == '1pl' else a['ability_dim']          # the difficulty column (1PL items have only that one)
             r_ours = np.corrcoef(ours[:, col], ref[:, col])[0, 1]
             print(f'[{golden_name}] difficulties r = {r_ours:.4f}')
-            assert r_ours > 0.97
+            # SURVEY 8c's bar.  (Measured 0.9974 .. 0.9985 over the five variants that keep an infer_dict; the reference's own
+            # --seed 42 / 43 / 44 runs correlate at 0.9966 .. 0.9984 on the 50- / 95-item variants -- and at 0.06 .. 0.18 on the
+            # 10-epoch 1 030- / 1 100-item ones, whose item embeddings are still dominated by their seed-dependent N(0,1)
+            # initialisation: there the bar is met because this run starts from the reference's seed-42 initialisation.)
+            assert r_ours > 0.99
         return
     # the reference's test loss drifts upward after the first epochs (756 -> 3424 over this run: an encoder trained on rows
     # with 20 % of the cells hidden is scored on complete rows) and is noise-dominated by then: compare the stable head of
