@@ -237,7 +237,7 @@ if a.target == 'module':
 t0, n, worst = time.time(), 0, 0.0
 while time.time() - t0 < a.seconds:
     irt = rng.choice([1, 2, 2, 3])
-    A = rng.choice([1, 1, 2, 3, 4, 5, 8])
+    A = rng.choice([1, 1, 2, 3, 4, 5, 8, 8, 9, 12, 16])      # (9..16: the wave-per-person kernel's wide instantiation)
     I = rng.choice([4, 8, 64, 96, 100, 255, 256, 257, 260, 511, 512, 516, 768, 1000, 1023, 1024, 1028, 2048, 2500, 3000])
     B = rng.choice([1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 130, 257])
     cond = rng.random() < 0.25
@@ -253,8 +253,8 @@ while time.time() - t0 < a.seconds:
     gather = rng.random() < 0.3          # minibatch as a row-index vector over a larger resident matrix
     no_mask = missing == 0.0 and rng.random() < 0.3
     fwd_only = rng.random() < 0.2
-    codes = rng.random() < 0.35 and not no_mask and not (cond and A > 4)      # rows as 1-byte cell codes (Format P)
-    given = (not cond) and rng.random() < 0.25      # caller-supplied posterior (VIBO_POSTERIOR_GIVEN, --ability-merge mean)
+    codes = rng.random() < 0.35 and not no_mask and not (cond and A > 4) and A <= 8      # rows as 1-byte cell codes (Format P)
+    given = (not cond) and A <= 8 and rng.random() < 0.25      # caller-supplied posterior (VIBO_POSTERIOR_GIVEN, --ability-merge mean)
     if a.replay:
         f = a.replay.split()
         irt, A, B, I, n_flows, dataseed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])

@@ -83,12 +83,12 @@ def main():
             irt, A, B, I, cond, n_flows = fixed[n]
         else:
             irt = rng.choice([1, 2, 2, 3])
-            A = rng.choice([1, 2, 3, 4, 5, 8, 11])
+            A = rng.choice([1, 2, 3, 4, 5, 8, 11, 16])
             B = rng.choice([1, 3, 7, 8, 9, 16, 17, 64, 130, 1000])
             I = rng.choice([1, 3, 4, 12, 64, 95, 100, 256, 260, 512, 1000, 1024, 1028, 2500, 6000, 10000])
             cond = rng.random() < 0.4
             n_flows = rng.choice([0, 0, 2, 4])
-        given = (not cond) and 4 <= I <= 32767 and rng.random() < 0.25 and n >= len(fixed)      # VIBO_POSTERIOR_GIVEN
+        given = (not cond) and A <= 8 and 4 <= I <= 32767 and rng.random() < 0.25 and n >= len(fixed)      # VIBO_POSTERIOR_GIVEN
         spec = ElboSpec(irt_model=irt, ability_dim=A, n_flows=n_flows, conditional=cond, given=given)
         try:
             spec.check_supported(I)

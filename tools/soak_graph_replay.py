@@ -33,7 +33,7 @@ torch.manual_seed(1)
 m1 = {1: VIBO_1PL, 2: VIBO_2PL, 3: VIBO_3PL}[a.irt](A, I, ability_merge='product', conditional_posterior=a.cond, n_norm_flows=a.flows).to(d)
 m2 = copy.deepcopy(m1)
 t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=7)
-t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=7)
+t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=7, fold=False)      # the four-launch form, launched eagerly: the yardstick
 rows = torch.zeros(B, dtype=torch.int64, device=d)
 perm = torch.randperm(P, device=d)
 for _ in range(3):
