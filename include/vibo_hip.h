@@ -365,6 +365,39 @@ int vibo_ctrain_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, 
                          float* loss_out, void* stream);
 
 /*
+ * The O(I) + O(1) part of a train step of the --ability-merge mean encoder (unconditional posterior, IRT decoder, no flows;
+ * models.py:584-594, 631-650; vibo.py:243-268) -- what vibo_train_prologue / vibo_train_epilogue are for the product-of-experts
+ * encoder.  A step is
+ *     vibo_mtrain_prologue      step_count[0] += 1; item sample, item KL parts (+ the Philox noise with draw_noise, as
+ *                               vibo_train_prologue_noise); the 2-row mlp1 forward and the u, v vectors of vibo_mean_encoder_forward
+ *                               (uv = u [H] | v [H]); saved = the activations the backward needs (4 H floats)
+ *     vibo_mean_encoder_forward (counts of the minibatch's rows, u, v, W22, b22) -> posterior [B][2A]
+ *     vibo_elbo_fwd_bwd         in VIBO_POSTERIOR_GIVEN mode (table = that posterior) -> flat = [8 scalars | grad_table [2][B][2A] | grad_item]
+ *     vibo_mean_encoder_backward_sets   = vibo_mean_encoder_backward on d loss / d posterior = -grad_table[0] + beta grad_table[1]
+ *                               (the combination done in the kernel: no [B][2A] temporary)
+ *     vibo_mtrain_epilogue      fixed-order sums of those per-wave records (grad_sums: 2H + 2A H + 2A floats of scratch), loss =
+ *                               -LL + beta (REG + KL_item), the backward through u, v, mlp2[0] and the 2-row mlp1 by hand, Adam
+ *                               on every parameter IN PLACE (torch.optim.Adam's update), item backward + Adam; step_count[1] += 1
+ *  params / adam_m / adam_v: one flat fp32 buffer each,
+ *      mlp1[0].weight [H] | .bias [H] | mlp1[2].weight [H][H] | .bias [H] | mlp2[0].weight [H][H] | .bias [H] | mlp2[2].weight [2A][H] | .bias [2A]
+ *      (vibo_mtrain_param_floats(d, H) floats); hidden_dim H <= 128; d->posterior must be VIBO_POSTERIOR_GIVEN.
+ *  kl_parts: ceil(I*D/64) floats; the other arguments as for vibo_train_prologue / vibo_train_epilogue.
+ */
+int64_t vibo_mtrain_param_floats(const vibo_desc* d, int hidden_dim);
+int vibo_mtrain_prologue(const vibo_desc* d, int hidden_dim, const float* params, const float* item_mu,
+                         const float* item_logvar, float* eps_item, uint64_t seed, int draw_noise, float* eps_ability,
+                         uint32_t ability_stream_id, float* item_feat, float* uv, float* saved, float* kl_parts,
+                         int32_t* step_count, void* stream);
+int vibo_mean_encoder_backward_sets(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v,
+                                    const float* w2, const float* grad_sets, const float* beta, float* partials,
+                                    int n_partials, void* stream);
+int vibo_mtrain_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, const float* partials, int n_partials,
+                         float* grad_sums, const float* saved, const float* kl_parts, const float* eps_item,
+                         const float* beta, const float* lr, int32_t* step_count, float* params, float* adam_m,
+                         float* adam_v, float* item_mu, float* item_logvar, float* item_m, float* item_v, float* loss_out,
+                         void* stream);
+
+/*
  * --ability-merge mean WITH --conditional-posterior (models.py:664-710 with _forward_mean :631-650): the per-term feature
  * depends on the item, feature[c][i][:] = elu(mlp1([c, item_i])) (the caller's 2 x I-row MLP), and the encoder's input is its mean
  * over a person's observed cells.  The sum over the cells -- one-hot(codes) [B, 2I] x feature [2I, H], the path's one dense

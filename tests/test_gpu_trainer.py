@@ -548,6 +548,86 @@ def test_fused_cond_flow_trainer_matches_torch_adam(cls, A, I, B, beta, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('cls,A,I,B,beta,kw', [
+    (VIBO_2PL, 1, 1000, 300, 1.0, {}), (VIBO_2PL, 8, 200, 130, 0.5, {}), (VIBO_3PL, 2, 95, 77, 1.0, {}),
+    (VIBO_1PL, 3, 64, 50, 0.7, dict(replace_missing_with_prior=False)), (VIBO_2PL, 2, 1100, 48, 1.0, {}),
+    (VIBO_2PL, 4, 5000, 16, 1.0, dict(hidden_dim=32)), (VIBO_2PL, 2, 130, 60, 1.0, dict(hidden_dim=128))])
+def test_fused_mean_trainer_matches_torch_adam(cls, A, I, B, beta, kw):
+    """FusedTrainer on --ability-merge mean models (FusedMeanTrainer: vibo_mtrain_prologue, vibo_mean_encoder_forward, the ELBO
+    kernel with the caller-supplied posterior, vibo_mean_encoder_backward_sets, vibo_mtrain_epilogue -- no autograd) follows
+    module + autograd + torch.optim.Adam: same seeds -> the same noise (rng='torch'), so losses and every parameter must agree
+    after several steps, on the whole matrix and on a gathered minibatch.  Reference: vibo.py:243-268, models.py:584-594, 631-650."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(A * 100 + I)
+    resp, mask = O.simulate_responses(cls.IRT, B + 20, I, A, generator=g, missing_frac=0.15)
+    mask[:, 0] = 1                      # (a person without an observed item has no mean: NaN in the reference too)
+    resp[:, 0] = resp[:, 0].clamp(min=0)
+    resp, mask = resp.to(dev), mask.bool().to(dev)
+    rows = torch.randperm(B + 20, generator=g)[:B].to(dev)
+    torch.manual_seed(3)
+    ref = cls(A, I, ability_merge='mean', **kw).to(dev)
+    fus = copy.deepcopy(ref)
+    opt = torch.optim.Adam(ref.parameters(), lr=5e-3)
+    trainer = FusedTrainer(fus, lr=5e-3)
+    assert type(trainer).__name__ == 'FusedMeanTrainer'
+    assert list(fus.state_dict().keys()) == list(ref.state_dict().keys())
+    for step in range(4):
+        ri = rows if step % 2 else None
+        torch.manual_seed(100 + step)
+        opt.zero_grad()
+        loss_ref = ref.elbo_step(resp, mask, annealing_factor=beta, row_index=ri)
+        loss_ref.backward()
+        if step == 0:
+            g_ref = {k: p.grad.clone() for k, p in ref.named_parameters()}
+        opt.step()
+        torch.manual_seed(100 + step)
+        loss_fus = trainer.step(resp, mask, beta=beta, row_index=ri)
+        assert abs(float(loss_fus) - float(loss_ref.detach())) < 3e-5 * abs(float(loss_ref.detach())), step
+        if step == 0:       # Adam's first step moves every parameter by lr * sign(g): a wrong gradient sign shows as 2 lr
+            for (k, a), (_, b) in zip(ref.named_parameters(), fus.named_parameters()):
+                big = g_ref[k].abs() > 1e-3 * g_ref[k].abs().max()
+                diff = (a.detach() - b.detach()).abs()
+                assert (diff[big] < 1e-4).all(), (k, float(diff.max()), int((diff[big] >= 1e-4).sum()), int(big.sum()))
+    for (k, a), (_, b) in zip(ref.state_dict().items(), fus.state_dict().items()):
+        assert (a - b).abs().max() < 2e-4, (k, float((a - b).abs().max()))
+    assert int(trainer.step_count) == 4
+
+
+@pytest.mark.gpu
+def test_fused_mean_trainer_replays_bitwise_from_a_hipgraph():
+    """The mean-merge step captured once and replayed (native noise: the counters live on the device) against the same steps
+    launched eagerly: bitwise, 200 replays over changing row-index vectors -- the captured autograd step this replaces is the
+    kind that went wrong after a dozen replays on this stack."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    P, I, A, B = 512, 1000, 2, 16
+    resp, mask = O.simulate_responses(2, P, I, A, generator=g, missing_frac=0.1)
+    resp, mask = resp.to(dev), mask.bool().to(dev)
+    torch.manual_seed(1)
+    m1 = VIBO_2PL(A, I, ability_merge='mean').to(dev)
+    m2 = copy.deepcopy(m1)
+    t1 = FusedTrainer(m1, lr=5e-3, rng='native', seed=7)
+    t2 = FusedTrainer(m2, lr=5e-3, rng='native', seed=7)
+    rows = torch.zeros(B, dtype=torch.int64, device=dev)
+    perm = torch.randperm(P, generator=g).to(dev)
+    for _ in range(3):
+        rows.copy_(perm[:B]); t1.step(resp, mask, row_index=rows); t2.step(resp, mask, row_index=rows)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        lg = t1.step(resp, mask, row_index=rows)
+    for it in range(200):
+        s0 = (it * B) % (P - B)
+        rows.copy_(perm[s0:s0 + B])
+        gr.replay()
+        l2 = t2.step(resp, mask, row_index=rows)
+        if it % 20 == 0 or it == 199:
+            assert torch.equal(lg, l2), it
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
 def test_fused_cond_flow_trainer_replays_bitwise_from_a_hipgraph():
     """The conditional + flows step (BASELINE configs[4]'s flag set) captured once and replayed: bitwise the parameters of the
     same steps launched eagerly (native noise: the counters live on the device), 200 replays -- the captured autograd step

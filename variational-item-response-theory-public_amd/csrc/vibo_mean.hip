@@ -51,8 +51,13 @@ template <int KCH>
 __global__ __launch_bounds__(256) void mean_encoder_bwd_kernel(const int* __restrict__ counts, const float* __restrict__ u,
                                                                const float* __restrict__ v, const float* __restrict__ w2,
                                                                const float* __restrict__ gpost, float* __restrict__ part,
-                                                               long long B, int H, int A2) {
+                                                               long long B, int H, int A2,
+                                                               // sets != null: d loss / d posterior = -sets[0] + beta sets[1]
+                                                               // (the two gradient sets of a VIBO_POSTERIOR_GIVEN call), gpost unused
+                                                               const float* __restrict__ sets, const float* __restrict__ beta_p) {
     const int lane = threadIdx.x & 63;
+    const float beta = sets ? *beta_p : 0.f;
+    const long long set1 = B * A2;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * 4;
     float uu[KCH], vv[KCH], wcol[KCH][2 * VIBO_MAX_ABILITY_DIM];
@@ -79,8 +84,9 @@ __global__ __launch_bounds__(256) void mean_encoder_bwd_kernel(const int* __rest
         const float w = (float)(c >> 16) / (float)(c & 0xffff);
         float g[2 * VIBO_MAX_ABILITY_DIM];
 #pragma unroll
-        for (int j = 0; j < 2 * VIBO_MAX_ABILITY_DIM; ++j) g[j] = j < A2 ? gpost[p * A2 + j] : 0.f;    // wave-uniform
-        if (lane < A2) gb += gpost[p * A2 + lane];
+        for (int j = 0; j < 2 * VIBO_MAX_ABILITY_DIM; ++j)                                             // wave-uniform
+            g[j] = j < A2 ? (sets ? fmaf(beta, sets[set1 + p * A2 + j], -sets[p * A2 + j]) : gpost[p * A2 + j]) : 0.f;
+        if (lane < A2) gb += sets ? fmaf(beta, sets[set1 + p * A2 + lane], -sets[p * A2 + lane]) : gpost[p * A2 + lane];
 #pragma unroll
         for (int ch = 0; ch < KCH; ++ch) {
             const float z = fmaf(w, vv[ch], uu[ch]);
@@ -147,12 +153,12 @@ extern "C" int vibo_mean_encoder_forward(const vibo_desc* d, int hidden, const i
     return (int)hipGetLastError();
 }
 
-extern "C" int vibo_mean_encoder_backward(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v,
-                                          const float* w2, const float* grad_posterior, float* partials, int n_partials,
-                                          void* stream) {
+static int mean_backward_launch(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v, const float* w2,
+                                const float* grad_posterior, const float* sets, const float* beta, float* partials, int n_partials,
+                                void* stream) {
     const int rc = mean_check(d, hidden);
     if (rc) return rc;
-    if (!counts || !u || !v || !w2 || !grad_posterior || !partials) return -5;
+    if (!counts || !u || !v || !w2 || (!grad_posterior && !sets) || (sets && !beta) || !partials) return -5;
     if (n_partials < 4 || n_partials % 4 != 0) return -3;
     const int kch = (hidden + 63) / 64;
     const dim3 grid(n_partials / 4), block(256);
@@ -160,10 +166,22 @@ extern "C" int vibo_mean_encoder_backward(const vibo_desc* d, int hidden, const 
     const long long B = d->num_person;
     const int A2 = 2 * d->ability_dim;
     switch (kch) {
-        case 1: hipLaunchKernelGGL(mean_encoder_bwd_kernel<1>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2); break;
-        case 2: hipLaunchKernelGGL(mean_encoder_bwd_kernel<2>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2); break;
-        case 3: hipLaunchKernelGGL(mean_encoder_bwd_kernel<3>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2); break;
-        default: hipLaunchKernelGGL(mean_encoder_bwd_kernel<4>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2); break;
+        case 1: hipLaunchKernelGGL(mean_encoder_bwd_kernel<1>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2, sets, beta); break;
+        case 2: hipLaunchKernelGGL(mean_encoder_bwd_kernel<2>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2, sets, beta); break;
+        case 3: hipLaunchKernelGGL(mean_encoder_bwd_kernel<3>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2, sets, beta); break;
+        default: hipLaunchKernelGGL(mean_encoder_bwd_kernel<4>, grid, block, 0, s, counts, u, v, w2, grad_posterior, partials, B, hidden, A2, sets, beta); break;
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int vibo_mean_encoder_backward(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v,
+                                          const float* w2, const float* grad_posterior, float* partials, int n_partials,
+                                          void* stream) {
+    return mean_backward_launch(d, hidden, counts, u, v, w2, grad_posterior, nullptr, nullptr, partials, n_partials, stream);
+}
+
+extern "C" int vibo_mean_encoder_backward_sets(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v,
+                                               const float* w2, const float* grad_sets, const float* beta, float* partials,
+                                               int n_partials, void* stream) {
+    return mean_backward_launch(d, hidden, counts, u, v, w2, nullptr, grad_sets, beta, partials, n_partials, stream);
 }

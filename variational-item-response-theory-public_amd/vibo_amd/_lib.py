@@ -70,7 +70,8 @@ EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_by
                     'vibo_decoder_person_chunks', 'vibo_decoder_fwd_bwd', 'vibo_flow_stack_forward', 'vibo_flow_stack_backward',
                     'vibo_ctrain_param_floats', 'vibo_ctrain_scratch_floats', 'vibo_ctrain_prologue', 'vibo_ctrain_epilogue',
                     'vibo_code_table_scratch_bytes', 'vibo_code_table_sum_forward', 'vibo_code_table_sum_backward',
-                    'vibo_train_step_supported', 'vibo_elbo_fwd_bwd_step', 'vibo_train_epilogue_fused', 'vibo_train_prime')
+                    'vibo_train_step_supported', 'vibo_elbo_fwd_bwd_step', 'vibo_train_epilogue_fused', 'vibo_train_prime',
+                    'vibo_mtrain_param_floats', 'vibo_mtrain_prologue', 'vibo_mean_encoder_backward_sets', 'vibo_mtrain_epilogue')
 
 _lib = None
 
@@ -168,6 +169,15 @@ def load():
                                               [ctypes.c_uint64, fp, fp, fp, ctypes.c_int64, ctypes.c_uint32, vp])
     lib.vibo_train_prime.restype = ctypes.c_int
     lib.vibo_train_prime.argtypes = [dp, ctypes.c_int] + [fp] * 8 + [vp, vp]
+    lib.vibo_mtrain_param_floats.restype = ctypes.c_int64
+    lib.vibo_mtrain_param_floats.argtypes = [dp, ctypes.c_int]
+    lib.vibo_mtrain_prologue.restype = ctypes.c_int
+    lib.vibo_mtrain_prologue.argtypes = [dp, ctypes.c_int, fp, fp, fp, fp, ctypes.c_uint64, ctypes.c_int, fp, ctypes.c_uint32,
+                                         fp, fp, fp, fp, vp, vp]
+    lib.vibo_mean_encoder_backward_sets.restype = ctypes.c_int
+    lib.vibo_mean_encoder_backward_sets.argtypes = [dp, ctypes.c_int, vp, fp, fp, fp, fp, fp, fp, ctypes.c_int, vp]
+    lib.vibo_mtrain_epilogue.restype = ctypes.c_int
+    lib.vibo_mtrain_epilogue.argtypes = [dp, ctypes.c_int, fp, fp, ctypes.c_int, fp, fp, fp, fp, fp, fp, vp] + [fp] * 8 + [vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

@@ -476,10 +476,14 @@ def main(argv=None):
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
     trainer = None
     plain = not args.conditional_posterior and args.n_norm_flows == 0
-    if (args.cuda and args.ability_merge == 'product' and args.generative_model == 'irt' and not args.torch_optimizer
-            and (args.hidden_dim <= 256 if plain else (args.hidden_dim in (32, 64) and args.ability_dim <= 8))):      # (else: module + torch.optim.Adam)
-        # the whole step natively: FusedTrainer's kernels, or (conditional posterior / planar flows) FusedCondFlowTrainer's --
-        # same Adam arithmetic, 4-12 launches per step, no PyTorch autograd inside the replayed graph
+    mean_native = (args.ability_merge == 'mean' and not args.conditional_posterior and args.n_norm_flows == 0
+                   and args.hidden_dim <= 128 and args.ability_dim <= 8 and world == 1)
+    if (args.cuda and args.generative_model == 'irt' and not args.torch_optimizer and
+            (mean_native if args.ability_merge == 'mean' else
+             (args.hidden_dim <= 256 if plain else (args.hidden_dim in (32, 64) and args.ability_dim <= 8)))):      # (else: module + torch.optim.Adam)
+        # the whole step natively: FusedTrainer's kernels, (conditional posterior / planar flows) FusedCondFlowTrainer's, or
+        # (--ability-merge mean, unconditional posterior, one GPU) FusedMeanTrainer's -- same Adam arithmetic, 2-12 launches
+        # per step, no PyTorch autograd inside the replayed graph
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)
     graphed = None

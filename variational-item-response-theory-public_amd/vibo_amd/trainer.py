@@ -32,9 +32,15 @@ from . import _lib, ops
 def fused_trainer_covers(model, hidden_dim=None):
     """True when one of the fused trainers of this module runs the model's whole train step natively: the product-of-experts
     encoder with the IRT decoder -- plain (FusedTrainer's kernels), or with the conditional posterior and / or planar flows
-    (FusedCondFlowTrainer's, hidden width 64 or 32).  --ability-merge mean and the MLP decoders train through the module +
-    torch.optim.Adam."""
-    if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
+    (FusedCondFlowTrainer's, hidden width 64 or 32) -- or the --ability-merge mean encoder with the unconditional posterior
+    (FusedMeanTrainer's, one GPU).  The MLP decoders and mean x conditional train through the module + torch.optim.Adam."""
+    if getattr(model, 'generative_model', 'irt') != 'irt':
+        return False
+    if model.ability_merge == 'mean':          # FusedMeanTrainer: unconditional posterior, no flows, hidden width <= 128
+        H = hidden_dim if hidden_dim is not None else model.ability_encoder.mlp1[0].weight.shape[0]
+        return (not model.conditional_posterior and model.n_norm_flows == 0 and H <= 128
+                and model.ability_dim <= _lib.MAX_ABILITY_DIM_FAST and model._reducer is None)
+    if model.ability_merge != 'product':
         return False
     if model.conditional_posterior or model.n_norm_flows > 0:
         H = hidden_dim if hidden_dim is not None else model.ability_encoder.mlp[0].weight.shape[0]
@@ -46,6 +52,8 @@ class FusedTrainer:
     def __new__(cls, model=None, *args, **kwargs):
         # one entry point: the conditional posterior / planar flows are served by the sibling class below
         # (model=None: copy / pickle re-create the object through cls.__new__(cls) and fill __dict__ themselves)
+        if cls is FusedTrainer and model is not None and model.ability_merge == 'mean':
+            return super().__new__(FusedMeanTrainer)
         if cls is FusedTrainer and model is not None and (model.conditional_posterior or model.n_norm_flows > 0):
             return super().__new__(FusedCondFlowTrainer)
         return super().__new__(cls)
@@ -376,4 +384,137 @@ class FusedCondFlowTrainer(FusedTrainer):
                                       p(self.item_mu), p(self.item_lv), p(self.item_m), p(self.item_v), p(self.scratch),
                                       p(self.loss), stream)
         _lib.check(rc, 'vibo_ctrain_epilogue')
+        return self.loss
+
+
+class FusedMeanTrainer(FusedTrainer):
+    """The fused train step for --ability-merge mean models with the unconditional posterior (vibo.py:243-268 with
+    models.py:584-594, 631-650): vibo_mtrain_prologue (item sample, item KL, the 2-row mlp1 forward and the u, v collapse of
+    mlp2[0]; optionally the Philox noise) -> vibo_mean_encoder_forward (per-person posterior from the row counts) ->
+    vibo_elbo_fwd_bwd in VIBO_POSTERIOR_GIVEN mode -> vibo_mean_encoder_backward_sets -> vibo_mtrain_epilogue (loss, the
+    backward through u, v and mlp1 by hand, Adam on everything).  No PyTorch autograd node: the step replays from a hipGraph
+    like FusedTrainer's (about ten launches).  Same interface (`FusedTrainer(model, ...)` returns this class for such models).
+    The packed row counts of the resident matrix are computed once (ops.row_counts keeps them while the same tensors come back).
+    One GPU: person-sharded mean-merge models keep the module path."""
+
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True):
+        if not fused_trainer_covers(model):
+            raise NotImplementedError('FusedMeanTrainer: --ability-merge mean with the unconditional posterior, the IRT decoder, no '
+                                      'flows, hidden_dim <= 128, ability_dim <= 8, one GPU; use model.elbo_step + torch.optim.Adam otherwise')
+        self.model = model
+        enc = model.ability_encoder
+        self.hidden = enc.mlp1[0].weight.shape[0]
+        plist = [enc.mlp1[0].weight, enc.mlp1[0].bias, enc.mlp1[2].weight, enc.mlp1[2].bias,
+                 enc.mlp2[0].weight, enc.mlp2[0].bias, enc.mlp2[2].weight, enc.mlp2[2].bias]
+        dev = plist[0].device
+        # one flat buffer (the layout of include/vibo_hip.h: vibo_mtrain_*); the nn.Parameters become views of it
+        self.par_flat = torch.cat([p.detach().reshape(-1) for p in plist]).contiguous()
+        off = 0
+        for p in plist:
+            n = p.numel()
+            p.data = self.par_flat[off:off + n].view_as(p)
+            off += n
+        self.par_m = torch.zeros_like(self.par_flat)
+        self.par_v = torch.zeros_like(self.par_flat)
+        self.item_mu = model.item_encoder.mu_lookup.weight
+        self.item_lv = model.item_encoder.logvar_lookup.weight
+        assert self.item_mu.is_contiguous() and self.item_lv.is_contiguous()
+        I, D = self.item_mu.shape
+        A, H = model.ability_dim, self.hidden
+        n_item = I * D
+        self._desc0 = ops._make_desc(model.spec, 1, I, _lib.MASK_NONE, _lib.REG_KL, True, I, 0)
+        lib = _lib.load()
+        if lib.vibo_mtrain_param_floats(ctypes.byref(self._desc0), H) != self.par_flat.numel():
+            raise RuntimeError('FusedMeanTrainer: parameter layout mismatch')
+        self.item_m = torch.zeros(2 * n_item, device=dev)
+        self.item_v = torch.zeros(2 * n_item, device=dev)
+        self._steps = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.lr = torch.tensor(float(lr), device=dev)
+        self.beta = torch.tensor(1.0, device=dev)
+        self._beta_host = 1.0
+        self.item_feat = torch.empty_like(self.item_mu)
+        self.uv = torch.empty(2 * H, device=dev)
+        self.saved = torch.empty(4 * H, device=dev)
+        self.grad_sums = torch.empty(2 * H + 2 * A * H + 2 * A, device=dev)
+        self.kl_parts = torch.empty((n_item + 63) // 64, device=dev)
+        o = 2 * H + H * H + H + H * H + H
+        self._w22 = self.par_flat[o:o + 2 * A * H]
+        self._b22 = self.par_flat[o + 2 * A * H:o + 2 * A * H + 2 * A]
+        self.loss = torch.zeros((), device=dev)
+        self.last = None
+        self._pending = None
+        if rng not in ('torch', 'native'):
+            raise ValueError("rng must be 'torch' or 'native'")
+        self.rng, self.seed = rng, int(seed)
+        self.fused_noise = True
+        self._eps_item = torch.empty_like(self.item_mu)
+        self._eps_ab = {}
+        self._parts = {}
+
+    @torch.no_grad()
+    def forward_backward(self, response, mask, beta=None, row_index=None, eps_item=None, eps_ability=None):
+        if beta is not None:
+            self.set_beta(beta)
+        model, spec, lib, p = self.model, self.model.spec, _lib.load(), ops._ptr
+        if model._reducer is not None:
+            raise NotImplementedError('FusedMeanTrainer: person-sharded mean-merge models train through model.elbo_step')
+        counts = ops.row_counts(response, mask)             # packed (n_correct << 16 | n_observed) of every resident row, cached
+        if row_index is not None:
+            counts = counts[row_index]
+        response, mask, code = ops.prepare_rows(response, mask)
+        B = int(row_index.numel()) if row_index is not None else response.shape[0]
+        I = response.shape[1]
+        dev = response.device
+        A, H = model.ability_dim, self.hidden
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        d = ops._make_desc(spec, B, I, code, _lib.REG_KL, True, response.stride(0), mask.stride(0) if mask is not None else 0)
+        given = eps_item is not None
+        native = self.rng == 'native' and not given
+        if given:
+            if eps_ability is None:
+                raise ValueError('pass both eps_item and eps_ability, or neither')
+            eps_item, eps_ab = eps_item.contiguous().float(), eps_ability.contiguous().float()
+        elif native:
+            eps_item = self._eps_item
+            eps_ab = self._eps_ab.get(B)
+            if eps_ab is None:
+                eps_ab = self._eps_ab[B] = torch.empty(B, A, device=dev)
+        else:
+            # reference draw order: item eps, then ability eps (models.py:361,368)
+            eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
+            eps_ab = None
+        rc = lib.vibo_mtrain_prologue(ctypes.byref(d), H, p(self.par_flat), p(self.item_mu), p(self.item_lv), p(eps_item), self.seed,
+                                      1 if native else 0, p(eps_ab) if native else ctypes.c_void_p(0), 1, p(self.item_feat), p(self.uv),
+                                      p(self.saved), p(self.kl_parts), p(self._steps), stream)
+        _lib.check(rc, 'vibo_mtrain_prologue')
+        if eps_ab is None:
+            eps_ab = model._randn((B, A), self.item_mu, model._ability_gen)
+        post = torch.empty(B, 2 * A, device=dev)
+        dm = ops._mean_desc(counts, A)
+        rc = lib.vibo_mean_encoder_forward(ctypes.byref(dm), H, p(counts), p(self.uv[:H]), p(self.uv[H:]), p(self._w22), p(self._b22),
+                                           p(post), stream)
+        _lib.check(rc, 'vibo_mean_encoder_forward')
+        raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, post, self.item_feat, eps_ab, None, _lib.REG_KL, True, B)
+        n_part = lib.vibo_mean_encoder_partials(ctypes.byref(dm))
+        parts = self._parts.get(n_part)
+        if parts is None:
+            parts = self._parts[n_part] = torch.empty(n_part, 2 * H + 2 * A * H + 2 * A, device=dev)
+        grad_sets = raw.flat[_lib.NUM_SCALARS:_lib.NUM_SCALARS + 2 * B * 2 * A]
+        rc = lib.vibo_mean_encoder_backward_sets(ctypes.byref(dm), H, p(counts), p(self.uv[:H]), p(self.uv[H:]), p(self._w22),
+                                                 p(grad_sets), p(self.beta), p(parts), n_part, stream)
+        _lib.check(rc, 'vibo_mean_encoder_backward_sets')
+        self._pending = (d, eps_item, raw, parts, n_part)
+        self.last = raw
+        return raw
+
+    @torch.no_grad()
+    def update(self):
+        d, eps_item, raw, parts, n_part = self._pending
+        lib, p = _lib.load(), ops._ptr
+        stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
+        rc = lib.vibo_mtrain_epilogue(ctypes.byref(d), self.hidden, p(raw.flat), p(parts), n_part, p(self.grad_sums), p(self.saved),
+                                      p(self.kl_parts), p(eps_item), p(self.beta), p(self.lr), p(self._steps), p(self.par_flat),
+                                      p(self.par_m), p(self.par_v), p(self.item_mu), p(self.item_lv), p(self.item_m), p(self.item_v),
+                                      p(self.loss), stream)
+        _lib.check(rc, 'vibo_mtrain_epilogue')
         return self.loss
