@@ -562,7 +562,8 @@ def test_fused_mean_trainer_matches_torch_adam(cls, A, I, B, beta, kw):
     resp, mask = O.simulate_responses(cls.IRT, B + 20, I, A, generator=g, missing_frac=0.15)
     mask[:, 0] = 1                      # (a person without an observed item has no mean: NaN in the reference too)
     resp[:, 0] = resp[:, 0].clamp(min=0)
-    resp, mask = resp.to(dev), mask.bool().to(dev)
+    from vibo_amd import ops
+    resp, mask = ops.pad_rows(resp.to(dev), mask.bool().to(dev))      # (95 items: row strides padded to 4 cells, as the CLI's resident splits)
     rows = torch.randperm(B + 20, generator=g)[:B].to(dev)
     torch.manual_seed(3)
     ref = cls(A, I, ability_merge='mean', **kw).to(dev)

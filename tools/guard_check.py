@@ -98,7 +98,7 @@ def main():
         g = torch.Generator().manual_seed(rng.randrange(1 << 30))
         resp, mask = O.simulate_responses(irt, B + 5, I, A, generator=g, missing_frac=rng.choice([0.0, 0.2]))
         r_, m_ = ops.pad_rows(resp.to(d), mask.bool().to(d))
-        use_codes = rng.random() < 0.4 and not (cond and A > 4) and I >= 4
+        use_codes = rng.random() < 0.4 and not (cond and A > 4) and I >= 4 and A <= 8
         if use_codes:
             r_, m_ = ops.pack_cell_codes(r_, m_), None
         r, m, code = ops.prepare_rows(r_, m_)
