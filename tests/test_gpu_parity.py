@@ -86,7 +86,7 @@ def test_golden_adam_trajectory_through_the_fused_trainers(golden):
     d = dev()
     model = model.to(d)
     tr = FusedTrainer(model, lr=5e-3)
-    resp, mask = golden.response.to(d), golden.mask.to(d).bool()
+    resp, mask = ops.pad_rows(golden.response.to(d), golden.mask.to(d).bool())      # (row strides padded to 4 cells, as the CLI's resident splits)
     eps_i, eps_a = golden.eps_item.to(d), golden.eps_ability.to(d)
     for step in range(3):
         loss = tr.step(resp, mask, beta=m['annealing_factor'], eps_item=eps_i, eps_ability=eps_a)

@@ -116,7 +116,7 @@ def main():
         fl = nan_fenced(torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5) if n_flows else None
         reg = _lib.REG_SAMPLED if n_flows else rng.choice([_lib.REG_KL, _lib.REG_SAMPLED])
         cfg = (irt, A, B, I, cond, n_flows, rows is not None, reg, use_codes, given)
-        exact = 4 <= I <= 32767 and (not cond or A <= 4)      # row-split paths: partial records + fp64 finalize, no atomics
+        exact = 4 <= I <= 32767 and (not cond or A <= 4) and A <= 8      # row-split paths: partial records + fp64 finalize, no atomics (9..16 dims: wave-per-person kernel)
         for want_grad in (False, True):
             res = []
             for FILL[0] in (0, 0xFF):
