@@ -47,7 +47,13 @@ def fuzz_multi():
         table = torch.randn(2, 2 * A, generator=g) * 0.7
         items = torch.randn(S, I, spec.item_dim, generator=g) * 0.6
         eps = torch.randn(S, B, A, generator=g)
-        fl = (torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5).to(d) if n_flows else None
+        fl = None
+        if n_flows:           # uhat | w | b with the reference's constraint w.uhat >= -1 (flows.py:23-26): without it 1 + psi.u crosses
+            raw = torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5          # zero and log|.| amplifies fp32 rounding without bound
+            u, w = raw[:, :A], raw[:, A:2 * A]
+            wu = (w * u).sum(1, keepdim=True)
+            raw[:, :A] = u + (-1 + torch.nn.functional.softplus(wu) - wu) * w / (w * w).sum(1, keepdim=True)
+            fl = raw.to(d)
         r_, m_ = ops.pad_rows(resp.to(d), mask.bool().to(d))
         r = ops.prepare_response(r_)
         m, code = ops.prepare_mask(m_)
