@@ -503,6 +503,9 @@ def test_graphed_module_step_survives_the_epochs_short_last_minibatch():
     (VIBO_2PL, 8, 300, 48, 1.0, dict(conditional_posterior=True)),
     (VIBO_2PL, 8, 300, 48, 1.0, dict(n_norm_flows=3)),
     (VIBO_2PL, 2, 130, 60, 1.0, dict(conditional_posterior=True, hidden_dim=32)),
+    (VIBO_2PL, 3, 130, 60, 1.0, dict(conditional_posterior=True, n_norm_flows=2, hidden_dim=48)),      # (narrower: zero-padded tile)
+    (VIBO_3PL, 1, 37, 20, 1.0, dict(conditional_posterior=True, hidden_dim=10)),
+    (VIBO_2PL, 2, 9000, 16, 1.0, dict(conditional_posterior=True)),          # > 512 tiles of table rows: two tiles per workgroup
 ])
 def test_fused_cond_flow_trainer_matches_torch_adam(cls, A, I, B, beta, kw):
     """FusedTrainer on --conditional-posterior / --n-norm-flows models (FusedCondFlowTrainer: vibo_ctrain_prologue, the ELBO

@@ -22,9 +22,12 @@ namespace vibo {
 constexpr int kCtMaxDim = 10;          // item_feat_dim = ability_dim + 2 <= 10
 constexpr int kCtItems = 256;          // items per workgroup of the item-side kernels
 
-__host__ __device__ inline int ct_rows_per_wave(int rows) {
-    const int r = (rows + 511) / 512;
-    return r < 8 ? 8 : r;
+constexpr int kCtTile = 16;            // table rows per tile of the matrix-pipe MLP kernels
+// tiles per workgroup: one, until there are more than 512 tiles (then the partial records stay at <= 512)
+__host__ __device__ inline int ct_tiles_per_block(int rows) {
+    const int nt = (rows + kCtTile - 1) / kCtTile;
+    const int t = (nt + 511) / 512;
+    return t < 1 ? 1 : t;
 }
 
 struct CtLayout {
@@ -42,7 +45,7 @@ __host__ __device__ inline CtLayout ct_layout(int I, int A, int irt, int cond, i
     L.w0 = 0; L.b0 = L.w0 + H * L.xin; L.w1 = L.b0 + H; L.b1 = L.w1 + H * H; L.w2 = L.b1 + H; L.b2 = L.w2 + L.O * H;
     L.n_mlp = L.b2 + L.O;
     L.fa = L.n_mlp; L.fi = L.fa + F * (2 * A + 1); L.n_par = L.fi + F * (2 * L.D + 1);
-    L.n_rb = (L.rows + ct_rows_per_wave(L.rows) - 1) / ct_rows_per_wave(L.rows);
+    L.n_rb = ((L.rows + kCtTile - 1) / kCtTile + ct_tiles_per_block(L.rows) - 1) / ct_tiles_per_block(L.rows);
     L.n_ib = (I + kCtItems - 1) / kCtItems;
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
@@ -187,167 +190,232 @@ __global__ __launch_bounds__(kCtItems) void ct_prologue_kernel(const CtProParams
 }
 
 // ---------------------------------------------------------------------------
-// table rows [c, item_i] (or [c]): one wave per workgroup, LANE = HIDDEN UNIT (H <= 64), rows one after the other.
-// Lane j keeps row j of W0 / W1 (and, backward, column j of W1 and W2) in registers; the activation vectors travel
-// through 64-float LDS vectors (broadcast reads).  (A first version with a thread per row and the activations in
-// per-thread arrays spilled them to scratch: 64 + 110 us per step instead of ~10.)
+// table rows [c, item_i] (or [c]) on the matrix pipe: tiles of 16 rows, one workgroup of four waves per tile (a workgroup
+// walks `tpb` tiles when there are more than 512 of them), every contraction of the 64-wide MLP as v_mfma_f32_16x16x4_f32
+// (fp32 operands: no splitting, results of fp32 grade by construction).  Hidden widths below 64 run zero-padded.
+//   operand layouts of one 16x16x4 step (lane = 16 kk + i16):  A[i16][kk], B[kk][i16], C: register r' = C[4 kk + r'][i16]
+//   K = 64 contractions walk k = 16 kk + s over 16 steps (each lane reads 16 consecutive floats of its row / loads 16
+//   consecutive weights once per workgroup), K = 16 (rows of the tile, or outputs) walk k = 4 kk + s over 4 steps.
+// (Round 3's version -- one wave per 8 rows, lane = hidden unit, dot products on the VALU through LDS broadcasts -- took
+//  13 us forward and 25 us backward for 2 000 rows; it is gone.)
 // ---------------------------------------------------------------------------
-// input of row r: [c, item_feat[i][0..D)) with c = r / I (conditional) or [r]   (r wave-uniform)
-__device__ inline void ct_row_input(const CtLayout& L, const float* __restrict__ item_feat, int r, float (&x)[kCtMaxDim + 1]) {
-#pragma unroll
-    for (int d = 0; d < kCtMaxDim + 1; ++d) x[d] = 0.f;
-    if (L.cond) {
-        const int c = r / L.I, i = r - c * L.I;
-        x[0] = (float)c;
-#pragma unroll
-        for (int d = 0; d < kCtMaxDim; ++d)
-            if (d < L.D) x[1 + d] = item_feat[(size_t)i * L.D + d];
-    } else {
-        x[0] = (float)r;
-    }
+typedef float ct_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ct_f32x4 ct_mfma(const float a, const float b, const ct_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-// h_out[lane] = elu(bias + sum_k wrow[k] * vec[k]) with vec in LDS (broadcast reads)
-template <int H>
-__device__ __forceinline__ float ct_dot_lds(const float (&wrow)[H], const float* __restrict__ vec) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+constexpr int kCtLd = 68;               // LDS row stride (floats) of the 16 x 64 tiles
+struct CtTileLds {
+    float X[kCtTile][16];               // inputs [c | item_feat | 0 ...], column 15 = 1 (bias column of the W0-gradient contraction)
+    float H0[kCtTile][kCtLd];
+    float H1[kCtTile][kCtLd];
+};
+// the weights a lane keeps for the forward of a tile
+struct CtFwdRegs {
+    float w0r[kCtMaxDim + 1];           // row j = tid & 63 of W0
+    float b0j;
+    float b1v[16];                      // W1[16 w + i16][16 kk + s]
+    float b1u;                          // b1[16 w + i16]
+};
+__device__ __forceinline__ void ct_load_fwd(const CtLayout& L, const float* __restrict__ P, const int tid, CtFwdRegs& R) {
+    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, j = tid & 63, unit = 16 * w + i16;
 #pragma unroll
-    for (int k = 0; k < H; k += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(vec + k);
-        a0 = fmaf(wrow[k], v.x, a0); a1 = fmaf(wrow[k + 1], v.y, a1); a2 = fmaf(wrow[k + 2], v.z, a2); a3 = fmaf(wrow[k + 3], v.w, a3);
+    for (int d = 0; d < kCtMaxDim + 1; ++d) R.w0r[d] = (j < L.H && d < L.xin) ? P[L.w0 + j * L.xin + d] : 0.f;
+    R.b0j = j < L.H ? P[L.b0 + j] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) R.b1v[s] = (unit < L.H && 16 * kk + s < L.H) ? P[L.w1 + unit * L.H + 16 * kk + s] : 0.f;
+    R.b1u = unit < L.H ? P[L.b1 + unit] : 0.f;
+}
+// K = 64 contraction: A = row i16 of a 16 x 64 LDS tile, B = the lane's 16 weights (two accumulator chains)
+__device__ __forceinline__ ct_f32x4 ct_contract64(const float (*T)[kCtLd], const float (&bw)[16], const int i16, const int kk) {
+    ct_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 v = *reinterpret_cast<const float4*>(&T[i16][16 * kk + 4 * s4]);
+        a0 = ct_mfma(v.x, bw[4 * s4], a0);
+        a1 = ct_mfma(v.y, bw[4 * s4 + 1], a1);
+        a0 = ct_mfma(v.z, bw[4 * s4 + 2], a0);
+        a1 = ct_mfma(v.w, bw[4 * s4 + 3], a1);
     }
-    return (a0 + a1) + (a2 + a3);
+    return a0 + a1;
+}
+// rows r0 .. r0 + 15: inputs and layer 0 on the VALU, layer 1 on the matrix pipe; leaves X, H0, H1 in LDS (the caller
+// synchronises before reading H1) and the lane's piece of H1 in h1c (rows 4 kk + r' of column 16 w + i16)
+__device__ __forceinline__ void ct_tile_forward(const CtLayout& L, const float* __restrict__ item_feat, const int r0, CtTileLds& S,
+                                                const CtFwdRegs& R, ct_f32x4& h1c, const int tid) {
+    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, unit = 16 * w + i16;
+    {
+        const int r = tid >> 4, d = tid & 15, row = r0 + r;
+        float x = 0.f;
+        if (row < L.rows) {
+            if (L.cond) {
+                const int c = row / L.I, i = row - c * L.I;
+                x = d == 0 ? (float)c : (d <= L.D ? item_feat[(size_t)i * L.D + d - 1] : 0.f);
+            } else {
+                x = d == 0 ? (float)row : 0.f;
+            }
+        }
+        S.X[r][d] = d == 15 ? 1.0f : x;
+    }
+    __syncthreads();
+    {
+        const int j = tid & 63;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = (tid >> 6) + 4 * m;
+            float a = R.b0j;
+#pragma unroll
+            for (int d = 0; d < kCtMaxDim + 1; ++d) a = fmaf(R.w0r[d], S.X[r][d], a);
+            S.H0[r][j] = j < L.H ? ct_elu(a) : 0.f;
+        }
+    }
+    __syncthreads();
+    const ct_f32x4 c = ct_contract64(S.H0, R.b1v, i16, kk);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const float h = unit < L.H ? ct_elu(c[rr] + R.b1u) : 0.f;
+        h1c[rr] = h;
+        S.H1[4 * kk + rr][unit] = h;
+    }
 }
 
-template <int H>
-__global__ __launch_bounds__(64) void ct_table_kernel(const CtLayout L, const float* __restrict__ P, const float* __restrict__ item_feat,
-                                                      float* __restrict__ table, int rpw) {
-    __shared__ __attribute__((aligned(16))) float S0[64], S1[64];
-    const int lane = threadIdx.x;
-    const bool act = lane < H;
-    const int j = act ? lane : 0;
-    float w0r[kCtMaxDim + 1], w1r[H], w2r[H];
+__global__ __launch_bounds__(256) void ct_table_kernel(const CtLayout L, const float* __restrict__ P, const float* __restrict__ item_feat,
+                                                       float* __restrict__ table, int tpb) {
+    __shared__ __attribute__((aligned(16))) CtTileLds S;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
+    CtFwdRegs R;
+    ct_load_fwd(L, P, tid, R);
+    float w2v[16];                      // wave 0: W2[q = i16][16 kk + s]
 #pragma unroll
-    for (int d = 0; d < kCtMaxDim + 1; ++d) w0r[d] = (act && d < L.xin) ? P[L.w0 + j * L.xin + d] : 0.f;
-#pragma unroll
-    for (int k = 0; k < H; ++k) w1r[k] = act ? P[L.w1 + j * H + k] : 0.f;
-    const bool outl = lane < L.O;                    // lane q < O owns output q (row q of W2)
-#pragma unroll
-    for (int k = 0; k < H; ++k) w2r[k] = outl ? P[L.w2 + lane * H + k] : 0.f;
-    const float b0j = act ? P[L.b0 + j] : 0.f, b1j = act ? P[L.b1 + j] : 0.f, b2q = outl ? P[L.b2 + lane] : 0.f;
-    const int r0 = blockIdx.x * rpw;
-    for (int rr = 0; rr < rpw; ++rr) {
-        const int r = r0 + rr;
-        if (r >= L.rows) break;
-        float x[kCtMaxDim + 1];
-        ct_row_input(L, item_feat, r, x);
-        float a = b0j;
-#pragma unroll
-        for (int d = 0; d < kCtMaxDim + 1; ++d) a = fmaf(w0r[d], x[d], a);
-        S0[lane] = act ? ct_elu(a) : 0.f;
+    for (int s = 0; s < 16; ++s) w2v[s] = (w == 0 && i16 < L.O && 16 * kk + s < L.H) ? P[L.w2 + i16 * L.H + 16 * kk + s] : 0.f;
+    const float b2q = i16 < L.O ? P[L.b2 + i16] : 0.f;
+    for (int t = 0; t < tpb; ++t) {
+        const int r0 = (blockIdx.x * tpb + t) * kCtTile;
+        if (r0 >= L.rows) break;
+        ct_f32x4 h1c;
+        ct_tile_forward(L, item_feat, r0, S, R, h1c, tid);
         __syncthreads();
-        const float h1 = ct_elu(b1j + ct_dot_lds<H>(w1r, S0));
-        S1[lane] = act ? h1 : 0.f;
-        __syncthreads();
-        const float o = b2q + ct_dot_lds<H>(w2r, S1);
-        if (outl) table[(size_t)r * L.O + lane] = o;
+        if (w == 0) {
+            const ct_f32x4 c = ct_contract64(S.H1, w2v, i16, kk);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = r0 + 4 * kk + rr;
+                if (row < L.rows && i16 < L.O) table[(size_t)row * L.O + i16] = c[rr] + b2q;
+            }
+        }
+        __syncthreads();                // (the next tile rewrites X / H0 / H1)
     }
 }
 
 // backward of the table rows: d loss / d table = -dLL + coef dREG (flat: [8 scalars | grad_table set 0 | set 1 | ...]);
 // one partial record of MLP-parameter gradients per workgroup (fixed order), d loss / d item_feat of the row -> gx
-template <int H>
-__global__ __launch_bounds__(64) void ct_rows_backward_kernel(const CtLayout L, const float* __restrict__ P, const float* __restrict__ item_feat,
-                                                              const float* __restrict__ flat, const float* __restrict__ beta_p,
-                                                              float* __restrict__ scratch, int rpw) {
-    __shared__ __attribute__((aligned(16))) float S0[64], S1[64], Sg[2 * VIBO_MAX_ABILITY_DIM];
-    const int lane = threadIdx.x;
-    const bool act = lane < H;
-    const int j = act ? lane : 0;
+struct CtBwdLds {
+    CtTileLds F;
+    float G1[kCtTile][kCtLd];           // d loss / d (layer-1 pre-activation)
+    float G0[kCtTile][kCtLd];           // d loss / d (layer-0 pre-activation)
+    float Sg[kCtTile][16];              // d loss / d table row (zero past O)
+};
+__global__ __launch_bounds__(256) void ct_rows_backward_kernel(const CtLayout L, const float* __restrict__ P, const float* __restrict__ item_feat,
+                                                               const float* __restrict__ flat, const float* __restrict__ beta_p,
+                                                               float* __restrict__ scratch, int tpb) {
+    __shared__ __attribute__((aligned(16))) CtBwdLds S;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, unit = 16 * w + i16;
     const float coef = L.F > 0 ? 1.0f : *beta_p;            // (flows: the annealing factor is ignored, models.py:406-424)
     const size_t n_table = (size_t)L.rows * L.O;
-    float w0r[kCtMaxDim + 1], w1r[H], w1c[H], w2c[2 * VIBO_MAX_ABILITY_DIM];
+    CtFwdRegs R;
+    ct_load_fwd(L, P, tid, R);
+    float w1t[16], w2t[4], w0t[16];
 #pragma unroll
-    for (int d = 0; d < kCtMaxDim + 1; ++d) w0r[d] = (act && d < L.xin) ? P[L.w0 + j * L.xin + d] : 0.f;
-#pragma unroll
-    for (int k = 0; k < H; ++k) {
-        w1r[k] = act ? P[L.w1 + j * H + k] : 0.f;          // row j:    W1[j][k]
-        w1c[k] = act ? P[L.w1 + k * H + j] : 0.f;          // column j: W1[k][j]
+    for (int s = 0; s < 16; ++s) {
+        const int j = 16 * kk + s;
+        w1t[s] = (j < L.H && unit < L.H) ? P[L.w1 + j * L.H + unit] : 0.f;                                 // W1[j][unit]
+        w0t[s] = (L.cond && w == 0 && j < L.H && i16 < L.D) ? P[L.w0 + j * L.xin + 1 + i16] : 0.f;        // W0[j][1 + d], d = i16
     }
 #pragma unroll
-    for (int q = 0; q < 2 * VIBO_MAX_ABILITY_DIM; ++q) w2c[q] = (act && q < L.O) ? P[L.w2 + q * H + j] : 0.f;
-    const float b0j = act ? P[L.b0 + j] : 0.f, b1j = act ? P[L.b1 + j] : 0.f;
-    // accumulators of this lane's rows of the parameter gradients
-    float aW0[kCtMaxDim + 1], aW1[H], aW2[2 * VIBO_MAX_ABILITY_DIM];
-    float ab0 = 0.f, ab1 = 0.f, ab2 = 0.f;
+    for (int s = 0; s < 4; ++s) w2t[s] = (4 * kk + s < L.O && unit < L.H) ? P[L.w2 + (4 * kk + s) * L.H + unit] : 0.f;   // W2[q][unit]
+    // gradient accumulators (C tiles, carried over the workgroup's tiles)
+    const ct_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    ct_f32x4 aW1[4] = {zero4, zero4, zero4, zero4};          // rows 16 w + 4 kk + r' of gW1, columns 16 cb + i16
+    ct_f32x4 aW2 = zero4;                                    // gW2[q = 4 kk + r'][unit]
+    ct_f32x4 aW0 = zero4;                                    // gW0[16 w + 4 kk + r'][d = i16], d = 15: gb0
+    float ab = 0.f;                                          // tid < 64: gb1[tid]; 64 <= tid < 80: gb2[tid - 64]
+    for (int t = 0; t < tpb; ++t) {
+        const int r0 = (blockIdx.x * tpb + t) * kCtTile;
+        if (r0 >= L.rows) break;
+        {
+            const int r = tid >> 4, q = tid & 15, row = r0 + r;
+            float g = 0.f;
+            if (row < L.rows && q < L.O)
+                g = -flat[VIBO_NUM_SCALARS + (size_t)row * L.O + q] + coef * flat[VIBO_NUM_SCALARS + n_table + (size_t)row * L.O + q];
+            S.Sg[r][q] = g;
+        }
+        ct_f32x4 h1c;
+        ct_tile_forward(L, item_feat, r0, S.F, R, h1c, tid);          // (its barriers publish Sg as well)
+        {   // G1 = (gO W2) * elu'(z1)   (elu'(z) = 1 | e^z = h + 1)
+            ct_f32x4 c = zero4;
+            const float4 v = *reinterpret_cast<const float4*>(&S.Sg[i16][4 * kk]);
+            c = ct_mfma(v.x, w2t[0], c); c = ct_mfma(v.y, w2t[1], c); c = ct_mfma(v.z, w2t[2], c); c = ct_mfma(v.w, w2t[3], c);
 #pragma unroll
-    for (int d = 0; d < kCtMaxDim + 1; ++d) aW0[d] = 0.f;
-#pragma unroll
-    for (int k = 0; k < H; ++k) aW1[k] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 2 * VIBO_MAX_ABILITY_DIM; ++q) aW2[q] = 0.f;
-    const int r0 = blockIdx.x * rpw;
-    for (int rr = 0; rr < rpw; ++rr) {
-        const int r = r0 + rr;
-        if (r >= L.rows) break;
-        float x[kCtMaxDim + 1];
-        ct_row_input(L, item_feat, r, x);
-        float a = b0j;
-#pragma unroll
-        for (int d = 0; d < kCtMaxDim + 1; ++d) a = fmaf(w0r[d], x[d], a);
-        const float h0 = act ? ct_elu(a) : 0.f;
-        S0[lane] = h0;
-        if (lane < 2 * VIBO_MAX_ABILITY_DIM)
-            Sg[lane] = lane < L.O ? -flat[VIBO_NUM_SCALARS + (size_t)r * L.O + lane] + coef * flat[VIBO_NUM_SCALARS + n_table + (size_t)r * L.O + lane] : 0.f;
+            for (int rr = 0; rr < 4; ++rr) S.G1[4 * kk + rr][unit] = c[rr] * (h1c[rr] > 0.f ? 1.0f : h1c[rr] + 1.0f);
+        }
         __syncthreads();
-        const float h1 = act ? ct_elu(b1j + ct_dot_lds<H>(w1r, S0)) : 0.f;
-        // g1 = W2^T gout * elu'(z1)   (elu'(z) = 1 | e^z = h + 1); W2 / b2 gradients
-        float g1 = 0.f;
+        // gW2 += gO^T H1,  gW1 += G1^T H0   (K = the tile's rows)
 #pragma unroll
-        for (int q = 0; q < 2 * VIBO_MAX_ABILITY_DIM; ++q) {
-            const float go = Sg[q];
-            g1 = fmaf(w2c[q], go, g1);
-            aW2[q] = fmaf(go, h1, aW2[q]);
-        }
-        if (lane < L.O) ab2 += Sg[lane];
-        g1 *= h1 > 0.f ? 1.0f : h1 + 1.0f;
-        if (!act) g1 = 0.f;
-        ab1 += g1;
-        // W1 gradient: row j accumulates g1[j] * h0[k]
+        for (int s = 0; s < 4; ++s) {
+            const int r = 4 * kk + s;
+            aW2 = ct_mfma(S.Sg[r][i16], S.F.H1[r][unit], aW2);
+            const float ga = S.G1[r][unit];
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(S0 + k);
-            aW1[k] = fmaf(g1, v.x, aW1[k]); aW1[k + 1] = fmaf(g1, v.y, aW1[k + 1]);
-            aW1[k + 2] = fmaf(g1, v.z, aW1[k + 2]); aW1[k + 3] = fmaf(g1, v.w, aW1[k + 3]);
+            for (int cb = 0; cb < 4; ++cb) aW1[cb] = ct_mfma(ga, S.F.H0[r][16 * cb + i16], aW1[cb]);
         }
-        S1[lane] = g1;
+        if (tid < 64) {
+#pragma unroll
+            for (int r = 0; r < kCtTile; ++r) ab += S.G1[r][tid];
+        } else if (tid < 80) {
+#pragma unroll
+            for (int r = 0; r < kCtTile; ++r) ab += S.Sg[r][tid - 64];
+        }
+        {   // G0 = (G1 W1) * elu'(z0)
+            const ct_f32x4 c = ct_contract64(S.G1, w1t, i16, kk);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float h0 = S.F.H0[4 * kk + rr][unit];
+                S.G0[4 * kk + rr][unit] = c[rr] * (h0 > 0.f ? 1.0f : h0 + 1.0f);
+            }
+        }
         __syncthreads();
-        // g0[k = lane] = sum_j W1[j][k] g1[j] * elu'(z0)
-        float g0 = ct_dot_lds<H>(w1c, S1) * (h0 > 0.f ? 1.0f : h0 + 1.0f);
-        if (!act) g0 = 0.f;
-        ab0 += g0;
+        // gW0 | gb0 += G0^T [X | 1]
 #pragma unroll
-        for (int d = 0; d < kCtMaxDim + 1; ++d) aW0[d] = fmaf(g0, x[d], aW0[d]);
-        // d loss / d x[1..] of this row (the conditional encoder sees the item sample): sums over the hidden units
-        if (L.cond) {
+        for (int s = 0; s < 4; ++s) aW0 = ct_mfma(S.G0[4 * kk + s][unit], S.F.X[4 * kk + s][i16], aW0);
+        // d loss / d x[1..] of the rows (the conditional encoder sees the item sample): G0 W0[:, 1:]
+        if (L.cond && w == 0) {
+            const ct_f32x4 c = ct_contract64(S.G0, w0t, i16, kk);
 #pragma unroll
-            for (int d = 0; d < kCtMaxDim; ++d)
-                if (d < L.D) {
-                    const float t = wave_total(w0r[1 + d] * g0);
-                    if (lane == 0) scratch[L.s_gx + (size_t)r * kCtMaxDim + d] = t;
-                }
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = r0 + 4 * kk + rr;
+                if (row < L.rows && i16 < L.D) scratch[L.s_gx + (size_t)row * kCtMaxDim + i16] = c[rr];
+            }
         }
-        __syncthreads();            // S0 / S1 / Sg are rewritten by the next row
+        __syncthreads();                // (the next tile rewrites the LDS tiles)
     }
     float* rec = scratch + L.s_mrec + (size_t)blockIdx.x * L.n_mlp;
-    if (act) {
-        for (int d = 0; d < L.xin; ++d) rec[L.w0 + j * L.xin + d] = aW0[d];
-        rec[L.b0 + j] = ab0;
 #pragma unroll
-        for (int k = 0; k < H; ++k) rec[L.w1 + j * H + k] = aW1[k];
-        rec[L.b1 + j] = ab1;
-        for (int q = 0; q < L.O; ++q) rec[L.w2 + q * H + j] = aW2[q];
+    for (int rr = 0; rr < 4; ++rr) {
+        const int jr = 16 * w + 4 * kk + rr;            // hidden unit = row of gW1 / gW0
+        if (jr < L.H) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                if (16 * cb + i16 < L.H) rec[L.w1 + jr * L.H + 16 * cb + i16] = aW1[cb][rr];
+            if (i16 < L.xin) rec[L.w0 + jr * L.xin + i16] = aW0[rr];
+            if (i16 == 15) rec[L.b0 + jr] = aW0[rr];
+        }
+        const int q = 4 * kk + rr;
+        if (q < L.O && unit < L.H) rec[L.w2 + q * L.H + unit] = aW2[rr];
     }
-    if (lane < L.O) rec[L.b2 + lane] = ab2;
+    if (tid < 64) {
+        if (tid < L.H) rec[L.b1 + tid] = ab;
+    } else if (tid < 80) {
+        if (tid - 64 < L.O) rec[L.b2 + tid - 64] = ab;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -550,7 +618,7 @@ using namespace vibo;
 static int ct_check(const vibo_desc* d, int hidden_dim, CtLayout* L) {
     if (!d || d->abi_version != VIBO_ABI_VERSION) return -2;
     if (d->posterior == VIBO_POSTERIOR_GIVEN) return -6;
-    if (hidden_dim != 64 && hidden_dim != 32) return -6;              // (activations of a table row live in registers)
+    if (hidden_dim < 1 || hidden_dim > 64) return -6;                 // (one 64-wide tile of the matrix-pipe MLP kernels; narrower: zero-padded)
     if (d->num_item < 1 || d->ability_dim < 1 || d->ability_dim > VIBO_MAX_ABILITY_DIM || d->n_flows < 0 || d->n_flows > VIBO_MAX_FLOWS) return -3;
     *L = ct_layout(d->num_item, d->ability_dim, d->irt_model, d->posterior == VIBO_POSTERIOR_CONDITIONAL ? 1 : 0, d->n_flows, hidden_dim);
     return 0;
@@ -587,9 +655,7 @@ int vibo_ctrain_prologue(const vibo_desc* d, int hidden_dim, const float* params
     hipLaunchKernelGGL(ct_prologue_kernel, dim3((unsigned)(1 + L.n_ib + ab_blocks)), dim3(kCtItems), 0, s, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const int rpw = ct_rows_per_wave(L.rows);
-    if (hidden_dim == 64) hipLaunchKernelGGL(ct_table_kernel<64>, dim3(L.n_rb), dim3(64), 0, s, L, params, (const float*)item_feat, table, rpw);
-    else hipLaunchKernelGGL(ct_table_kernel<32>, dim3(L.n_rb), dim3(64), 0, s, L, params, (const float*)item_feat, table, rpw);
+    hipLaunchKernelGGL(ct_table_kernel, dim3(L.n_rb), dim3(256), 0, s, L, params, (const float*)item_feat, table, ct_tiles_per_block(L.rows));
     return (int)hipGetLastError();
 }
 
@@ -604,9 +670,8 @@ int vibo_ctrain_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, 
         !item_logvar || !item_m || !item_v || !scratch || !loss_out)
         return -5;
     hipStream_t s = (hipStream_t)stream;
-    const int rpw = ct_rows_per_wave(L.rows);
-    if (hidden_dim == 64) hipLaunchKernelGGL(ct_rows_backward_kernel<64>, dim3(L.n_rb), dim3(64), 0, s, L, (const float*)params, item_feat, flat, beta, scratch, rpw);
-    else hipLaunchKernelGGL(ct_rows_backward_kernel<32>, dim3(L.n_rb), dim3(64), 0, s, L, (const float*)params, item_feat, flat, beta, scratch, rpw);
+    hipLaunchKernelGGL(ct_rows_backward_kernel, dim3(L.n_rb), dim3(256), 0, s, L, (const float*)params, item_feat, flat, beta, scratch,
+                       ct_tiles_per_block(L.rows));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     CtItemParams qi;

@@ -32,7 +32,7 @@ from . import _lib, ops
 def fused_trainer_covers(model, hidden_dim=None):
     """True when one of the fused trainers of this module runs the model's whole train step natively: the product-of-experts
     encoder with the IRT decoder -- plain (FusedTrainer's kernels), or with the conditional posterior and / or planar flows
-    (FusedCondFlowTrainer's, hidden width 64 or 32) -- or the --ability-merge mean encoder with the unconditional posterior
+    (FusedCondFlowTrainer's, hidden width <= 64) -- or the --ability-merge mean encoder with the unconditional posterior
     (FusedMeanTrainer's, one GPU).  The MLP decoders and mean x conditional train through the module + torch.optim.Adam."""
     if getattr(model, 'generative_model', 'irt') != 'irt':
         return False
@@ -44,7 +44,7 @@ def fused_trainer_covers(model, hidden_dim=None):
         return False
     if model.conditional_posterior or model.n_norm_flows > 0:
         H = hidden_dim if hidden_dim is not None else model.ability_encoder.mlp[0].weight.shape[0]
-        return H in (32, 64) and model.ability_dim <= _lib.MAX_ABILITY_DIM_FAST      # (vibo_ctrain_*: 8 ability dims)
+        return H <= 64 and model.ability_dim <= _lib.MAX_ABILITY_DIM_FAST      # (vibo_ctrain_*: one 64-wide tile, 8 ability dims)
     return True
 
 
@@ -276,9 +276,9 @@ class FusedCondFlowTrainer(FusedTrainer):
         self.model = model
         mlp = model.ability_encoder.mlp
         self.hidden = mlp[0].weight.shape[0]
-        if self.hidden not in (32, 64):
-            raise NotImplementedError('FusedCondFlowTrainer: hidden_dim 64 or 32 (the rows of the expert table keep their '
-                                      'activations in registers); use model.elbo_step + torch.optim.Adam otherwise')
+        if self.hidden > 64:
+            raise NotImplementedError('FusedCondFlowTrainer: hidden_dim <= 64 (one 64-wide tile of the matrix-pipe table MLP); '
+                                      'use model.elbo_step + torch.optim.Adam otherwise')
         plist = [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, mlp[4].weight, mlp[4].bias]
         F = model.n_norm_flows
         if F > 0:
