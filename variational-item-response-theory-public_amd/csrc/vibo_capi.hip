@@ -10,6 +10,7 @@
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
 #include "vibo_cond.hpp"
+#include "vibo_cond_finalize.hpp"
 #include "vibo_finalize.hpp"
 #include "vibo_general.hpp"
 #include "vibo_launch.hpp"
@@ -594,6 +595,11 @@ __global__ __launch_bounds__(256) void pack_codes4_kernel(const float* __restric
 template <int OUT>
 __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeParams f) {
     constexpr int SLICES = 1024 / OUT;
+    __shared__ __attribute__((aligned(16))) double part[SLICES][OUT];
+    if ((int)blockIdx.x >= f.n_fin) {      // the conditional posterior's table gradients (vibo_cond_finalize.hpp)
+        cond_fin_tail_body(f.tail, (int)blockIdx.x - f.n_fin, &part[0][0]);
+        return;
+    }
     // element e of the logical output vector: [0,8) scalars | table grads | flow grads | item grads
     const int n_tab = 8 * f.A;
     const int n_flow = 2 * f.n_flows * (2 * f.A + 1);
@@ -601,7 +607,6 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeParams f) 
     const int n_out = 8 + (f.want_grad ? n_tab + n_flow + n_item : 0);
     const int lane = threadIdx.x % OUT, slice = threadIdx.x / OUT;
     const int e = blockIdx.x * OUT + lane;
-    __shared__ double part[SLICES][OUT];
     double acc = 0.0;
     if (e < n_out) {
         int src, b0 = 0, b1 = f.nblk;
@@ -934,6 +939,8 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
     if ((uintptr_t)workspace & 255) return fail(-7, "workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int I = d->num_item, A = d->ability_dim;
+    CondFinTail tail;                  // the conditional posterior's last stage, launched with the ELBO finalize
+    memset(&tail, 0, sizeof(tail));
     // 16-byte row loads need aligned rows
     const bool vec = rows_vec_ok(d, response, mask);
     bool codes = d->mask_dtype == VIBO_MASK_CODES;      // (panel mode on fp32 rows: true from the second pass on, see off_codes)
@@ -1105,7 +1112,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             if (pl.cmat_post) {
                 if (e == hipSuccess)
                     e = launch_cond_post_mfma(static_cast<const uint8_t*>(cp.mask), cp.mask_stride, cp.row_index, d->num_person, I, A, table,
-                                              coef, grad_table, mscratch, s);
+                                              coef, grad_table, mscratch, s, &tail);
             } else {
                 for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
                     cp.item0 = pn * 1024;
@@ -1114,7 +1121,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
                     for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4)
                         e = launch_cond_post(cp, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, pl.cond_post_nblk, s);
                 }
-                if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.cond_post_nblk, pl.cond_rec, s);
+                if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.cond_post_nblk, pl.cond_rec, s, &tail);
             }
         }
         if (pl.given && grad && e == hipSuccess) {
@@ -1150,9 +1157,16 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
     f.irt = d->irt_model; f.want_grad = grad ? 1 : 0; f.lay = pl.lay;
     f.panel_items = panel_items; f.bpp = bpp ? bpp : nblk_used;
     const int n_out = 8 + (grad ? 8 * A + 2 * d->n_flows * (2 * A + 1) + I * pl.D : 0);
-    if (f.bpp >= 1024 || n_out <= 64)      // many small records, or the 8 scalars of a forward-only call: more slices per output
-        hipLaunchKernelGGL(finalize_kernel<16>, dim3((n_out + 15) / 16), dim3(1024), 0, s, f);
-    else hipLaunchKernelGGL(finalize_kernel<64>, dim3((n_out + 63) / 64), dim3(1024), 0, s, f);
+    // (the conditional posterior's table-gradient finalize rides in the same launch: workgroups past n_fin)
+    f.tail = tail;
+    const int n_tail = tail.kind ? tail.gx * tail.gy : 0;
+    if (f.bpp >= 1024 || n_out <= 64) {    // many small records, or the 8 scalars of a forward-only call: more slices per output
+        f.n_fin = (n_out + 15) / 16;
+        hipLaunchKernelGGL(finalize_kernel<16>, dim3(f.n_fin + n_tail), dim3(1024), 0, s, f);
+    } else {
+        f.n_fin = (n_out + 63) / 64;
+        hipLaunchKernelGGL(finalize_kernel<64>, dim3(f.n_fin + n_tail), dim3(1024), 0, s, f);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "finalize launch");
     return 0;

@@ -36,6 +36,8 @@
 #include "../../include/vibo_hip.h"
 #include "vibo_device.hpp"
 #include "vibo_cond.hpp"
+#include "vibo_cond_finalize.hpp"
+#include <string.h>
 
 namespace vibo {
 
@@ -522,51 +524,10 @@ __global__ __launch_bounds__(256) void cm_backward_reduce_kernel(const float* __
     for (; r < nR; ++r) a[0] += rp[(size_t)r * rs];
     dX[t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
-// conditional posterior: S1, S2 per (head, code, item, dim) from the records -> grad_table[head][code][I][mu dims | logvar dims]
-//   d/d mu = S1 tau,  d/d logvar = -(S1 mu + S2) tau^2 exp(logvar)       (the chain through utils.py:105-113)
-// One workgroup per (stripe S, quarter g' of its 128 record columns = 16 items x 2 codes): the records' 32 x N block is summed
-// over the person ranges with whole-row loads (fixed order), the chain rule runs on the sums in LDS.
-__global__ __launch_bounds__(1024) void cm_cond_finalize_kernel(const float* __restrict__ rec, const float* __restrict__ table,
-                                                                float* __restrict__ grad_table, int I, int A, int nR, int N) {
-    __shared__ float part[1024];
-    __shared__ float sum[32 * 32];
-    const int S = blockIdx.x, gq = blockIdx.y, tid = threadIdx.x;
-    const int E = 32 * N, nsl = 1024 / E;            // E = 512 or 1024 record values of this quarter; nsl person-range slices
-    {
-        const int e = tid % E, sl = tid / E;
-        const float* q = rec + ((size_t)S * nR * 128 + 32 * gq) * N + e;
-        const size_t rs = (size_t)128 * N;
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int r = sl;
-        for (; r + 7 * nsl < nR; r += 8 * nsl) {         // 8 loads in flight per thread
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += q[(size_t)(r + u * nsl) * rs];
-        }
-        for (; r < nR; r += nsl) a[0] += q[(size_t)r * rs];
-        part[tid] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
-    __syncthreads();
-    if (tid < E) {
-        float t = part[tid];
-        for (int sl = 1; sl < nsl; ++sl) t += part[sl * E + tid];
-        sum[tid] = t;
-    }
-    __syncthreads();
-    for (int e = tid; e < 32 * A; e += 1024) {
-        const int a = e % A, col = e / A;                 // col = 8 j + kk: item 64 S + 16 g' + 4 j + (kk >> 1), code kk & 1
-        const int item = 64 * S + 16 * gq + 4 * (col >> 3) + ((col & 7) >> 1), c = col & 1;
-        if (item >= I) continue;
-        const float* sp = sum + col * N;
-        const float* te = table + ((size_t)c * I + item) * 2 * A;
-        const float es = expf(te[A + a]), tau = 1.0f / (es + kPoeEps), mu = te[a];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float s1 = sp[(2 * h) * A + a], s2 = sp[(2 * h + 1) * A + a];
-            float* go = grad_table + ((size_t)(h * 2 + c) * I + item) * 2 * A;
-            go[a] = s1 * tau;
-            go[A + a] = -(s1 * mu + s2) * tau * tau * es;
-        }
-    }
+// conditional posterior: S1, S2 per (head, code, item, dim) from the records -> grad_table: vibo_cond_finalize.hpp
+__global__ __launch_bounds__(1024) void cm_cond_finalize_kernel(const CondFinTail t) {
+    __shared__ __attribute__((aligned(16))) float smem[2048];
+    cm_cond_finalize_body(t, blockIdx.x, blockIdx.y, smem);
 }
 
 // ~2048 workgroups: nS item stripes x nR person ranges of a multiple of 64 persons; nR a multiple of 8 where the persons
@@ -662,7 +623,8 @@ hipError_t launch_cond_pre_mfma(const uint8_t* codes, long long stride, const in
 }
 // grad_table[2 heads][2][I][2A] from the per-person coefficients coef[B][4A] = [head][P1 | P2][dim]
 hipError_t launch_cond_post_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,
-                                 const float* table, const float* coef, float* grad_table, void* scratch, hipStream_t s) {
+                                 const float* table, const float* coef, float* grad_table, void* scratch, hipStream_t s,
+                                 CondFinTail* defer) {
     const int nS = (I + 63) / 64;
     const int NT = (4 * A + 15) / 16;
     char* base = static_cast<char*>(scratch) + cm_timg_bytes(nS, 1);
@@ -675,7 +637,11 @@ hipError_t launch_cond_post_mfma(const uint8_t* codes, long long stride, const i
     int nR = 0;
     e = cm_launch_backward(NT, codes, stride, row_index, B, I, nS, gimg, rec, s, &nR);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cm_cond_finalize_kernel, dim3(nS, 4), dim3(1024), 0, s, (const float*)rec, table, grad_table, I, A, nR, 16 * NT);
+    CondFinTail t;
+    memset(&t, 0, sizeof(t));
+    t.kind = 2; t.gx = nS; t.gy = 4; t.rec = rec; t.table = table; t.grad_table = grad_table; t.I = I; t.A = A; t.nR = nR; t.N = 16 * NT;
+    if (defer) { *defer = t; return hipSuccess; }        // (rides in the ELBO finalize launch)
+    hipLaunchKernelGGL(cm_cond_finalize_kernel, dim3(nS, 4), dim3(1024), 0, s, t);
     return hipGetLastError();
 }
 

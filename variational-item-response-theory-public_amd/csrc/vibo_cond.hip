@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/vibo_hip.h"
 #include "vibo_cond.hpp"
+#include "vibo_cond_finalize.hpp"
+#include <string.h>
 #include "vibo_device.hpp"
 #include "vibo_split_kernel.hpp"
 
@@ -302,29 +304,10 @@ __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_
     }
 }
 
-// grad_table[head][code][i][j2] = sum over the panel's workgroup records (fp64, fixed order)
-__global__ __launch_bounds__(1024) void cond_finalize_kernel(const float* __restrict__ partial, float* __restrict__ grad_table,
-                                                             int I, int A, int panels, int bpp, int rec_stride) {
-    __shared__ double part[16][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int hcj = blockIdx.y;                       // (head * 2 + code) * 2A + j2
-    const int i = blockIdx.x * 64 + lane;
-    double acc = 0.0;
-    if (i < I) {
-        const int pn = i >> 10, local = i & 1023;
-        const float* src = partial + (size_t)pn * bpp * rec_stride + (size_t)hcj * 1024 + local;
-        for (int b = slice; b < bpp; b += 16) acc += (double)src[(size_t)b * rec_stride];
-    }
-    part[slice][lane] = acc;
-    __syncthreads();
-    if (slice == 0 && i < I) {
-        double t = 0.0;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) t += part[s][lane];
-        const int hc = hcj / (2 * A), j2 = hcj % (2 * A);
-        grad_table[((size_t)hc * I + i) * 2 * A + j2] = (float)t;
-    }
-    (void)panels;
+// grad_table[head][code][i][j2] = sum over the panel's workgroup records (fp64, fixed order): vibo_cond_finalize.hpp
+__global__ __launch_bounds__(1024) void cond_finalize_kernel(const CondFinTail t) {
+    __shared__ __attribute__((aligned(16))) double smem[1024];
+    cond_finalize_body(t, blockIdx.x, blockIdx.y, smem);
 }
 
 hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
@@ -356,9 +339,14 @@ hipError_t launch_cond_post(const CondParams& p, int at, int nq, int grid, hipSt
     return hipGetLastError();
 }
 hipError_t launch_cond_finalize(const float* partial, float* grad_table, int I, int A, int panels, int bpp, int rec_stride,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(cond_finalize_kernel, dim3((I + 63) / 64, 2 * 2 * 2 * A), dim3(1024), 0, s, partial, grad_table, I, A,
-                       panels, bpp, rec_stride);
+                                hipStream_t s, CondFinTail* defer) {
+    CondFinTail t;
+    memset(&t, 0, sizeof(t));
+    t.kind = 1; t.gx = (I + 63) / 64; t.gy = 2 * 2 * 2 * A; t.rec = partial; t.grad_table = grad_table; t.I = I; t.A = A;
+    t.bpp = bpp; t.rec_stride = rec_stride;
+    (void)panels;
+    if (defer) { *defer = t; return hipSuccess; }        // (rides in the ELBO finalize launch)
+    hipLaunchKernelGGL(cond_finalize_kernel, dim3(t.gx, t.gy), dim3(1024), 0, s, t);
     return hipGetLastError();
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "vibo_params.hpp"
 
 namespace vibo {
 
@@ -22,14 +23,16 @@ struct CondParams {
 
 hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s);
 hipError_t launch_cond_post(const CondParams& p, int at, int nq, int grid, hipStream_t s);
+// defer != nullptr: nothing is launched, *defer describes the job for the ELBO finalize launch (FinalizeParams::tail)
 hipError_t launch_cond_finalize(const float* partial, float* grad_table, int I, int A, int panels, int bpp, int rec_stride,
-                                hipStream_t s);
+                                hipStream_t s, CondFinTail* defer = nullptr);
 
 // the same two passes on the matrix pipe, all items in one launch, rows as 1-byte cell codes (vibo_cmean.hip)
 size_t cond_mfma_scratch_bytes(long long B, int I, int A);
 hipError_t launch_cond_pre_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,
                                 const float* table, float* pre, void* scratch, hipStream_t s);
 hipError_t launch_cond_post_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,
-                                 const float* table, const float* coef, float* grad_table, void* scratch, hipStream_t s);
+                                 const float* table, const float* coef, float* grad_table, void* scratch, hipStream_t s,
+                                 CondFinTail* defer = nullptr);
 
 }  // namespace vibo

@@ -77,6 +77,18 @@ struct ElboParams {
     int32_t* step_tick;       // non-null: workgroup 0 increments it (the train step's Adam counter, vibo_elbo_fwd_bwd_step)
 };
 
+// the conditional posterior's table-gradient finalize riding in the ELBO finalize launch (vibo_cond_finalize.hpp)
+struct CondFinTail {
+    int kind;                 // 0: none, 1: cond_post_kernel's records (VALU pass), 2: cm_backward_kernel's (matrix-pipe pass)
+    int gx, gy;               // its grid
+    const float* rec;
+    const float* table;       // kind 2: the expert table (chain rule through the product of experts)
+    float* grad_table;
+    int I, A;
+    int bpp, rec_stride;      // kind 1
+    int nR, N;                // kind 2
+};
+
 struct FinalizeParams {
     const float* partial;
     float* out_scalars;
@@ -86,6 +98,8 @@ struct FinalizeParams {
     int nblk, I, A, D, n_flows, reg_mode, irt, want_grad;
     int panel_items, bpp;     // item grads of item i live in blocks [i / panel_items * bpp, +bpp) (panel mode)
     PartialLayout lay;
+    int n_fin;                // workgroups of the finalize proper; the ones past them run `tail`
+    CondFinTail tail;
 };
 
 // launch parameters of train_epilogue_fused_kernel (vibo_trainer.hip; host side: vibo_train_epilogue_fused in vibo_capi.hip)
