@@ -35,7 +35,7 @@ struct CtLayout {
     int w0, b0, w1, b1, w2, b2, n_mlp, fa, fi, n_par;      // offsets into the flat parameter buffer
     int n_rb, n_ib;                                        // row blocks, item blocks
     // scratch (floats)
-    size_t s_pack, s_tanh, s_parts, s_gx, s_mrec, s_frec, s_total;
+    size_t s_pack, s_tanh, s_parts, s_gx, s_mrec, s_frec, s_gz, s_total;
 };
 __host__ __device__ inline CtLayout ct_layout(int I, int A, int irt, int cond, int F, int H) {
     CtLayout L;
@@ -55,6 +55,7 @@ __host__ __device__ inline CtLayout ct_layout(int I, int A, int irt, int cond, i
     L.s_gx = take((size_t)L.rows * kCtMaxDim);
     L.s_mrec = take((size_t)L.n_rb * L.n_mlp);
     L.s_frec = take((size_t)L.n_ib * (F > 0 ? F : 1) * (2 * L.D + 1));
+    L.s_gz = take((size_t)I * kCtMaxDim);      // flows: d loss / d item_feat behind the item-side flows (ct_backward_kernel -> ct_update_kernel)
     L.s_total = o;
     return L;
 }
@@ -105,10 +106,7 @@ __device__ __forceinline__ void ct_adam(float& p, float& m, float& v, const floa
     p -= (lr / bc1) * (m / denom);
 }
 
-// ---------------------------------------------------------------------------
-// prologue: block 0 = flow packing (+ step counter); blocks 1..n_ib = items (sample, flows forward, partial sums);
-// further blocks = ability noise
-// ---------------------------------------------------------------------------
+// parameters of the prologue launch (ct_prologue_kernel, after the table tiles below)
 struct CtProParams {
     CtLayout L;
     const float* params; const float* mu; const float* lv;
@@ -117,8 +115,133 @@ struct CtProParams {
     int32_t* step_count;
     int gen; uint32_t seed_lo, seed_hi;
     float* eps_ab; long long n_ab; uint32_t ab_stream;
+    float* table; int ab_blocks, tpb;
 };
 
+// ---------------------------------------------------------------------------
+// table rows [c, item_i] (or [c]) on the matrix pipe: tiles of 16 rows, one workgroup of four waves per tile (a workgroup
+// walks `tpb` tiles when there are more than 512 of them), every contraction of the 64-wide MLP as v_mfma_f32_16x16x4_f32
+// (fp32 operands: no splitting, results of fp32 grade by construction).  Hidden widths below 64 run zero-padded.
+//   operand layouts of one 16x16x4 step (lane = 16 kk + i16):  A[i16][kk], B[kk][i16], C: register r' = C[4 kk + r'][i16]
+//   K = 64 contractions walk k = 16 kk + s over 16 steps (each lane reads 16 consecutive floats of its row / loads 16
+//   consecutive weights once per workgroup), K = 16 (rows of the tile, or outputs) walk k = 4 kk + s over 4 steps.
+// (Round 3's version -- one wave per 8 rows, lane = hidden unit, dot products on the VALU through LDS broadcasts -- took
+//  13 us forward and 25 us backward for 2 000 rows; it is gone.)
+// ---------------------------------------------------------------------------
+typedef float ct_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ct_f32x4 ct_mfma(const float a, const float b, const ct_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+constexpr int kCtLd = 68;               // LDS row stride (floats) of the 16 x 64 tiles
+struct CtTileLds {
+    float X[kCtTile][16];               // inputs [c | item_feat | 0 ...], column 15 = 1 (bias column of the W0-gradient contraction)
+    float H0[kCtTile][kCtLd];
+    float H1[kCtTile][kCtLd];
+};
+// the weights a lane keeps for the forward of a tile
+struct CtFwdRegs {
+    float w0r[kCtMaxDim + 1];           // row j = tid & 63 of W0
+    float b0j;
+    float b1v[16];                      // W1[16 w + i16][16 kk + s]
+    float b1u;                          // b1[16 w + i16]
+};
+__device__ __forceinline__ void ct_load_fwd(const CtLayout& L, const float* __restrict__ P, const int tid, CtFwdRegs& R) {
+    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, j = tid & 63, unit = 16 * w + i16;
+#pragma unroll
+    for (int d = 0; d < kCtMaxDim + 1; ++d) R.w0r[d] = (j < L.H && d < L.xin) ? P[L.w0 + j * L.xin + d] : 0.f;
+    R.b0j = j < L.H ? P[L.b0 + j] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) R.b1v[s] = (unit < L.H && 16 * kk + s < L.H) ? P[L.w1 + unit * L.H + 16 * kk + s] : 0.f;
+    R.b1u = unit < L.H ? P[L.b1 + unit] : 0.f;
+}
+// K = 64 contraction: A = row i16 of a 16 x 64 LDS tile, B = the lane's 16 weights (two accumulator chains)
+__device__ __forceinline__ ct_f32x4 ct_contract64(const float (*T)[kCtLd], const float (&bw)[16], const int i16, const int kk) {
+    ct_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 v = *reinterpret_cast<const float4*>(&T[i16][16 * kk + 4 * s4]);
+        a0 = ct_mfma(v.x, bw[4 * s4], a0);
+        a1 = ct_mfma(v.y, bw[4 * s4 + 1], a1);
+        a0 = ct_mfma(v.z, bw[4 * s4 + 2], a0);
+        a1 = ct_mfma(v.w, bw[4 * s4 + 3], a1);
+    }
+    return a0 + a1;
+}
+// rows r0 .. r0 + 15: inputs and layer 0 on the VALU, layer 1 on the matrix pipe; leaves X, H0, H1 in LDS (the caller
+// synchronises before reading H1) and the lane's piece of H1 in h1c (rows 4 kk + r' of column 16 w + i16)
+// feat(i, d): entry d of item i's sample (an array read, or -- in the prologue launch -- the sample formed on the spot)
+template <class Feat>
+__device__ __forceinline__ void ct_tile_forward(const CtLayout& L, const Feat& feat, const int r0, CtTileLds& S,
+                                                const CtFwdRegs& R, ct_f32x4& h1c, const int tid) {
+    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, unit = 16 * w + i16;
+    {
+        const int r = tid >> 4, d = tid & 15, row = r0 + r;
+        float x = 0.f;
+        if (row < L.rows) {
+            if (L.cond) {
+                const int c = row / L.I, i = row - c * L.I;
+                x = d == 0 ? (float)c : (d <= L.D ? feat(i, d - 1) : 0.f);
+            } else {
+                x = d == 0 ? (float)row : 0.f;
+            }
+        }
+        S.X[r][d] = d == 15 ? 1.0f : x;
+    }
+    __syncthreads();
+    {
+        const int j = tid & 63;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = (tid >> 6) + 4 * m;
+            float a = R.b0j;
+#pragma unroll
+            for (int d = 0; d < kCtMaxDim + 1; ++d) a = fmaf(R.w0r[d], S.X[r][d], a);
+            S.H0[r][j] = j < L.H ? ct_elu(a) : 0.f;
+        }
+    }
+    __syncthreads();
+    const ct_f32x4 c = ct_contract64(S.H0, R.b1v, i16, kk);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const float h = unit < L.H ? ct_elu(c[rr] + R.b1u) : 0.f;
+        h1c[rr] = h;
+        S.H1[4 * kk + rr][unit] = h;
+    }
+}
+
+template <class Feat>
+__device__ __forceinline__ void ct_table_body(const CtLayout& L, const float* __restrict__ P, const Feat& feat, float* __restrict__ table,
+                                              const int tpb, const int block, CtTileLds& S) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
+    CtFwdRegs R;
+    ct_load_fwd(L, P, tid, R);
+    float w2v[16];                      // wave 0: W2[q = i16][16 kk + s]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w2v[s] = (w == 0 && i16 < L.O && 16 * kk + s < L.H) ? P[L.w2 + i16 * L.H + 16 * kk + s] : 0.f;
+    const float b2q = i16 < L.O ? P[L.b2 + i16] : 0.f;
+    for (int t = 0; t < tpb; ++t) {
+        const int r0 = (block * tpb + t) * kCtTile;
+        if (r0 >= L.rows) break;
+        ct_f32x4 h1c;
+        ct_tile_forward(L, feat, r0, S, R, h1c, tid);
+        __syncthreads();
+        if (w == 0) {
+            const ct_f32x4 c = ct_contract64(S.H1, w2v, i16, kk);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = r0 + 4 * kk + rr;
+                if (row < L.rows && i16 < L.O) table[(size_t)row * L.O + i16] = c[rr] + b2q;
+            }
+        }
+        __syncthreads();                // (the next tile rewrites X / H0 / H1)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// prologue launch: block 0 = flow packing (+ step counter); blocks 1..n_ib = items (sample, flows forward, partial sums);
+// then ab_blocks of ability noise; then the tiles of the expert table (they form the item sample of their 16 rows themselves,
+// with the item blocks' statements: no wait for them -- round 3 ran the table as a launch of its own)
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kCtItems) void ct_prologue_kernel(const CtProParams q) {
     const CtLayout& L = q.L;
     __shared__ float pk[VIBO_MAX_FLOWS][2 * kCtMaxDim + 2];
@@ -132,6 +255,17 @@ __global__ __launch_bounds__(kCtItems) void ct_prologue_kernel(const CtProParams
             ct_pack_flow(q.params + L.fa + tid * (2 * A + 1), A, o);
             for (int e = 0; e < 2 * A + 1; ++e) q.flow_packed[tid * (2 * A + 1) + e] = o[e];
         }
+        return;
+    }
+    if ((int)blockIdx.x > L.n_ib + q.ab_blocks) {    // expert-table tiles
+        __shared__ __attribute__((aligned(16))) CtTileLds S;
+        const uint32_t ctr = (uint32_t)q.step_count[1];
+        auto feat = [&](const int i, const int d) -> float {
+            const int idx = i * D + d;
+            const float e = q.gen ? philox_normal1(idx, ctr, 0u, q.seed_lo, q.seed_hi) : q.eps[idx];
+            return fmaf(expf(0.5f * q.lv[idx]), e, q.mu[idx]);
+        };
+        ct_table_body(L, q.params, feat, q.table, q.tpb, (int)blockIdx.x - 1 - L.n_ib - q.ab_blocks, S);
         return;
     }
     if ((int)blockIdx.x > L.n_ib) {                  // ability noise (stream ab_stream), 4 normals per thread
@@ -189,123 +323,6 @@ __global__ __launch_bounds__(kCtItems) void ct_prologue_kernel(const CtProParams
     if (tid < 3) q.scratch[L.s_parts + (size_t)(blockIdx.x - 1) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-// ---------------------------------------------------------------------------
-// table rows [c, item_i] (or [c]) on the matrix pipe: tiles of 16 rows, one workgroup of four waves per tile (a workgroup
-// walks `tpb` tiles when there are more than 512 of them), every contraction of the 64-wide MLP as v_mfma_f32_16x16x4_f32
-// (fp32 operands: no splitting, results of fp32 grade by construction).  Hidden widths below 64 run zero-padded.
-//   operand layouts of one 16x16x4 step (lane = 16 kk + i16):  A[i16][kk], B[kk][i16], C: register r' = C[4 kk + r'][i16]
-//   K = 64 contractions walk k = 16 kk + s over 16 steps (each lane reads 16 consecutive floats of its row / loads 16
-//   consecutive weights once per workgroup), K = 16 (rows of the tile, or outputs) walk k = 4 kk + s over 4 steps.
-// (Round 3's version -- one wave per 8 rows, lane = hidden unit, dot products on the VALU through LDS broadcasts -- took
-//  13 us forward and 25 us backward for 2 000 rows; it is gone.)
-// ---------------------------------------------------------------------------
-typedef float ct_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ ct_f32x4 ct_mfma(const float a, const float b, const ct_f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-constexpr int kCtLd = 68;               // LDS row stride (floats) of the 16 x 64 tiles
-struct CtTileLds {
-    float X[kCtTile][16];               // inputs [c | item_feat | 0 ...], column 15 = 1 (bias column of the W0-gradient contraction)
-    float H0[kCtTile][kCtLd];
-    float H1[kCtTile][kCtLd];
-};
-// the weights a lane keeps for the forward of a tile
-struct CtFwdRegs {
-    float w0r[kCtMaxDim + 1];           // row j = tid & 63 of W0
-    float b0j;
-    float b1v[16];                      // W1[16 w + i16][16 kk + s]
-    float b1u;                          // b1[16 w + i16]
-};
-__device__ __forceinline__ void ct_load_fwd(const CtLayout& L, const float* __restrict__ P, const int tid, CtFwdRegs& R) {
-    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, j = tid & 63, unit = 16 * w + i16;
-#pragma unroll
-    for (int d = 0; d < kCtMaxDim + 1; ++d) R.w0r[d] = (j < L.H && d < L.xin) ? P[L.w0 + j * L.xin + d] : 0.f;
-    R.b0j = j < L.H ? P[L.b0 + j] : 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) R.b1v[s] = (unit < L.H && 16 * kk + s < L.H) ? P[L.w1 + unit * L.H + 16 * kk + s] : 0.f;
-    R.b1u = unit < L.H ? P[L.b1 + unit] : 0.f;
-}
-// K = 64 contraction: A = row i16 of a 16 x 64 LDS tile, B = the lane's 16 weights (two accumulator chains)
-__device__ __forceinline__ ct_f32x4 ct_contract64(const float (*T)[kCtLd], const float (&bw)[16], const int i16, const int kk) {
-    ct_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const float4 v = *reinterpret_cast<const float4*>(&T[i16][16 * kk + 4 * s4]);
-        a0 = ct_mfma(v.x, bw[4 * s4], a0);
-        a1 = ct_mfma(v.y, bw[4 * s4 + 1], a1);
-        a0 = ct_mfma(v.z, bw[4 * s4 + 2], a0);
-        a1 = ct_mfma(v.w, bw[4 * s4 + 3], a1);
-    }
-    return a0 + a1;
-}
-// rows r0 .. r0 + 15: inputs and layer 0 on the VALU, layer 1 on the matrix pipe; leaves X, H0, H1 in LDS (the caller
-// synchronises before reading H1) and the lane's piece of H1 in h1c (rows 4 kk + r' of column 16 w + i16)
-__device__ __forceinline__ void ct_tile_forward(const CtLayout& L, const float* __restrict__ item_feat, const int r0, CtTileLds& S,
-                                                const CtFwdRegs& R, ct_f32x4& h1c, const int tid) {
-    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, unit = 16 * w + i16;
-    {
-        const int r = tid >> 4, d = tid & 15, row = r0 + r;
-        float x = 0.f;
-        if (row < L.rows) {
-            if (L.cond) {
-                const int c = row / L.I, i = row - c * L.I;
-                x = d == 0 ? (float)c : (d <= L.D ? item_feat[(size_t)i * L.D + d - 1] : 0.f);
-            } else {
-                x = d == 0 ? (float)row : 0.f;
-            }
-        }
-        S.X[r][d] = d == 15 ? 1.0f : x;
-    }
-    __syncthreads();
-    {
-        const int j = tid & 63;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int r = (tid >> 6) + 4 * m;
-            float a = R.b0j;
-#pragma unroll
-            for (int d = 0; d < kCtMaxDim + 1; ++d) a = fmaf(R.w0r[d], S.X[r][d], a);
-            S.H0[r][j] = j < L.H ? ct_elu(a) : 0.f;
-        }
-    }
-    __syncthreads();
-    const ct_f32x4 c = ct_contract64(S.H0, R.b1v, i16, kk);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const float h = unit < L.H ? ct_elu(c[rr] + R.b1u) : 0.f;
-        h1c[rr] = h;
-        S.H1[4 * kk + rr][unit] = h;
-    }
-}
-
-__global__ __launch_bounds__(256) void ct_table_kernel(const CtLayout L, const float* __restrict__ P, const float* __restrict__ item_feat,
-                                                       float* __restrict__ table, int tpb) {
-    __shared__ __attribute__((aligned(16))) CtTileLds S;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
-    CtFwdRegs R;
-    ct_load_fwd(L, P, tid, R);
-    float w2v[16];                      // wave 0: W2[q = i16][16 kk + s]
-#pragma unroll
-    for (int s = 0; s < 16; ++s) w2v[s] = (w == 0 && i16 < L.O && 16 * kk + s < L.H) ? P[L.w2 + i16 * L.H + 16 * kk + s] : 0.f;
-    const float b2q = i16 < L.O ? P[L.b2 + i16] : 0.f;
-    for (int t = 0; t < tpb; ++t) {
-        const int r0 = (blockIdx.x * tpb + t) * kCtTile;
-        if (r0 >= L.rows) break;
-        ct_f32x4 h1c;
-        ct_tile_forward(L, item_feat, r0, S, R, h1c, tid);
-        __syncthreads();
-        if (w == 0) {
-            const ct_f32x4 c = ct_contract64(S.H1, w2v, i16, kk);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = r0 + 4 * kk + rr;
-                if (row < L.rows && i16 < L.O) table[(size_t)row * L.O + i16] = c[rr] + b2q;
-            }
-        }
-        __syncthreads();                // (the next tile rewrites X / H0 / H1)
-    }
-}
-
 // backward of the table rows: d loss / d table = -dLL + coef dREG (flat: [8 scalars | grad_table set 0 | set 1 | ...]);
 // one partial record of MLP-parameter gradients per workgroup (fixed order), d loss / d item_feat of the row -> gx
 struct CtBwdLds {
@@ -314,15 +331,15 @@ struct CtBwdLds {
     float G0[kCtTile][kCtLd];           // d loss / d (layer-0 pre-activation)
     float Sg[kCtTile][16];              // d loss / d table row (zero past O)
 };
-__global__ __launch_bounds__(256) void ct_rows_backward_kernel(const CtLayout L, const float* __restrict__ P, const float* __restrict__ item_feat,
-                                                               const float* __restrict__ flat, const float* __restrict__ beta_p,
-                                                               float* __restrict__ scratch, int tpb) {
-    __shared__ __attribute__((aligned(16))) CtBwdLds S;
+__device__ __forceinline__ void ct_rows_backward_body(const CtLayout& L, const float* __restrict__ P, const float* __restrict__ item_feat,
+                                                      const float* __restrict__ flat, const float* __restrict__ beta_p,
+                                                      float* __restrict__ scratch, const int tpb, const int block, CtBwdLds& S) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, unit = 16 * w + i16;
     const float coef = L.F > 0 ? 1.0f : *beta_p;            // (flows: the annealing factor is ignored, models.py:406-424)
     const size_t n_table = (size_t)L.rows * L.O;
     CtFwdRegs R;
     ct_load_fwd(L, P, tid, R);
+    auto feat = [&](const int i, const int d) -> float { return item_feat[(size_t)i * L.D + d]; };
     float w1t[16], w2t[4], w0t[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(256) void ct_rows_backward_kernel(const CtLayout L,
     ct_f32x4 aW0 = zero4;                                    // gW0[16 w + 4 kk + r'][d = i16], d = 15: gb0
     float ab = 0.f;                                          // tid < 64: gb1[tid]; 64 <= tid < 80: gb2[tid - 64]
     for (int t = 0; t < tpb; ++t) {
-        const int r0 = (blockIdx.x * tpb + t) * kCtTile;
+        const int r0 = (block * tpb + t) * kCtTile;
         if (r0 >= L.rows) break;
         {
             const int r = tid >> 4, q = tid & 15, row = r0 + r;
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(256) void ct_rows_backward_kernel(const CtLayout L,
             S.Sg[r][q] = g;
         }
         ct_f32x4 h1c;
-        ct_tile_forward(L, item_feat, r0, S.F, R, h1c, tid);          // (its barriers publish Sg as well)
+        ct_tile_forward(L, feat, r0, S.F, R, h1c, tid);          // (its barriers publish Sg as well)
         {   // G1 = (gO W2) * elu'(z1)   (elu'(z) = 1 | e^z = h + 1)
             ct_f32x4 c = zero4;
             const float4 v = *reinterpret_cast<const float4*>(&S.Sg[i16][4 * kk]);
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(256) void ct_rows_backward_kernel(const CtLayout L,
         }
         __syncthreads();                // (the next tile rewrites the LDS tiles)
     }
-    float* rec = scratch + L.s_mrec + (size_t)blockIdx.x * L.n_mlp;
+    float* rec = scratch + L.s_mrec + (size_t)block * L.n_mlp;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int jr = 16 * w + 4 * kk + rr;            // hidden unit = row of gW1 / gW0
@@ -428,30 +445,33 @@ struct CtItemParams {
     float* mu; float* lv; float* im; float* iv;
     float* scratch;
 };
-__global__ __launch_bounds__(kCtItems) void ct_item_backward_kernel(const CtItemParams q) {
+// flows (F > 0): d loss / d item_k back through the item-side planar flows -> s_gz, and this block's flow-parameter records
+__device__ __forceinline__ void ct_item_flows_backward_body(const CtItemParams& q, const int block) {
     const CtLayout& L = q.L;
     __shared__ float pk[VIBO_MAX_FLOWS][2 * kCtMaxDim + 2];
     __shared__ float red[4][2 * kCtMaxDim + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int D = L.D, F = L.F;
-    for (int e = tid; e < F * (2 * kCtMaxDim + 2); e += kCtItems) (&pk[0][0])[e] = q.scratch[L.s_pack + e];
-    __syncthreads();
-    const int i = blockIdx.x * kCtItems + tid;
+    const int i = block * kCtItems + tid;
     const bool ok = i < L.I;
-    const float beta = *q.beta_p, lr = *q.lr_p;
-    const float t_ = (float)q.step_count[0];
-    const float bc1 = 1.0f - powf(0.9f, t_), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t_));
     const size_t o_item = VIBO_NUM_SCALARS + 2 * (size_t)L.rows * L.O;
-    float zz[kCtMaxDim], gz[kCtMaxDim];
+    float zz[kCtMaxDim], gz[kCtMaxDim], th[VIBO_MAX_FLOWS];
 #pragma unroll
     for (int d = 0; d < kCtMaxDim; ++d) {
-        zz[d] = (ok && d < D) ? q.item_k[(size_t)i * D + d] : 0.f;
-        // d loss / d item_k = -dLL/d item_k  (+ item_k: -log p(item_k) with flows)
-        gz[d] = (ok && d < D) ? -q.flat[o_item + (size_t)i * D + d] + (F > 0 ? zz[d] : 0.f) : 0.f;
+        const bool on = ok && d < D;
+        zz[d] = on ? q.item_k[(size_t)i * D + d] : 0.f;
+        // d loss / d item_k = -dLL/d item_k + item_k (-log p(item_k))
+        gz[d] = on ? -q.flat[o_item + (size_t)i * D + d] + zz[d] : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < VIBO_MAX_FLOWS; ++k) th[k] = (ok && k < F) ? q.scratch[L.s_tanh + (size_t)i * F + k] : 0.f;
+    for (int e = tid; e < F * (2 * kCtMaxDim + 2); e += kCtItems) (&pk[0][0])[e] = q.scratch[L.s_pack + e];
+    __syncthreads();
     const float gl = ok ? -1.0f : 0.f;                  // d loss / d ladj_i: loss holds + log q = ... - ladj
-    for (int k = F - 1; k >= 0; --k) {
-        const float t = ok ? q.scratch[L.s_tanh + (size_t)i * F + k] : 0.f;
+#pragma unroll
+    for (int k = VIBO_MAX_FLOWS - 1; k >= 0; --k) {
+        if (k >= F) continue;                           // (uniform)
+        const float t = th[k];
         const float c = pk[k][2 * D + 1];
         const float omt = 1.0f - t * t;
         const float psi = 1.0f + omt * c;
@@ -485,28 +505,47 @@ __global__ __launch_bounds__(kCtItems) void ct_item_backward_kernel(const CtItem
         __syncthreads();
         if (tid < 2 * D + 1) {
             const int e = tid < D ? tid : tid < 2 * D ? kCtMaxDim + (tid - D) : 2 * kCtMaxDim;
-            q.scratch[L.s_frec + ((size_t)blockIdx.x * F + k) * (2 * D + 1) + tid] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+            q.scratch[L.s_frec + ((size_t)block * F + k) * (2 * D + 1) + tid] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
         }
         __syncthreads();
     }
     if (!ok) return;
+#pragma unroll
+    for (int d = 0; d < kCtMaxDim; ++d)
+        if (d < D) q.scratch[L.s_gz + (size_t)i * kCtMaxDim + d] = gz[d];
+}
+
+// d loss / d item_feat (+ the encoder-input gradient of the conditional posterior) -> sample -> Adam
+__device__ __forceinline__ void ct_item_update_body(const CtItemParams& q, const int block) {
+    const CtLayout& L = q.L;
+    const int tid = threadIdx.x;
+    const int D = L.D, F = L.F;
+    const int i = block * kCtItems + tid;
+    if (i >= L.I) return;
+    const int n = L.I * D;
+    const size_t o_item = VIBO_NUM_SCALARS + 2 * (size_t)L.rows * L.O;
+    const float beta = *q.beta_p, lr = *q.lr_p;
+    const float t_ = (float)q.step_count[0];
+    const float bc1 = 1.0f - powf(0.9f, t_), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t_));
     const bool kl_mode = F == 0;
 #pragma unroll
     for (int d = 0; d < kCtMaxDim; ++d)
         if (d < D) {
-            const int idx = i * D + d;
-            float gf = gz[d];
+            const size_t idx = (size_t)i * D + d;
+            float gf = kl_mode ? -q.flat[o_item + idx] : q.scratch[L.s_gz + (size_t)i * kCtMaxDim + d];
             if (L.cond) gf += q.scratch[L.s_gx + (size_t)i * kCtMaxDim + d] + q.scratch[L.s_gx + (size_t)(L.I + i) * kCtMaxDim + d];
             const float m = q.mu[idx], l = q.lv[idx];
             // KL mode: + beta KL(q(d) || N(0,1));  flows: + log q(d_0) = ... - lv / 2 (mu cancels through the sample)
             const float g_mu = kl_mode ? gf + beta * m : gf;
             const float g_lv = gf * 0.5f * expf(0.5f * l) * q.eps[idx] + (kl_mode ? -0.5f * beta * (1.0f - expf(l)) : -0.5f);
-            float pm = m, pl = l;
-            const int n = L.I * D;
-            ct_adam(pm, q.im[idx], q.iv[idx], g_mu, lr, bc1, bc2_sqrt);
-            ct_adam(pl, q.im[n + idx], q.iv[n + idx], g_lv, lr, bc1, bc2_sqrt);
-            q.mu[idx] = pm;
-            q.lv[idx] = pl;
+            float nm = m, nl = l;
+            float m0 = q.im[idx], v0 = q.iv[idx], m1 = q.im[n + idx], v1 = q.iv[n + idx];
+            ct_adam(nm, m0, v0, g_mu, lr, bc1, bc2_sqrt);
+            ct_adam(nl, m1, v1, g_lv, lr, bc1, bc2_sqrt);
+            q.mu[idx] = nm;
+            q.lv[idx] = nl;
+            q.im[idx] = m0; q.iv[idx] = v0;
+            q.im[n + idx] = m1; q.iv[n + idx] = v1;
         }
 }
 
@@ -518,41 +557,47 @@ struct CtFinParams {
     const float* flat; const float* beta_p; const float* lr_p; int32_t* step_count;
     float* P; float* M; float* V; float* scratch; float* loss_out;
 };
-__global__ __launch_bounds__(256) void ct_finish_kernel(const CtFinParams q) {
+// records -> gradient -> Adam of 64 MLP parameters (fixed order)
+__device__ __forceinline__ void ct_mlp_adam_body(const CtFinParams& q, const int block) {
     const CtLayout& L = q.L;
     __shared__ float part[4][64];
+    const int tid = threadIdx.x;
+    const float lr = *q.lr_p;
+    const float t_ = (float)q.step_count[0];
+    const float bc1 = 1.0f - powf(0.9f, t_), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t_));
+    const int e = tid & 63, sl = tid >> 6;
+    const int k = block * 64 + e;
+    // (fixed order; four records in flight per thread: the loop is latency-bound)
+    float acc = 0.f;
+    float p = 0.f, m = 0.f, v = 0.f;
+    if (k < L.n_mlp) {
+        if (sl == 0) { p = q.P[k]; m = q.M[k]; v = q.V[k]; }
+        const float* rp = q.scratch + L.s_mrec + k;
+        int b = sl;
+        for (; b + 12 < L.n_rb; b += 16) {
+            const float v0 = rp[(size_t)b * L.n_mlp], v1 = rp[(size_t)(b + 4) * L.n_mlp];
+            const float v2 = rp[(size_t)(b + 8) * L.n_mlp], v3 = rp[(size_t)(b + 12) * L.n_mlp];
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; b < L.n_rb; b += 4) acc += rp[(size_t)b * L.n_mlp];
+    }
+    part[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && k < L.n_mlp) {
+        const float g = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        ct_adam(p, m, v, g, lr, bc1, bc2_sqrt);
+        q.P[k] = p; q.M[k] = m; q.V[k] = v;
+    }
+}
+
+// the update launch's last workgroup: loss, flow parameters
+__device__ __forceinline__ void ct_finish_last_body(const CtFinParams& q) {
+    const CtLayout& L = q.L;
     __shared__ float fg[VIBO_MAX_FLOWS][2 * kCtMaxDim + 1];
     const int tid = threadIdx.x;
     const float lr = *q.lr_p;
     const float t_ = (float)q.step_count[0];
     const float bc1 = 1.0f - powf(0.9f, t_), bc2_sqrt = sqrtf(1.0f - powf(0.999f, t_));
-    const int n_pb = (L.n_mlp + 63) / 64;
-    if ((int)blockIdx.x < n_pb) {
-        const int e = tid & 63, sl = tid >> 6;
-        const int k = blockIdx.x * 64 + e;
-        // (fixed order; four records in flight per thread: the loop is latency-bound)
-        float acc = 0.f;
-        if (k < L.n_mlp) {
-            const float* rp = q.scratch + L.s_mrec + k;
-            int b = sl;
-            for (; b + 12 < L.n_rb; b += 16) {
-                const float v0 = rp[(size_t)b * L.n_mlp], v1 = rp[(size_t)(b + 4) * L.n_mlp];
-                const float v2 = rp[(size_t)(b + 8) * L.n_mlp], v3 = rp[(size_t)(b + 12) * L.n_mlp];
-                acc += (v0 + v1) + (v2 + v3);
-            }
-            for (; b < L.n_rb; b += 4) acc += rp[(size_t)b * L.n_mlp];
-        }
-        part[sl][e] = acc;
-        __syncthreads();
-        if (sl == 0 && k < L.n_mlp) {
-            const float g = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-            float p = q.P[k], m = q.M[k], v = q.V[k];
-            ct_adam(p, m, v, g, lr, bc1, bc2_sqrt);
-            q.P[k] = p; q.M[k] = m; q.V[k] = v;
-        }
-        return;
-    }
-    // ---- last workgroup
     const int A = L.A, D = L.D, F = L.F;
     if (tid < 64) {                          // item-side scalars: the prologue's partial sums, fixed order
         float kl = 0.f, lq = 0.f, lp = 0.f;
@@ -611,6 +656,35 @@ __global__ __launch_bounds__(256) void ct_finish_kernel(const CtFinParams q) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// the epilogue's two launches (round 3: four):
+//   ct_backward_kernel  workgroups [0, n_rb) = table-row tiles (MLP backward), then -- with flows -- n_ib item blocks that take
+//                       d loss / d item_k back through the item-side flows (independent of the tiles)
+//   ct_update_kernel    [0, n_ib) = item sample backward + Adam, then the MLP records -> Adam, then ONE workgroup for the loss
+//                       and the flow parameters; everything they read comes from earlier launches
+// ---------------------------------------------------------------------------
+struct CtEpiParams {
+    CtItemParams it;
+    CtFinParams fin;
+    const float* item_feat;
+    int tpb;
+};
+__global__ __launch_bounds__(kCtItems) void ct_backward_kernel(const CtEpiParams q) {
+    const CtLayout& L = q.fin.L;
+    __shared__ __attribute__((aligned(16))) CtBwdLds S;
+    const int b = blockIdx.x;
+    if (b < L.n_rb) ct_rows_backward_body(L, q.fin.P, q.item_feat, q.fin.flat, q.fin.beta_p, q.fin.scratch, q.tpb, b, S);
+    else ct_item_flows_backward_body(q.it, b - L.n_rb);
+}
+__global__ __launch_bounds__(kCtItems) void ct_update_kernel(const CtEpiParams q) {
+    const CtLayout& L = q.fin.L;
+    const int b = blockIdx.x, n_pb = (L.n_mlp + 63) / 64;
+    if (b < L.n_ib) ct_item_update_body(q.it, b);
+    else if (b < L.n_ib + n_pb) ct_mlp_adam_body(q.fin, b - L.n_ib);
+    else ct_finish_last_body(q.fin);
+}
+
 }  // namespace vibo
 
 using namespace vibo;
@@ -652,10 +726,8 @@ int vibo_ctrain_prologue(const vibo_desc* d, int hidden_dim, const float* params
     q.eps_ab = eps_ability; q.n_ab = draw_noise ? (long long)d->num_person * d->ability_dim : 0; q.ab_stream = ability_stream_id;
     const long long ab_blocks = draw_noise ? ((q.n_ab + 3) / 4 + kCtItems - 1) / kCtItems : 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ct_prologue_kernel, dim3((unsigned)(1 + L.n_ib + ab_blocks)), dim3(kCtItems), 0, s, q);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ct_table_kernel, dim3(L.n_rb), dim3(256), 0, s, L, params, (const float*)item_feat, table, ct_tiles_per_block(L.rows));
+    q.table = table; q.ab_blocks = (int)ab_blocks; q.tpb = ct_tiles_per_block(L.rows);
+    hipLaunchKernelGGL(ct_prologue_kernel, dim3((unsigned)(1 + L.n_ib + ab_blocks + L.n_rb)), dim3(kCtItems), 0, s, q);
     return (int)hipGetLastError();
 }
 
@@ -670,20 +742,18 @@ int vibo_ctrain_epilogue(const vibo_desc* d, int hidden_dim, const float* flat, 
         !item_logvar || !item_m || !item_v || !scratch || !loss_out)
         return -5;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ct_rows_backward_kernel, dim3(L.n_rb), dim3(256), 0, s, L, (const float*)params, item_feat, flat, beta, scratch,
-                       ct_tiles_per_block(L.rows));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
     CtItemParams qi;
     qi.L = L; qi.flat = flat; qi.eps = eps_item; qi.item_k = item_k; qi.beta_p = beta; qi.lr_p = lr; qi.step_count = step_count;
     qi.mu = item_mu; qi.lv = item_logvar; qi.im = item_m; qi.iv = item_v; qi.scratch = scratch;
-    hipLaunchKernelGGL(ct_item_backward_kernel, dim3(L.n_ib), dim3(kCtItems), 0, s, qi);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
     CtFinParams qf;
     qf.L = L; qf.flat = flat; qf.beta_p = beta; qf.lr_p = lr; qf.step_count = step_count; qf.P = params; qf.M = adam_m; qf.V = adam_v;
     qf.scratch = scratch; qf.loss_out = loss_out;
-    hipLaunchKernelGGL(ct_finish_kernel, dim3((L.n_mlp + 63) / 64 + 1), dim3(256), 0, s, qf);
+    CtEpiParams qe;
+    qe.it = qi; qe.fin = qf; qe.item_feat = item_feat; qe.tpb = ct_tiles_per_block(L.rows);
+    hipLaunchKernelGGL(ct_backward_kernel, dim3(L.n_rb + (L.F > 0 ? L.n_ib : 0)), dim3(kCtItems), 0, s, qe);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ct_update_kernel, dim3(L.n_ib + (L.n_mlp + 63) / 64 + 1), dim3(kCtItems), 0, s, qe);
     return (int)hipGetLastError();
 }
 
