@@ -348,7 +348,7 @@ int vibo_train_prime(const vibo_desc* d, int hidden_dim, const float* mlp_params
  *
  *  params / adam_m / adam_v: one flat fp32 buffer each,
  *      W0 [H][xin] | b0 [H] | W1 [H][H] | b1 [H] | W2 [2A][H] | b2 [2A] | ability flows F x (u[A] | w[A] | b) | item flows F x (u[D] | w[D] | b)
- *      with xin = 1 + D (conditional) or 1; vibo_ctrain_param_floats(d, H) floats.  hidden_dim H: 64 or 32.
+ *      with xin = 1 + D (conditional) or 1; vibo_ctrain_param_floats(d, H) floats.  hidden_dim H <= 64 (narrower widths run zero-padded on the 64-wide matrix-pipe tile).
  *  scratch: vibo_ctrain_scratch_floats(d, H) floats, handed to both calls of a step unchanged in between.
  *  step_count, beta, lr, item_m / item_v: as for vibo_train_prologue / vibo_train_epilogue.
  * Every reduction is a fixed-order sum of per-workgroup records: bitwise reproducible, hipGraph-capturable (no host sync).

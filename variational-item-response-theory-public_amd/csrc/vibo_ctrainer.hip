@@ -5,8 +5,8 @@
 //   item sample (models.py:361-362, 506-510) -> item-side planar flows (flows.py:21-66, models.py:346-348)
 //   -> expert table = encoder MLP on the rows [c, item_i] (models.py:666-710; 2 rows [c] without the conditional posterior)
 //   -> vibo_elbo_fwd_bwd -> loss (models.py:380-443) -> backward through table MLP / flows / sample -> Adam (vibo.py:221).
-// The module path runs this as ~190 PyTorch launches per step (2.2 ms at 16 persons); here it is five launches around
-// the ELBO call, all deterministic (fixed-order partial records), so a captured hipGraph contains no PyTorch autograd node.
+// The module path runs this as ~190 PyTorch launches per step (2.2 ms at 16 persons); here it is three launches around
+// the ELBO call (prologue + table tiles | backward | update), all deterministic (fixed-order partial records), so a captured hipGraph contains no PyTorch autograd node.
 //
 // Flat parameter buffer (`params`, and the Adam moments in the same layout):
 //   W0 [H][xin] | b0 [H] | W1 [H][H] | b1 [H] | W2 [O][H] | b2 [O] | ability flows F x (u[A] | w[A] | b) | item flows F x (u[D] | w[D] | b)

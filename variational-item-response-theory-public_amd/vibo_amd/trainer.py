@@ -266,7 +266,7 @@ class FusedCondFlowTrainer(FusedTrainer):
     packing, the encoder MLP on the 2 x I rows [c, item_i] -> expert table; optionally the Philox noise) -> vibo_elbo_fwd_bwd
     -> [one all-reduce when person-sharded] -> vibo_ctrain_epilogue (loss, table-MLP / flow / sample backward, Adam on
     everything).  No PyTorch autograd node: the step replays from a hipGraph like FusedTrainer's.  Same interface
-    (`FusedTrainer(model, ...)` returns this class for such models).  Hidden width 64 or 32."""
+    (`FusedTrainer(model, ...)` returns this class for such models).  Hidden width <= 64."""
 
     def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True):
         # (fold: FusedTrainer's two-launch form; this class's step is prologue / ELBO call / epilogue either way)
