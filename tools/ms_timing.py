@@ -10,8 +10,9 @@ from vibo_amd import _lib
 lib = _lib.load() if hasattr(_lib, 'load') else ctypes.CDLL(os.path.join(ROOT, 'variational-item-response-theory-public_amd', 'vibo_amd', 'libvibo_hip.so'))
 n = 1024 * 8 * 16
 buf = (ctypes.c_longlong * n)()
-lib.vibo_debug_ms_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
-rc = lib.vibo_debug_ms_timing(buf, n)
+fn = lib.vibo_debug_ms_timing_c if '--codes' in sys.argv else lib.vibo_debug_ms_timing      # (one buffer per translation unit)
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = fn(buf, n)
 raw = np.frombuffer(buf, dtype=np.int64).reshape(1024, 8, 16)[:256]
 t = raw[:, :, :12].astype(np.float64)
 nb = (P + 31) // 32 / 256
