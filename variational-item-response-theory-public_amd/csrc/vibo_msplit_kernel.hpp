@@ -1127,7 +1127,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 out[p.lay.off_flow + idx] = t;
             }
         }
-        // item gradients.  d LL/d a: lane (col i16, g) holds items 4 g + j of tile (u, t): cols a and 8 + a add up
+        // item gradients.  d LL/d a: lane (col i16, g) holds items 4 g + j of tile (u, t): cols a and 8 + a add up.
+        // The wave's 128 items x (A + 2) rows go through its own LDS (the operand images are dead by now; nobody else reads
+        // them: no barrier) and leave as whole 256-byte rows -- the registers' own layout is 4-byte stores scattered over 32
+        // cache lines each, ~5 us at the end of every workgroup.
+        constexpr int kStage = 130;                  // floats per staged row (128 + 2: the 32 writers of a row group hit 32 banks)
+        float* stage = reinterpret_cast<float*>(&wl.tr[0][0][0]);
+        static_assert(sizeof(wl.tr) + sizeof(wl.img) >= (size_t)(VIBO_MAX_ABILITY_DIM + 2) * kStage * sizeof(float), "staging area");
+        const int brow = IRT == 1 ? 0 : A;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1136,24 +1143,30 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = (acc_ga[u][t][j] + dpp_f<0x128>(acc_ga[u][t][j])) * sc_a;       // sum g theta' = 2^-jsh sum g theta
-                        const int il = kMsSpan * q + 64 * u + 4 * (4 * g + j) + t;
-                        if (i16 < A && il < I) out[p.lay.off_item + (size_t)i16 * p.lay.i_pad + il] = -v;
+                        if (i16 < A) stage[i16 * kStage + 64 * u + 4 * (4 * g + j) + t] = -v;
                     }
                 }
                 // d LL/d b (and d/d guess-logit): the lane's 8 persons per batch -> sum over the 4 lane groups
                 float b = acc_b[u][t];
                 b += __shfl_xor(b, 16);
                 b += __shfl_xor(b, 32);
-                const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
-                const int brow = IRT == 1 ? 0 : A;
-                if (g == 0 && il < I) out[p.lay.off_item + (size_t)brow * p.lay.i_pad + il] = b;
+                if (g == 0) stage[brow * kStage + 64 * u + 4 * i16 + t] = b;
                 if constexpr (IRT == 3) {
                     float gg = acc_g[u][t];
                     gg += __shfl_xor(gg, 16);
                     gg += __shfl_xor(gg, 32);
-                    if (g == 0 && il < I) out[p.lay.off_item + (size_t)(A + 1) * p.lay.i_pad + il] = gg;
+                    if (g == 0) stage[(A + 1) * kStage + 64 * u + 4 * i16 + t] = gg;
                 }
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS writes, in order: visible to its reads)
+        const int n_rows = IRT == 1 ? 1 : IRT == 2 ? A + 1 : A + 2;
+        for (int row = 0; row < n_rows; ++row) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int il = kMsSpan * q + 64 * h + lane;
+                if (il < I) out[p.lay.off_item + (size_t)row * p.lay.i_pad + il] = stage[row * kStage + 64 * h + lane];
+            }
+        }
     }
 #ifdef VIBO_MS_TIMING
     {
