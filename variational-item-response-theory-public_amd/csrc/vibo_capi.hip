@@ -1034,22 +1034,16 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             p.pre_panels = 1;
             p.table = item;               // the 2-row expert table is not used in this mode: any finite floats (>= 4 A of them)
         } else if (pl.cmat_pre) {
-            // matrix-pipe pre pass: fp32 rows are turned into cell codes first (one streaming pass, minibatch order)
-            const uint8_t* crows = static_cast<const uint8_t*>(mask);
-            long long cstride = d->mask_row_stride;
-            const int64_t* cidx = row_index;
+            // matrix-pipe pre pass.  fp32 rows: the contraction kernel reads them itself and leaves the rows' cell codes behind for
+            // the passes that follow (minibatch order) -- round 3 ran a re-pack stream (row_count_kernel) in front of it
             if (emit) {
-                int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
-                int cgrid = num_cu * 8;
-                if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
-                hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
-                                   (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype,
-                                   code_rows, (long long)pl.codes_stride);
-                e = hipGetLastError();
-                crows = code_rows; cstride = pl.codes_stride; cidx = nullptr;
+                e = launch_cond_pre_mfma_fp32(response, d->mask_dtype == VIBO_MASK_U8 ? mask : nullptr, (long long)d->response_row_stride,
+                                              (long long)d->mask_row_stride, row_index, d->num_person, I, A, table, pre, code_rows,
+                                              (long long)pl.codes_stride, mscratch, s);
+            } else {
+                e = launch_cond_pre_mfma(static_cast<const uint8_t*>(mask), d->mask_row_stride, row_index, d->num_person, I, A, table, pre,
+                                         mscratch, s);
             }
-            if (e == hipSuccess)
-                e = launch_cond_pre_mfma(crows, cstride, cidx, d->num_person, I, A, table, pre, mscratch, s);
             p.pre_stats = pre;
             p.pre_panels = 1;
         } else if (pl.cond) {

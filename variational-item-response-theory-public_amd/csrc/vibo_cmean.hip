@@ -339,6 +339,190 @@ __global__ __launch_bounds__(320, NT == 1 ? 4 : 1) void cm_forward_kernel(const 
     }
 }
 
+// ---- the same forward straight from fp32 rows (+ u8 mask): count-and-emit inside the contraction ---------------------------
+// The conditional posterior on fp32 rows used to run a pure re-pack stream (row_count_kernel: 5 B in, 1 B out per cell, 1.26 ms
+// per 1M x 1k) in front of the forward contraction (0.29 ms).  Here the compute waves load the fp32 cells themselves, turn each
+// 16-cell piece into the 16 code bytes the contraction wants (cell_codes4), leave them behind as the row's Format P codes for the
+// passes that follow (minibatch order) and go on as cm_forward_kernel<1> does.  One N-tile only (2A + 1 <= 16 columns; 8 dims
+// count with the code words).  A compute wave owns 32 persons (two M-tiles) and keeps three steps of raw cells in flight
+// (3 x 40 registers: at five waves per workgroup a wave has 256).
+struct CmRawPiece {        // the 16 cells at items [i0, i0 + 16) of one row
+    float4 x[4];
+    uint4 m;
+};
+__device__ __forceinline__ uint4 cm_codes_of(const CmRawPiece& r) {
+    return uint4{cell_codes4(r.x[0], r.m.x), cell_codes4(r.x[1], r.m.y), cell_codes4(r.x[2], r.m.z), cell_codes4(r.x[3], r.m.w)};
+}
+constexpr int kCmF32MT = 2;            // M-tiles (16 persons) per compute wave of cm_forward_fp32_kernel
+template <bool COUNT, bool MAL /* mask rows 16-byte aligned */>
+__global__ __launch_bounds__(320, 1) void cm_forward_fp32_kernel(const float* __restrict__ response, const uint8_t* __restrict__ mask,
+                                                                 long long resp_stride, long long mask_stride,
+                                                                 const int64_t* __restrict__ row_index, long long B, int I, int nS,
+                                                                 const uint4* __restrict__ img, float* __restrict__ out, int out_stride,
+                                                                 int ncols, uint8_t* __restrict__ codes_out, long long codes_stride) {
+    __shared__ uint4 bimg[2][768];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wv == 4) {                                   // ---- producer wave (as in cm_forward_kernel<1>: one 12 KB chunk per step)
+        const cm_u4* src = reinterpret_cast<const cm_u4*>(img) + lane;
+        cm_u4* lds = reinterpret_cast<cm_u4*>(&bimg[0][0]) + lane;
+        cm_u4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11;
+#define CM_CHUNK_LOAD(np) { r0 = (np)[0]; r1 = (np)[64]; r2 = (np)[128]; r3 = (np)[192]; r4 = (np)[256]; r5 = (np)[320]; \
+                            r6 = (np)[384]; r7 = (np)[448]; r8 = (np)[512]; r9 = (np)[576]; r10 = (np)[640]; r11 = (np)[704]; }
+#define CM_CHUNK_STORE(dp) { (dp)[0] = r0; (dp)[64] = r1; (dp)[128] = r2; (dp)[192] = r3; (dp)[256] = r4; (dp)[320] = r5; \
+                             (dp)[384] = r6; (dp)[448] = r7; (dp)[512] = r8; (dp)[576] = r9; (dp)[640] = r10; (dp)[704] = r11; }
+        CM_CHUNK_LOAD(src)
+        CM_CHUNK_STORE(lds)
+        CM_CHUNK_LOAD(src + (size_t)(1 < nS ? 1 : 0) * 768)
+        __syncthreads();
+        for (int q = 0; q < nS; ++q) {
+            cm_u4* dst = lds + ((q + 1) & 1) * 768;
+            CM_CHUNK_STORE(dst)
+            const cm_u4* np = src + (size_t)(q + 2 < nS ? q + 2 : nS - 1) * 768;
+            CM_CHUNK_LOAD(np)
+            __syncthreads();
+        }
+#undef CM_CHUNK_LOAD
+#undef CM_CHUNK_STORE
+        return;
+    }
+    const int m = lane & 15, g = lane >> 4;
+    constexpr int MT = kCmF32MT;
+    const long long p0 = ((long long)blockIdx.x * 4 + wv) * (16 * MT);
+    const int lrow = lane >> 2, lpiece = lane & 3;
+    const int perm_addr = 4 * (4 * m + g);
+    const float* rpx[MT];
+    const uint8_t* rpm[MT];
+    uint8_t* rpc[MT];                                 // nullptr: the row does not exist (nothing is stored for it)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long p = p0 + 16 * mt + lrow;
+        const long long pc = p < B ? p : B - 1;
+        const long long src = row_index ? row_index[pc] : pc;
+        rpx[mt] = response + src * resp_stride;
+        rpm[mt] = mask ? mask + src * mask_stride : nullptr;
+        rpc[mt] = (codes_out && p < B) ? codes_out + p * codes_stride : nullptr;
+    }
+    cm_f32x4 acc[MT];
+    int cnt[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) cnt[mt] = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = cm_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nFull = I >> 6;                        // steps whose 64 items all exist; one partial step may follow
+    auto fetch = [&](CmRawPiece (&w)[MT], const int S) {
+        const int i0 = 64 * (S < nFull ? S : nFull - 1) + 16 * lpiece;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4* xp = reinterpret_cast<const float4*>(rpx[mt] + i0);
+            w[mt].x[0] = xp[0]; w[mt].x[1] = xp[1]; w[mt].x[2] = xp[2]; w[mt].x[3] = xp[3];
+            if (mask) {
+                if constexpr (MAL) w[mt].m = *reinterpret_cast<const uint4*>(rpm[mt] + i0);
+                else {
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(rpm[mt] + i0);
+                    w[mt].m = uint4{q[0], q[1], q[2], q[3]};
+                }
+            } else {
+                w[mt].m = uint4{0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one 64-item step on the code words wl (this lane's pieces: stored as the rows' codes, then permuted into the operand layout)
+    auto step = [&](const int S, const uint4 (&wl)[MT]) {
+        const int i0 = 64 * S + 16 * lpiece;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if (rpc[mt]) *reinterpret_cast<uint4*>(rpc[mt] + i0) = wl[mt];
+        uint4 w[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            w[mt] = uint4{(uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].x), (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].y),
+                          (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].z), (uint32_t)__builtin_amdgcn_ds_bpermute(perm_addr, (int)wl[mt].w)};
+        const int cur = S & 1;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            uint4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = cm_onehot(jj == 0 ? w[mt].x : jj == 1 ? w[mt].y : jj == 2 ? w[mt].z : w[mt].w);
+            const uint4* bp = &bimg[cur][jj * kCmNP * 64 + lane];
+            const uint4 b0 = bp[0], b1 = bp[64], b2 = bp[128];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt] = cm_mfma(a[mt], b2, acc[mt]);        // smallest pieces first
+                acc[mt] = cm_mfma(a[mt], b1, acc[mt]);
+                acc[mt] = cm_mfma(a[mt], b0, acc[mt]);
+            }
+        }
+        __syncthreads();
+        if constexpr (COUNT) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) cnt[mt] += cm_observed(w[mt]);
+        }
+    };
+    // three steps of raw cells in flight (3 x 40 registers); a set is converted when its step comes up
+    CmRawPiece rA[MT], rB[MT], rC[MT];
+    if (nFull > 0) {
+        fetch(rA, 0);
+        fetch(rB, 1);
+    }
+    __syncthreads();
+    auto run = [&](const int S, const CmRawPiece (&raw)[MT]) {
+        uint4 wl[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wl[mt] = cm_codes_of(raw[mt]);
+        step(S, wl);
+    };
+    int S = 0;
+    for (; S + 3 <= nFull; S += 3) {
+        fetch(rC, S + 2); run(S, rA);
+        fetch(rA, S + 3); run(S + 1, rB);
+        fetch(rB, S + 4); run(S + 2, rC);
+    }
+    if (S < nFull) {
+        run(S, rA);
+        if (S + 1 < nFull) run(S + 1, rB);
+    }
+    if (nS > nFull) {                                // the row's last, partial step: 4 cells at a time, cells past the row's end missing
+        uint4 wl[MT];
+        const int i0 = 64 * nFull + 16 * lpiece;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            uint32_t d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int left = I - (i0 + 4 * k);
+                uint32_t v = kAllMissing4;
+                if (left > 0) {                      // (rows are whole 4-cell chunks: the chunk is inside the row's stride)
+                    const float4 x = *reinterpret_cast<const float4*>(rpx[mt] + i0 + 4 * k);
+                    uint32_t mm = mask ? *reinterpret_cast<const uint32_t*>(rpm[mt] + i0 + 4 * k) : 0x01010101u;
+                    if (left < 4) mm &= (1u << (8 * left)) - 1u;
+                    v = cell_codes4(x, mm);
+                }
+                d[k] = v;
+            }
+            wl[mt] = uint4{d[0], d[1], d[2], d[3]};
+        }
+        step(nFull, wl);
+    }
+    // D: lane (col n = m, g) holds rows 4 g + jj of the M-tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const long long p = p0 + 16 * mt + 4 * g + jj;
+            if (p < B && m < ncols) out[p * out_stride + m] = acc[mt][jj];
+        }
+        if constexpr (COUNT) {
+            int t = cnt[mt];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            const long long p = p0 + 16 * mt + m;
+            if (g == 0 && p < B) out[p * out_stride + ncols] = (float)t;
+        }
+    }
+}
+
 // ---- backward: dX = onehot^T G ; a wave (= workgroup) owns a stripe of 64 items x a range of persons x NT N-tiles -------
 // One-hot tile [64 persons][128 (item, code) columns] of bf16, 256-byte rows, XOR-swizzled so that neither the 16-byte writes
 // of a code row's pieces nor the transposed 8-byte reads of a 16-lane group (4 persons x 32 bytes) share banks:
@@ -620,6 +804,28 @@ hipError_t launch_cond_pre_mfma(const uint8_t* codes, long long stride, const in
     if (e != hipSuccess) return e;
     if (ncols > 2 * A) return cm_launch_forward<false>(1, codes, stride, row_index, B, I, nS, img, pre, 2 * A + 1, ncols, s);
     return cm_launch_forward<true>(1, codes, stride, row_index, B, I, nS, img, pre, 2 * A + 1, 2 * A, s);
+}
+// the same from fp32 rows (+ u8 mask or none): the rows' cell codes are left in `codes_out` (minibatch order, rows of
+// `codes_stride` bytes = whole 64-byte steps) for the passes that follow
+hipError_t launch_cond_pre_mfma_fp32(const float* response, const void* mask, long long resp_stride, long long mask_stride,
+                                     const int64_t* row_index, long long B, int I, int A, const float* table, float* pre,
+                                     uint8_t* codes_out, long long codes_stride, void* scratch, hipStream_t s) {
+    const int nS = (I + 63) / 64;
+    uint4* img = static_cast<uint4*>(scratch);
+    const int ncols = 2 * A < 16 ? 2 * A + 1 : 2 * A;
+    hipLaunchKernelGGL((cm_table_image_kernel<true>), dim3((nS * 4 * 64 + 255) / 256), dim3(256), 0, s, table, img, I, nS, 1, ncols);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint8_t* mk = static_cast<const uint8_t*>(mask);
+    const bool mal = !mk || (mask_stride % 16 == 0 && ((uintptr_t)mk & 15) == 0);
+    const dim3 grid((unsigned)((B + 64 * kCmF32MT - 1) / (64 * kCmF32MT)));
+    const bool count = ncols == 2 * A;               // 8 dims: no room for the ones column, the code words are counted
+#define CM_FWD32(C, M) hipLaunchKernelGGL((cm_forward_fp32_kernel<C, M>), grid, dim3(320), 0, s, response, mk, resp_stride, mask_stride, row_index, B, I, \
+                                          nS, (const uint4*)img, pre, 2 * A + 1, count ? 2 * A : ncols, codes_out, codes_stride)
+    if (count) { if (mal) CM_FWD32(true, true); else CM_FWD32(true, false); }
+    else { if (mal) CM_FWD32(false, true); else CM_FWD32(false, false); }
+#undef CM_FWD32
+    return hipGetLastError();
 }
 // grad_table[2 heads][2][I][2A] from the per-person coefficients coef[B][4A] = [head][P1 | P2][dim]
 hipError_t launch_cond_post_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,

@@ -31,6 +31,9 @@ hipError_t launch_cond_finalize(const float* partial, float* grad_table, int I, 
 size_t cond_mfma_scratch_bytes(long long B, int I, int A);
 hipError_t launch_cond_pre_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,
                                 const float* table, float* pre, void* scratch, hipStream_t s);
+hipError_t launch_cond_pre_mfma_fp32(const float* response, const void* mask, long long resp_stride, long long mask_stride,
+                                     const int64_t* row_index, long long B, int I, int A, const float* table, float* pre,
+                                     uint8_t* codes_out, long long codes_stride, void* scratch, hipStream_t s);
 hipError_t launch_cond_post_mfma(const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int A,
                                  const float* table, const float* coef, float* grad_table, void* scratch, hipStream_t s,
                                  CondFinTail* defer = nullptr);
