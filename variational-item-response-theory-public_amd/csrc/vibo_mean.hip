@@ -28,6 +28,12 @@ __global__ __launch_bounds__(256) void mean_encoder_fwd_kernel(const int* __rest
                                                                const float* __restrict__ v, const float* __restrict__ w2,
                                                                const float* __restrict__ b2, float* __restrict__ post, long long B,
                                                                int H, int A2) {
+    // the weights through LDS first (broadcast reads in the loop: with per-iteration global loads a 16-person call was a chain of
+    // 64 dependent round trips, 18 - 43 us)
+    __shared__ float su[kMeanMaxHidden], sv[kMeanMaxHidden], sw[2 * VIBO_MAX_ABILITY_DIM * kMeanMaxHidden];
+    for (int k = threadIdx.x; k < H; k += 256) { su[k] = u[k]; sv[k] = v[k]; }
+    for (int e = threadIdx.x; e < A2 * H; e += 256) sw[e] = w2[e];
+    __syncthreads();
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= B) return;
     const int c = counts[p];
@@ -36,14 +42,45 @@ __global__ __launch_bounds__(256) void mean_encoder_fwd_kernel(const int* __rest
 #pragma unroll
     for (int j = 0; j < 2 * VIBO_MAX_ABILITY_DIM; ++j) out[j] = j < A2 ? b2[j] : 0.f;
     for (int k = 0; k < H; ++k) {
-        const float a = elu1(fmaf(w, v[k], u[k]));
+        const float a = elu1(fmaf(w, sv[k], su[k]));
 #pragma unroll
         for (int j = 0; j < 2 * VIBO_MAX_ABILITY_DIM; ++j)
-            if (j < A2) out[j] = fmaf(w2[j * H + k], a, out[j]);
+            if (j < A2) out[j] = fmaf(sw[j * H + k], a, out[j]);
     }
 #pragma unroll
     for (int j = 0; j < 2 * VIBO_MAX_ABILITY_DIM; ++j)
         if (j < A2) post[p * A2 + j] = out[j];
+}
+
+// the same for small minibatches: a wave per person, lane = hidden unit (the thread-per-person loop above is 64 x (expm1 + 2A
+// fmas) in a row for a handful of active lanes: 18 - 44 us for 16 persons).  Its sums over the hidden units are wave reductions,
+// so the two kernels agree to fp32 rounding, not bit for bit; the choice depends on the person count only.
+template <int KCH>
+__global__ __launch_bounds__(256) void mean_encoder_fwd_wave_kernel(const int* __restrict__ counts, const float* __restrict__ u,
+                                                                    const float* __restrict__ v, const float* __restrict__ w2,
+                                                                    const float* __restrict__ b2, float* __restrict__ post, long long B,
+                                                                    int H, int A2) {
+    const int lane = threadIdx.x & 63;
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= B) return;
+    const int c = counts[p];
+    const float w = (float)(c >> 16) / (float)(c & 0xffff);
+    float a[KCH];
+#pragma unroll
+    for (int ch = 0; ch < KCH; ++ch) {
+        const int k = ch * 64 + lane;
+        a[ch] = k < H ? elu1(fmaf(w, v[k], u[k])) : 0.f;
+    }
+    for (int j = 0; j < A2; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < KCH; ++ch) {
+            const int k = ch * 64 + lane;
+            t = fmaf(k < H ? w2[j * H + k] : 0.f, a[ch], t);
+        }
+        t = wave_total(t);
+        if (lane == 0) post[p * A2 + j] = t + b2[j];
+    }
 }
 
 // partial record of a wave: [ d/du (H) | d/dv (H) | d/dW2 (A2 x H, row-major) | d/db2 (A2) ]
@@ -148,8 +185,21 @@ extern "C" int vibo_mean_encoder_forward(const vibo_desc* d, int hidden, const i
     const int rc = mean_check(d, hidden);
     if (rc) return rc;
     if (!counts || !u || !v || !w2 || !b2 || !posterior) return -5;
-    hipLaunchKernelGGL(mean_encoder_fwd_kernel, dim3((unsigned)((d->num_person + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       counts, u, v, w2, b2, posterior, (long long)d->num_person, hidden, 2 * d->ability_dim);
+    const long long B = d->num_person;
+    const int A2 = 2 * d->ability_dim;
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 2048) {                          // launch-bound minibatches: a wave per person
+        const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+        switch ((hidden + 63) / 64) {
+            case 1: hipLaunchKernelGGL(mean_encoder_fwd_wave_kernel<1>, grid, block, 0, s, counts, u, v, w2, b2, posterior, B, hidden, A2); break;
+            case 2: hipLaunchKernelGGL(mean_encoder_fwd_wave_kernel<2>, grid, block, 0, s, counts, u, v, w2, b2, posterior, B, hidden, A2); break;
+            case 3: hipLaunchKernelGGL(mean_encoder_fwd_wave_kernel<3>, grid, block, 0, s, counts, u, v, w2, b2, posterior, B, hidden, A2); break;
+            default: hipLaunchKernelGGL(mean_encoder_fwd_wave_kernel<4>, grid, block, 0, s, counts, u, v, w2, b2, posterior, B, hidden, A2); break;
+        }
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(mean_encoder_fwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, counts, u, v, w2, b2, posterior, B,
+                       hidden, A2);
     return (int)hipGetLastError();
 }
 
