@@ -55,6 +55,9 @@ while time.time() - t0 < a.seconds:
     for k in leaves:
         if float(leaves[k].grad.abs().max()) > 1e-6:
             errs[k] = rel(dl[k].grad.double().cpu(), leaves[k].grad)
+            if k == 'b3':      # one scalar = a sum of nobs terms of either sign: measured against the sum's natural scale, not against
+                #               a value that may cancel to ~0 (seen: 0.0027 from 2 145 terms of ~0.5, 6e-6 apart = 2.4e-3 "relative")
+                errs[k] = float((dl[k].grad.double().cpu() - leaves[k].grad).abs().max()) / max(float(leaves[k].grad.abs().max()), 0.01 * max(nobs, 1.0) ** 0.5)
     # (a handful of terms with strongly negative pre-activations: ELU' = h + 1 carries the 6e-8 absolute rounding of h, exactly as
     #  the reference's in-place ELU backward does; with thousands of terms it averages out)
     gtol = 3e-3 if B * I < 64 else 5e-4
@@ -62,7 +65,8 @@ while time.time() - t0 < a.seconds:
     worst = max(worst, max(errs.values()))
     n += 1
     if bad:
-        print(f'FAIL mode={mode} B={B} I={I} missing={missing} scale={sc} seed={seed}: {bad}')
+        detail = {k: (float(dl[k].grad.double().cpu().abs().max()), float(leaves[k].grad.abs().max())) for k in bad if k != 'll'}
+        print(f'FAIL mode={mode} B={B} I={I} missing={missing} scale={sc} seed={seed}: {bad}  (|grad| max: kernel, float64 reference) {detail}')
         sys.exit(1)
     # the flow stack on a random small matrix
     N, Dm, K = rng.choice([1, 7, 256, 257, 1000]), rng.choice([1, 2, 3, 9, 10]), rng.choice([1, 2, 4, 8])
