@@ -210,6 +210,8 @@ int vibo_row_counts(const vibo_desc* d, const float* response, const void* mask,
  * and its backward: given d loss / d posterior [B][2A] (what vibo_elbo_fwd_bwd returns in VIBO_POSTERIOR_GIVEN mode,
  * combined by the caller), `partials` receives n_partials records [ d/du (H) | d/dv (H) | d/dW2 (2A x H) | d/db2 (2A) ]
  * that the caller sums (fixed order).  n_partials = vibo_mean_encoder_partials(d); hidden <= 256.
+ * The forward runs a wave per person up to 2 048 persons (sums over the hidden units as wave totals) and a thread per person
+ * beyond: a call is bit-identical to itself, calls on either side of that size agree to fp32 rounding.
  */
 int vibo_mean_encoder_partials(const vibo_desc* d);
 int vibo_mean_encoder_forward(const vibo_desc* d, int hidden, const int32_t* counts, const float* u, const float* v,
