@@ -623,6 +623,11 @@ MATRIX_PIPE_POSTERIOR = [
     (2, 1, 4096, 64, 0, False, True, False),       # exactly one whole step, nothing else
     (2, 8, 16, 1000, 0, False, True, False),       # the CLI's default minibatch: one partly filled M-tile
     (3, 3, 77, 95, 2, True, False, True),          # fp32 rows, small gathered minibatch
+    # fp32 rows at 5+ dims: the forward contraction reads the fp32 cells itself and leaves the codes behind (cm_forward_fp32_kernel)
+    (2, 8, 300, 1000, 0, True, False, False),      # 8 dims (observed counts from the code words), gathered rows, 15 steps + a 40-item tail
+    (2, 6, 16, 128, 0, False, False, True),        # two whole steps and nothing else, 16 persons
+    (3, 5, 100, 40, 2, False, False, False),       # fewer than 64 items: only the partial step
+    (2, 8, 4100, 1000, 0, False, False, False),    # in order: must equal the same call on packed cell codes bit for bit (below)
 ]
 
 
@@ -681,6 +686,13 @@ def test_matrix_pipe_passes_of_the_conditional_posterior(irt, A, B, I, n_flows, 
     f = run(_lib.FLAG_COND_MATRIX, want_grad=False)  # forward only: the same posterior and scalars
     assert torch.equal(f.ability_mu, a.ability_mu) and torch.equal(f.ability_logvar, a.ability_logvar)
     assert rel_err(f.scalars[_lib.S_LL], a.scalars[_lib.S_LL]) < 1e-6
+    if not codes and A >= 5 and not gather:
+        # Format R at 5+ dims = the same three passes on the codes the first one emits: bit-identical to the Format P call
+        pc = ops.pack_cell_codes(resp.to(d), mask.to(d)).codes
+        monkeypatch.setattr(ops, 'DESC_FLAGS', kernel | _lib.FLAG_COND_MATRIX)
+        c = ops._hip_launch_elbo(spec, pc, pc, _lib.MASK_CODES, None, *args[5:], True, B)
+        torch.cuda.synchronize()
+        assert torch.equal(c.ability_mu, a.ability_mu) and torch.equal(c.ability_logvar, a.ability_logvar) and torch.equal(c.flat, a.flat)
 
 
 @pytest.mark.parametrize('irt,A,I,cond,n_flows', [(2, 1, 95, False, 0), (2, 8, 1003, False, 0), (3, 2, 333, False, 2),
