@@ -49,9 +49,28 @@ def two():
 def two_ev():
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); ga.replay(); e1.record(); gb.replay()
-res = {'one': [], 'two': [], 'two_ev': []}
+# more forms, to see what about the graph boundary matters (box-dependent: DESIGN 3.1a)
+tiny = torch.zeros(64, device=dev)
+gm = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gm, pool=g1.pool()):          # one graph with a tiny fill between the two kernels
+    raw_m = tr.forward_backward(resp, mask)
+    tiny.add_(1.0)
+    tr.update()
+gt = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gt, pool=g1.pool()):          # a graph of its own that does next to nothing
+    tiny.add_(1.0)
+def one_fill():
+    gm.replay()
+def three():
+    ga.replay(); gt.replay(); gb.replay()
+def one_then_tiny():
+    g1.replay(); gt.replay()
+def eager():
+    tr.step(resp, mask)
+forms = (('one', one), ('two', two), ('two_ev', two_ev), ('one_fill', one_fill), ('three', three), ('one_then_tiny', one_then_tiny), ('eager', eager))
+res = {k: [] for k, _ in forms}
 for rep in range(5):
-    for name, fn in (('one', one), ('two', two), ('two_ev', two_ev)):
+    for name, fn in forms:
         for _ in range(5): fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
