@@ -237,7 +237,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
     };
-    constexpr bool kPrs = RM == 2;
+    // the single-panel statistics of the conditional / given posterior travel a batch ahead with eps (prs0..2) in every row mode
+    // (round 3: cell codes only; on fp32 rows the slot lanes read them in the sync phase -- a memory round trip between the
+    // barriers of every batch: VIBO_POSTERIOR_GIVEN 1.25 -> 1.21 ms at 8 dims, 1.06 -> 0.99 at 1; +5 spilled registers there)
+    constexpr bool kPrs = true;
     float prs0 = 0.f, prs1 = 0.f, prs2 = 0.f;
     // slots of this wave for a batch: [s0, s1) in steps of `step` (one slot at most with 4 or more waves)
     auto my_slots = [&](const int par, int& s0, int& s1, int& step) {
