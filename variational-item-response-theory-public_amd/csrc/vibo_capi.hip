@@ -1025,7 +1025,12 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
         cp.B = d->num_person; cp.I_total = I; cp.A = A; cp.mask_dtype = d->mask_dtype;
         cp.coef_panels = pl.panels; cp.rec_stride = pl.cond_rec; cp.coef_in = coef;
         e = hipSuccess;
-        if (pl.given) {
+        const bool given_direct = pl.given && pl.panels == 1;      // one panel: the kernel's slot lanes read / write the posterior themselves
+        if (given_direct) {
+            p.given_post = table;
+            p.given_grad = grad ? grad_table : nullptr;
+            p.table = item;               // the 2-row expert table is not used in this mode: any finite floats (>= 4 A of them)
+        } else if (pl.given) {
             const long long n = (long long)d->num_person * (A + 1);
             hipLaunchKernelGGL(given_pre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, pre,
                                (long long)d->num_person, A, I);
@@ -1092,7 +1097,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             p.I = I - p.item0 < 1024 ? I - p.item0 : 1024;
             p.primary = pn == 0 ? 1 : 0;
             p.partial = partial + (size_t)pn * pl.split_nblk * pl.lay.stride;
-            p.post_coef = ((pl.cond || pl.given) && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
+            p.post_coef = ((pl.cond || (pl.given && !given_direct)) && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
             const int nq = (p.I + 255) / 256;
             e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s, pl.msplit);
         }
@@ -1118,7 +1123,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
                 if (e == hipSuccess) e = launch_cond_finalize(cpart, grad_table, I, A, pl.panels, pl.cond_post_nblk, pl.cond_rec, s, &tail);
             }
         }
-        if (pl.given && grad && e == hipSuccess) {
+        if (pl.given && !given_direct && grad && e == hipSuccess) {
             const long long n = (long long)d->num_person * A;
             hipLaunchKernelGGL(given_post_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, coef, pl.panels,
                                grad_table, (long long)d->num_person, A);

@@ -260,7 +260,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             const int row = bt * R + ((64 * s0 + lane) >> 3);
             epn = (ed < A && row < p.B) ? p.eps[(long long)row * A + ed] : 0.f;
             if constexpr (EXTRA && kPrs) {
-                if (p.pre_stats && p.pre_panels == 1) {
+                if (p.given_post) {                    // caller-supplied posterior (given_pre_kernel's statements)
+                    const bool lv = ed < A && row < p.B;
+                    const float* po = p.given_post + (size_t)(lv ? row : 0) * 2 * A;
+                    const float lam_g = expf(-po[lv ? A + ed : 0]);
+                    prs0 = lv ? lam_g : 0.f; prs1 = lv ? po[ed] * lam_g : 0.f; prs2 = lv ? (float)p.I_total : 0.f;
+                } else if (p.pre_stats && p.pre_panels == 1) {
                     const bool lv = ed < A && row < p.B;
                     const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
                     prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
@@ -550,8 +555,18 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         }
+        if constexpr (EXT) {
+            if (p.given_post) {
+                lam = 0.f; smu = 0.f; nobs = (float)p.I_total;
+                if (live) {
+                    const float* po = p.given_post + (size_t)(row0 + pp) * 2 * A;
+                    lam = expf(-po[A + ed]);
+                    smu = po[ed] * lam;
+                }
+            }
+        }
         if constexpr (EXTRA && !EXT && kPrs) {
-            if (p.pre_stats) { lam = prs0; smu = prs1; nobs = prs2; }
+            if (p.pre_stats || p.given_post) { lam = prs0; smu = prs1; nobs = prs2; }
         }
         const float nmiss = (float)p.I_total - nobs;
         lam = fmaf(nmiss, prior_w, lam);
@@ -690,6 +705,16 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             glv[1] = gz1 * h - 0.5f;
         }
         if (!reg_on) { gmu[1] = 0.f; glv[1] = 0.f; }
+        if (EXTRA && p.given_grad) {
+            if (live) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    float* gg = p.given_grad + ((size_t)st * p.B + (row0 + pp)) * 2 * A;
+                    gg[ed] = gmu[st];
+                    gg[A + ed] = glv[st];
+                }
+            }
+        }
         if (EXTRA && p.post_coef) {
             if (live) {
                 float* pc = p.post_coef + (size_t)(row0 + pp) * 4 * A;
@@ -722,7 +747,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         my_slots(par, s0, s1, step);
         if constexpr (EXTRA || !NW8) {
             bool ext = nw < 4;                                   // (wave-uniform)
-            if constexpr (EXTRA) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));
+            if constexpr (EXTRA) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
             if (ext) {
                 // (without the EXTRA hooks the plain variant serves the narrow workgroups too: eps is loaded here)
 #pragma unroll 1
@@ -1200,7 +1225,7 @@ static hipError_t launch_msplit_inst(const ElboParams& p, int nw, int grid, hipS
 template <int IRT, bool GRAD, int RM, bool FLOWS>
 static hipError_t launch_msplit_one(const ElboParams& p, int nw, int grid, hipStream_t s) {
     // EXTRA: the panel / conditional / given hooks (see the kernel); NW8: exactly 8 waves per workgroup
-    const bool extra = p.row_cnt || p.pre_stats || p.post_coef || !p.primary;
+    const bool extra = p.row_cnt || p.pre_stats || p.post_coef || p.given_post || p.given_grad || !p.primary;
     if (nw == 8) return extra ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, true>(p, nw, grid, s)
                               : launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, false>(p, nw, grid, s);
     return extra ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, true>(p, nw, grid, s)

@@ -69,6 +69,11 @@ struct ElboParams {
     const float* pre_stats;   // [pre_panels][B][2A+1] = lam[A] | s[A] | nobs, or null
     float* post_coef;         // [B][2 sets][2][A]: P1 = gmu / lam, P2 = -(gmu amu + glv) / lam   (this launch's share)
     int pre_panels;
+    // VIBO_POSTERIOR_GIVEN, one panel: the caller's posterior read by the slot lanes themselves (lam = exp(-logvar), s = mu lam,
+    // nobs = I_total: given_pre_kernel's statements) and its gradient written by them (d/d mu, d/d logvar of the two sets:
+    // the posterior IS (mu, logvar) there) -- no pre_stats / post_coef round trip, two launches less per call
+    const float* given_post;  // [B][2A] = mu | logvar, or null
+    float* given_grad;        // [2 sets][B][2A], or null
     long long resp_stride, mask_stride;
     int B, I, A, D, DP;
     int n_tiles, lds_stride, lds_main;

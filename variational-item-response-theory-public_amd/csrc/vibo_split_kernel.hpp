@@ -349,6 +349,14 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
                 }
             }
         }
+        if (p.given_post) {                 // caller-supplied posterior (given_pre_kernel's statements)
+            lam = 0.f; smu = 0.f; nobs = (float)p.I_total;
+            if (live) {
+                const float* po = p.given_post + (size_t)(row0 + er) * 2 * A;
+                lam = expf(-po[A + ed]);
+                smu = po[ed] * lam;
+            }
+        }
         const float nmiss = (float)p.I_total - nobs;
         if (p.missing_mode == 0) lam += nmiss * (1.0f / (1.0f + kPoeEps));
         if (!live) lam = 1.0f;              // rows past the end / padded dims: keep the arithmetic finite
@@ -600,6 +608,16 @@ __global__ __launch_bounds__(256, (RM == 2 && (AT <= 2 || (AT == 4 && IRT <= 2))
                     glv[1] = gz1 * h - 0.5f;
                 }
                 if (!reg_on) { gmu[1] = 0.f; glv[1] = 0.f; }
+                if (p.given_grad) {
+                    if (live) {
+#pragma unroll
+                        for (int st = 0; st < 2; ++st) {
+                            float* gg = p.given_grad + ((size_t)st * p.B + (row0 + er)) * 2 * A;
+                            gg[ed] = gmu[st];
+                            gg[A + ed] = glv[st];
+                        }
+                    }
+                }
                 if (p.post_coef) {
                     if (live) {
                         float* pc = p.post_coef + (size_t)(row0 + er) * 4 * A;
