@@ -190,7 +190,8 @@ def fuzz_trainer():
         ref = cls(A, I, hidden_dim=hidden, ability_merge='product').to(d)
         if irt == 3:      # keep 3PL logits out of the probability-clamp band (|logit| > ~12), where 1-ulp differences of the
             with torch.no_grad():      # item sample (torch ops vs the prologue kernel) flip single cells with O(1) gradients
-                ref.item_encoder.mu_lookup.weight.mul_(0.5)
+                ref.item_encoder.mu_lookup.weight.mul_(0.5 if A <= 3 else 0.25)      # (the logit's spread grows with sqrt(A): seed 777 found
+                #  3PL, 8 dims, 256 items at 1.2 % of the encoder's first moment with 0.5 -- tests/test_gpu_trainer.py notes the same band)
         fus = copy.deepcopy(ref)
         opt = torch.optim.Adam(ref.parameters(), lr=lr)
         trainer = FusedTrainer(fus, lr=lr)
