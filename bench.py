@@ -11,8 +11,9 @@ timed region), the persons sharded over the N ranks (`--scaling strong`, the def
 matrix; `--scaling weak` gives every rank 1M persons, and a run with N > 1 reports that too, under `also_weak`).  `also`
 repeats the measurement at ability_dim 1 (configs[1]'s width, the reference default).  One step = one ELBO train step over the
 rank's whole person shard, replayed from a hipGraph -- TWO launches (the folded step, vibo_amd/trainer.py):
-vibo_elbo_fwd_bwd_train (the row-split ELBO kernel; its own prologue forms the item sample, the item KL and the encoder
-table) and vibo_train_epilogue_fused (finalize, loss, encoder-MLP / item backward, Adam, the next step's Philox noise); with
+vibo_elbo_fwd_bwd_step (the row-split ELBO kernel; everything it reads -- item sample, encoder table, noise -- was left in
+memory by the previous step's epilogue) and vibo_train_epilogue_fused (finalize, loss, encoder-MLP / item backward, Adam, and
+the NEXT step's head: Philox noise, item sample, item KL, encoder table); with
 N > 1 the finalize stays with the first launch and ONE all-reduce of the flat [scalars | grads] buffer sits between the two
 (captured inside the step's graph by default, `--two-graphs` for an eager collective between two graphs).
 --torch-optimizer runs the O(I) part as PyTorch autograd + torch.optim.Adam instead.
@@ -34,6 +35,9 @@ Adds to the contract line:
                 the matrix kernel starts at 4 096 persons / 32 768 at ability_dim <= 4), and the line says so
                 (elbo_rel_err_detail.kernel = vibo_plan_kernel's answer).  `also` and `format_p` carry their own.
   roofline.frac_step  the same algorithmic bytes over the whole timed step (ms_per_step), next to the kernel-only frac.
+  also_config2  BASELINE configs[1] LITERALLY: 2PL, 100 000 persons x 1 000 items, ability_dim 1, on one GPU -- the same train step
+                (a launch of 12.2 batches per workgroup: the kernel's one-shot prologue / end code and the 12-vs-13-round
+                quantisation show), with its own kernel and step fractions of the 8 TB/s roofline (N = 1 only).
   extra         config5_path: BASELINE configs[4]'s path (3PL, 10 000 items, conditional, 4 flows) on 100 000 persons;
                 decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate);
                 train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md 8d;
@@ -74,6 +78,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong', help="'strong' (default): --persons is the whole matrix, split over the ranks (BASELINE configs[2] literally: 1M x 1k over 8 GPUs); 'weak': every rank holds --persons rows")
+    ap.add_argument('--no-also-config2', action='store_true', help='skip the BASELINE configs[1] leg (100k x 1k, ability_dim 1: also_config2)')
     ap.add_argument('--no-also-weak', action='store_true', help='N > 1 under strong scaling: skip the extra weak-scaling measurement (also_weak)')
     ap.add_argument('--no-extra', action='store_true', help='skip the minibatch-size sweep and the ELBO rel-err check')
     ap.add_argument('--eval-only', action='store_true', help='forward ELBO only (no backward/optimizer)')
@@ -692,6 +697,24 @@ def main():
                 'elbo_rel_err': m2['rel']['vs_reference_op_sequence_fp32'] if m2.get('rel') else None,
                 'elbo_rel_err_kernel': m2['rel']['kernel'] if m2.get('rel') else None}
 
+    also_config2 = None
+    if world == 1 and not args.no_also_config2 and not args.eval_only:
+        # BASELINE configs[1] literally (100k x 1k, ability_dim 1): a short launch, reported with its own fractions
+        Pc2 = 100_000
+        save = args.no_extra
+        args.no_extra = True             # (no rel-err / sweep legs of its own)
+        mc = measure(1, persons=Pc2)
+        args.no_extra = save
+        bc = 5.0 + 12.0 * 1 / I
+        also_config2 = {'workload': f'BASELINE configs[1]: {args.irt_model.upper()} simulation, {Pc2} persons x {I} items, ability_dim=1, {args.missing:.0%} missing, one GPU, full-matrix minibatch',
+                        'value': float(Pc2) * I * args.steps / mc['dt'], 'unit': 'terms/s', 'ms_per_step': mc['dt'] / args.steps * 1e3,
+                        'kernel_ms': mc['kern_ms'], 'kernel_timing': mc.get('instep'), 'bare_launch_ms': mc.get('bare_ms'),
+                        'bytes_per_term': bc, 'launch': mc['launch'],
+                        'roofline_achieved_GBps': bc * Pc2 * I / (mc['kern_ms'] * 1e-3) / 1e9,
+                        'roofline_frac': bc * Pc2 * I / (mc['kern_ms'] * 1e-3) / 1e9 / 8000.0,
+                        'roofline_frac_step': bc * Pc2 * I * args.steps / mc['dt'] / 1e9 / 8000.0,
+                        'note': '3 125 batches of 32 rows over 256 workgroups = 12.2 per workgroup (13 rounds) + the kernel\'s one-shot prologue / end code: a short-launch regime, not the streaming one of the headline'}
+
     format_p = None
     if not args.no_format_p:
         m3 = measure(A, codes=True)
@@ -758,6 +781,8 @@ def main():
             line['extra'] = {'decoder_kernel': decoder_probe(), 'config5_path': config5_probe(), 'conditional_posterior': conditional_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
         if also is not None:
             line['also'] = also
+        if also_config2 is not None:
+            line['also_config2'] = also_config2
         if format_p is not None:
             line['format_p'] = format_p
         if world == 1 and not args.no_cpu_baseline:

@@ -269,6 +269,12 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
             pl->AT = 8;
             pl->DP = prepped_item_width(d->irt_model, 8);
             pl->split_nblk = msplit_blocks(num_cu, I < 1024 ? I : 1024, d->num_person);
+            if (pl->panels > 1) {
+                // all panels in ONE launch (ElboParams::panel_count): the chip's workgroup slots are shared out over the panels
+                int per = num_cu / pl->panels;
+                if (per < 1) per = 1;
+                if (pl->split_nblk > per) pl->split_nblk = per;
+            }
         }
         pl->nblk = 0;
         pl->lds_main = 0;
@@ -1052,9 +1058,20 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             p.pre_stats = pre;
             p.pre_panels = 1;
         } else if (pl.cond) {
-            for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
+            // more than one panel: ALL of them in one launch per 4 ability dims (CondParams::panel_count), the chip's workgroup
+            // slots shared out over the panels
+            const bool one_launch = pl.panels > 1;
+            const int pre_launches = one_launch ? 1 : pl.panels;
+            int pre_blocks = cond_blocks;
+            if (one_launch) {
+                int per = cond_blocks / pl.panels;
+                if (per < 1) per = 1;
+                pre_blocks = per * pl.panels;
+                cp.panel_count = pl.panels;
+            }
+            for (int pn = 0; pn < pre_launches && e == hipSuccess; ++pn) {
                 cp.item0 = pn * 1024;
-                cp.I = I - cp.item0 < 1024 ? I - cp.item0 : 1024;
+                cp.I = one_launch ? 1024 : (I - cp.item0 < 1024 ? I - cp.item0 : 1024);
                 cp.pre_out = pre + (size_t)pn * d->num_person * (2 * A + 1);
                 for (cp.a0 = 0; cp.a0 < A && e == hipSuccess; cp.a0 += 4) {     // 4 ability dims per launch
                     cp.codes_out = (emit && cp.a0 == 0) ? code_rows : nullptr;
@@ -1063,10 +1080,11 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
                         cq.response = nullptr; cq.mask = code_rows; cq.row_index = nullptr;
                         cq.mask_stride = pl.codes_stride; cq.mask_dtype = VIBO_MASK_CODES;
                     }
-                    e = launch_cond_pre(cq, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, cond_blocks, s);   // own template width (3PL widens the split kernel's)
+                    e = launch_cond_pre(cq, A == 1 ? 1 : A <= 2 ? 2 : 4, (cp.I + 255) / 256, pre_blocks, s);   // own template width (3PL widens the split kernel's)
                 }
             }
             cp.codes_out = nullptr;
+            cp.panel_count = 0;
             p.pre_stats = pre;
             p.pre_panels = pl.panels;
             if (pl.panels > 1 && e == hipSuccess) {
@@ -1092,6 +1110,13 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             cp.response = nullptr; cp.mask = code_rows; cp.row_index = nullptr;
             cp.mask_stride = pl.codes_stride; cp.mask_dtype = VIBO_MASK_CODES;
         }
+        if (pl.msplit && pl.panels > 1 && e == hipSuccess) {
+            // the matrix kernel takes all panels in one launch: workgroup = (panel, slot), see ElboParams::panel_count
+            p.item0 = 0; p.I = 1024; p.primary = 1; p.panel_count = pl.panels;
+            p.partial = partial;
+            p.post_coef = ((pl.cond || (pl.given && !given_direct)) && grad) ? coef : nullptr;
+            e = launch_split(p, pl.AT, codes, d->irt_model, grad, 4, pl.panels * pl.split_nblk, s, true);
+        } else
         for (int pn = 0; pn < pl.panels && e == hipSuccess; ++pn) {
             p.item0 = pn * 1024;
             p.I = I - p.item0 < 1024 ? I - p.item0 : 1024;
@@ -1187,7 +1212,11 @@ int vibo_train_step_supported(const vibo_desc* d) {
     Plan pl;
     if (make_plan(d, &pl) < 0) return 0;
     if (!step_plan_ok(d, pl)) return 0;
-    return 1 | (pl.split_nblk < 1024 ? 2 : 0);     // bit 1: vibo_train_epilogue_fused can also take over the finalize
+    // bit 1: vibo_train_epilogue_fused can also take over the finalize -- where it sums the partial records in the same order as the
+    // stand-alone finalize would (16 slices; elbo_fwd_bwd_impl picks the 64-slice finalize_kernel<16> for fewer than 65 outputs
+    // or 1024+ records: there the four-launch form and the folded one would differ in the last bits)
+    const int n_out = 8 + 8 * d->ability_dim + d->num_item * pl.D;
+    return 1 | ((pl.split_nblk < 1024 && n_out > 64) ? 2 : 0);
 }
 
 int vibo_elbo_fwd_bwd_step(const vibo_desc* d, int32_t* step_count, int skip_finalize, const float* response, const void* mask,

@@ -125,9 +125,20 @@ __device__ __forceinline__ void word_indicators(const uint32_t wd, const uint32_
 
 // ---------------------------------------------------------------------------
 template <int AT, bool CODES>
-__global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const CondParams p) {
+__global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const CondParams p_in) {
     constexpr int NV = 2 * AT + 1;
     __shared__ float part[4][kCR][NV];
+    // all panels of a wide row in one launch (CondParams::panel_count): this workgroup's panel, its share of the row batches
+    CondParams p = p_in;
+    long long bt0 = blockIdx.x, bstep = gridDim.x;
+    if (p_in.panel_count > 1) {
+        const int panel = (int)(blockIdx.x % (unsigned)p_in.panel_count);
+        bt0 = blockIdx.x / (unsigned)p_in.panel_count;
+        bstep = gridDim.x / (unsigned)p_in.panel_count;
+        p.item0 = panel * 1024;
+        p.I = p.I_total - p.item0 < 1024 ? p.I_total - p.item0 : 1024;
+        p.pre_out = p_in.pre_out + (size_t)panel * p.B * (2 * p.A + 1);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nq = blockDim.x >> 6;
@@ -158,9 +169,9 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
         }
     const long long n_batches = ((long long)p.B + kCR - 1) / kCR;
     RowBatch<CODES> rb;
-    long long bt = blockIdx.x;
+    long long bt = bt0;
     if (bt < n_batches) load_rows(p, bt, chunk, chunk_ok, rb);
-    for (; bt < n_batches; bt += gridDim.x) {
+    for (; bt < n_batches; bt += bstep) {
         const long long row0 = bt * kCR;
         float v[NV][kCR];
 #pragma unroll
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
             }
             v[2 * AT][r] = (float)nobs;
         }
-        if (bt + gridDim.x < n_batches) load_rows(p, bt + gridDim.x, chunk, chunk_ok, rb);
+        if (bt + bstep < n_batches) load_rows(p, bt + bstep, chunk, chunk_ok, rb);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const float t = bfly8f(v[k], lane);            // lane l: row l >> 3

@@ -19,6 +19,8 @@ struct CondParams {
     uint8_t* codes_out;        // cond_pre on fp32 rows: if set, the rows' 1-byte cell codes go here ([B][codes_stride], minibatch order)
     long long codes_stride;
     int a0;                    // first ability dim of this launch (dims a0 .. a0 + AT - 1: more than 4 dims take two launches)
+    int panel_count;           // cond_pre: > 1 = ALL 1024-item panels in this launch (workgroup blockIdx.x = slot * panel_count + panel;
+                               // item0 / I / pre_out follow from it): ten launches of a 10 000-item row become one
 };
 
 hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s);

@@ -68,13 +68,16 @@ __device__ __forceinline__ dh2 dpk(float a, float b) { return __builtin_bit_cast
 // 8 floats -> f16 hi and lo pieces (x = hi + lo to 2^-22)
 // (hi = round-toward-zero pair; lo = f16(x - hi) by two mixed-precision fmas that write the two halves of one register)
 __device__ __forceinline__ void split8(const float* x, dh8& hi, dh8& lo) {
+    uint32_t hw[4], lw[4];
+    float xv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[e] = x[e];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) hw[e >> 1] = __builtin_bit_cast(uint32_t, dpk(x[e], x[e + 1]));
+    lo_pieces4(hw, xv, lw);      // (one asm block ending in the wait states an MFMA consumer needs: vibo_device.hpp)
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
-        const dh2 h = dpk(x[e], x[e + 1]);
-        uint32_t lw;
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(h), "v"(x[e]));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(h), "v"(x[e + 1]));
-        const dh2 l = __builtin_bit_cast(dh2, lw);
+        const dh2 h = __builtin_bit_cast(dh2, hw[e >> 1]), l = __builtin_bit_cast(dh2, lw[e >> 1]);
         hi[e] = h[0]; hi[e + 1] = h[1];
         lo[e] = l[0]; lo[e + 1] = l[1];
     }

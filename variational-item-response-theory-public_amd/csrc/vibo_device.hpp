@@ -129,4 +129,27 @@ __device__ __forceinline__ uint32_t cell_codes4(const float4 x, const uint32_t m
     return (hi & m & 0x01010101u) | ((m ^ 0x01010101u) << 1);
 }
 
+// Four (a, b) float pairs -> their f16 hi pieces (round toward zero, one v_cvt_pkrtz each -- by the caller) and lo pieces
+// lo = f16(x - hi) by two mixed-precision fmas per pair that write the two halves of one register.
+// ONE asm block that ends in `s_nop 1`: the compiler's hazard recognizer does not see what inline asm writes, and a VALU result
+// needs two wait states before a v_mfma reads it (plus the destination-select forwarding state of the half-register writes).
+// Rounds 2-4 had the two instructions as separate asm statements: wherever the scheduler placed the second one right in front
+// of the MFMA that reads the pair, the MFMA took the register's OLD upper half -- seen in round 5 as d LL/d a of the odd item
+// tiles off by 10x, not reproducible run to run, in the one instantiation (3PL + flows + gathered fp32 rows) whose schedule
+// happened to do that.
+__device__ __forceinline__ void lo_pieces4(const uint32_t (&hi)[4], const float (&x)[8], uint32_t (&lo)[4]) {
+    asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]),
+          "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+}
+
 }  // namespace vibo

@@ -80,8 +80,13 @@ struct alignas(16) MsFlowLds {      // planar flows only (appended to the dynami
     float lacc[2][kMsRows];         // running sums of the persons' log|det| terms
     float facc[2][4][2][kMsMF][3][8];   // [batch parity][slot][set: LL | REG][flow][uhat | w | b][dim]: running flow-parameter gradients
 };
-inline size_t msplit_lds_bytes(int nw, bool flows = false) {
-    return sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (flows ? sizeof(MsFlowLds) : 0);
+// 3PL only (behind the flow block): the guess probabilities of a wave's 128 items, [u-step][tile t][chunk i16] -- they used to
+// sit in 16 registers per lane (guess and 1 - guess of its 8 items) next to the 8 guess-gradient accumulators, which is what
+// pushed every 3PL instantiation with gradients over the 256-register budget (8..136 B of scratch per lane)
+constexpr int kMsGuessFloats = 2 * 4 * 16;
+inline size_t msplit_lds_bytes(int nw, bool flows = false, bool guess = false) {
+    return sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (flows ? sizeof(MsFlowLds) : 0) +
+           (guess ? (size_t)nw * kMsGuessFloats * sizeof(float) : 0);
 }
 // sum over the 8 consecutive lanes that hold one person's ability dims (every lane of the group gets it)
 __device__ __forceinline__ float ms_group_sum(float v) {
@@ -120,14 +125,19 @@ __device__ __forceinline__ half8 cat8(const half2v a, const half2v b, const half
 // through p.row_index; 2 = 1-byte cell codes (VIBO_MASK_CODES, through p.mask), with or without p.row_index.
 // FLOWS: planar flows on the ability sample (flows.py:21-66, models.py:342-348) in the (person, dim) lanes.
 // NW8: the workgroup has exactly 8 waves (897..1024 items, the benchmark's width): slot ownership and the sums over the
-// waves' LDS records are compile-time.  EXTRA: the launch uses one of the panel / conditional / given hooks (p.row_cnt,
-// p.pre_stats, p.post_coef, p.primary == 0); without it those branches do not exist in the code.
+// waves' LDS records are compile-time.  XM: which hooks the launch uses (0: none -- those branches do not exist in the code;
+// 1: panel / conditional: p.row_cnt, p.pre_stats, p.post_coef, p.primary == 0, p.panel_count; 2: p.given_post / p.given_grad).
 // blockDim.x = 64 nw, dynamic LDS = msplit_lds_bytes(nw, FLOWS).
 // The kernel runs at 2 waves per SIMD, where a wave issues at most one instruction per ~5 cycles whatever its type: every
 // scalar instruction, branch and spill reload in the batch loop costs as much as a vector instruction (round 3: the loop
 // lost ~500 of its ~2 300 executed instructions per wave and batch this way).
-template <int IRT, bool GRAD, int RM, bool FLOWS, bool NW8, bool EXTRA>
+template <int IRT, bool GRAD, int RM, bool FLOWS, bool NW8, int XM>
 __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
+    // XM (hook mode): 0 = none; 1 = the panel / conditional hooks (p.row_cnt, p.pre_stats, p.post_coef, p.primary, p.panel_count);
+    // 2 = the caller-supplied posterior read / written by the slot lanes themselves (p.given_post, p.given_grad; one panel).
+    // Two modes instead of one EXTRA flag (round 4): each carries the other's pointers, branches and -- the given mode's expf /
+    // logvar loads -- spilled registers no longer.
+    constexpr bool EXTRA = XM != 0, XCOND = XM == 1, XGIVEN = XM == 2;
     constexpr bool CODES = RM == 2;
     constexpr int R = kMsRows;
     constexpr float kLoS = kLogitLo * kLog2e, kHiS = kLogitHi * kLog2e;
@@ -149,7 +159,26 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int nw = NW8 ? 8 : (int)(blockDim.x >> 6);
     MsWaveLds& wl = wls[q];
     MsFlowLds& fl = *reinterpret_cast<MsFlowLds*>(ms_smem + sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds));   // (FLOWS only)
-    const int I = p.I, A = p.A;
+    // Panel mode in ONE launch (rows of more than 1024 items, EXTRA only): p.panel_count 1024-item panels x G workgroups each,
+    // workgroup blockIdx.x = G-slot * panel_count + panel -- the panels of a row batch start side by side (one DRAM page run),
+    // every workgroup builds its operand image once and streams ceil(batches / G) batches of ITS panel, and the records land
+    // where the per-panel launches of rounds 1-4 put them (panel-major).  Those launches paid the kernel's one-shot prologue /
+    // end code (~18 us) and a 12.2 -> 13-round quantisation once per panel of a 100 000-row call.
+    int wg = (int)blockIdx.x, G = (int)gridDim.x, item0 = p.item0, I = p.I, rec = (int)blockIdx.x;
+    bool primary = XCOND ? p.primary != 0 : true;
+    float* post_coef = XCOND ? p.post_coef : nullptr;
+    if constexpr (XCOND) {
+        if (p.panel_count > 1) {
+            const int panel = wg % p.panel_count;
+            wg /= p.panel_count; G /= p.panel_count;
+            item0 = panel * 1024;
+            I = min(p.I_total - item0, 1024);
+            primary = panel == 0;
+            if (post_coef) post_coef += (size_t)panel * p.B * 4 * p.A;
+            rec = panel * G + wg;
+        }
+    }
+    const int A = p.A;
     const int n4 = (I + 3) >> 2;
     const int i16 = lane & 15, g = lane >> 4;
 
@@ -196,9 +225,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const unsigned br = rows > 0 ? (unsigned)(rows - 1) * rstride4 + 16u * n4 : 0u;
         const unsigned bm = (rows > 0 && have_mask) ? (unsigned)(rows - 1) * mstride + 4u * n4 : 0u;
         RowSrc rs;
-        rs.m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(static_cast<const uint8_t*>(p.mask) + (size_t)bt * R * p.mask_stride + p.item0),
+        rs.m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(static_cast<const uint8_t*>(p.mask) + (size_t)bt * R * p.mask_stride + item0),
                                                  (short)0, (int)bm, 0x00020000);
-        if constexpr (!CODES) rs.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.response + (size_t)bt * R * p.resp_stride + p.item0),
+        if constexpr (!CODES) rs.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.response + (size_t)bt * R * p.resp_stride + item0),
                                                                        (short)0, (int)br, 0x00020000);
         else rs.r = rs.m;
         return rs;
@@ -220,15 +249,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             if (bt >= n_batches) return;
             const long long src = (long long)ridx[4 * h + j];
             if constexpr (CODES) {
-                const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
+                const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + item0);
                 m[2 * j] = mp[cc0];
                 m[2 * j + 1] = mp[cc1];
             } else {
-                const float4* rp = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0);
+                const float4* rp = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + item0);
                 x[2 * j] = rp[cc0];
                 x[2 * j + 1] = rp[cc1];
                 if (p.mask_dtype == 0) {
-                    const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0);
+                    const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + item0);
                     m[2 * j] = mp[cc0];
                     m[2 * j + 1] = mp[cc1];
                 } else {
@@ -258,14 +287,20 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         my_slots(par, s0, s1, step);
         if (s0 < s1) {
             const int row = bt * R + ((64 * s0 + lane) >> 3);
+            // (the lane's dim goes through an empty asm: hipcc otherwise keeps 64-bit per-lane bases `pointer + 4 ed` of every
+            //  array read here live across the whole batch -- in the instantiations at the register limit they were the spilled
+            //  values, reloaded from scratch right here in every batch)
+            int ed = lane & 7;
+            asm volatile("" : "+v"(ed));
             epn = (ed < A && row < p.B) ? p.eps[(long long)row * A + ed] : 0.f;
-            if constexpr (EXTRA && kPrs) {
-                if (p.given_post) {                    // caller-supplied posterior (given_pre_kernel's statements)
-                    const bool lv = ed < A && row < p.B;
-                    const float* po = p.given_post + (size_t)(lv ? row : 0) * 2 * A;
-                    const float lam_g = expf(-po[lv ? A + ed : 0]);
-                    prs0 = lv ? lam_g : 0.f; prs1 = lv ? po[ed] * lam_g : 0.f; prs2 = lv ? (float)p.I_total : 0.f;
-                } else if (p.pre_stats && p.pre_panels == 1) {
+            if constexpr (XGIVEN && kPrs) {            // caller-supplied posterior (given_pre_kernel's statements)
+                const bool lv = ed < A && row < p.B;
+                const float* po = p.given_post + (size_t)(lv ? row : 0) * 2 * A;
+                const float lam_g = expf(-po[lv ? A + ed : 0]);
+                prs0 = lv ? lam_g : 0.f; prs1 = lv ? po[ed] * lam_g : 0.f; prs2 = lv ? (float)p.I_total : 0.f;
+            }
+            if constexpr (XCOND && kPrs) {
+                if (p.pre_stats && p.pre_panels == 1) {
                     const bool lv = ed < A && row < p.B;
                     const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
                     prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
@@ -275,14 +310,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     };
     // ---- the first batch's rows (M-tile 0) and noise are requested before anything else: their HBM / TLB latency (the first
     //      touch of this workgroup's pages) runs under the operand-image build below instead of after it
-    int bt = (int)blockIdx.x;
+    int bt = wg;
     const RowSrc src_first = row_src(bt);
     if (bt < n_batches) {
         fetch_idx(bt, ridx);
 #pragma unroll
         for (int j = 0; j < 4; ++j) load_quarter(bt, src_first, 0, j);
         fetch_eps(bt, 0);
-        fetch_idx(bt + (int)gridDim.x, ridx_n);
+        fetch_idx(bt + G, ridx_n);
     }
 
     auto put_ctab = [&](const float* table) {
@@ -340,7 +375,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     //     (bsh = 0 below 2^15).
     // Beyond that (|b| > 2^30, or a sample with |theta 2^-jsh| > 65 504) the results turn into NaN rather than into
     // silently wrong numbers; VIBO_FLAG_KERNEL_VALU runs such inputs on the fp32 VALU kernel.
-    float gs[2][4], om[2][4];           // 3PL: guess, 1 - guess of the lane's items
+    // 3PL: guess probabilities of the wave's items, read back per tile (see kMsGuessFloats)
+    float* const gsl = reinterpret_cast<float*>(ms_smem + sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (FLOWS ? sizeof(MsFlowLds) : 0)) + q * kMsGuessFloats;
     float na_raw[2][8], nb_raw[2];
     float amax = 0.f, bmax = 0.f;
 #pragma unroll
@@ -348,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int xl = 64 * h + lane;                                   // item of the wave, one per lane and pass
         const int il = kMsSpan * q + xl;
         const bool ok = il < I;
-        const size_t ir = (size_t)(p.item0 + (ok ? il : 0)) * p.D;     // (entry index into the caller's item sample)
+        const size_t ir = (size_t)(item0 + (ok ? il : 0)) * p.D;     // (entry index into the caller's item sample)
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float na = 0.f;
@@ -410,9 +446,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         for (int t = 0; t < 4; ++t) {
             const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
             const bool ok = IRT == 3 && il < I;
-            const float gv = ok ? 1.0f / (1.0f + expf(-p.item_raw[(size_t)(p.item0 + il) * p.D + A + 1])) : 0.f;   // models.py:758
-            gs[u][t] = gv;
-            om[u][t] = 1.0f - gv;
+            if constexpr (IRT == 3) {
+                const float gv = ok ? 1.0f / (1.0f + expf(-p.item_raw[(size_t)(item0 + il) * p.D + A + 1])) : 0.f;   // models.py:758
+                if (g == 0) gsl[(u * 4 + t) * 16 + i16] = gv;
+            }
         }
     // per-lane offsets (halfs) into the operand image
     const int b1ofs = i16 * kMsItemLane + (g == 1 ? 8 : g == 3 ? 16 : 0);
@@ -512,7 +549,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     //  eps -- prs -- and the plain variant serves them: the conditional posterior's matrix pass runs on emitted codes)
     // prior experts of the missing cells (models.py:613-620): weight 1 / (1 + eps) each, or dropped
     const float prior_w = p.missing_mode == 0 ? 1.0f / (1.0f + kPoeEps) : 0.f;
-    const bool primary = EXTRA ? p.primary != 0 : true;
     auto forward_slot = [&](auto extc, const int bt, const int par, const int s, const float eps_c) {
         constexpr bool EXT = decltype(extc)::value;
         static_assert(EXTRA || !EXT, "the global-memory variant belongs to the EXTRA instantiations");
@@ -521,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const bool live = ed < A && (row0 + pp) < p.B;
         int cnt = 0;
         bool have_cnt = false;
-        if constexpr (EXT) {
+        if constexpr (EXT && XCOND) {
             if (p.row_cnt) {
                 cnt = live ? p.row_cnt[row0 + pp] : 0;
                 have_cnt = true;
@@ -544,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         // (written as one fma each: the contraction hipcc picks for a sum of two products depends on the surrounding code,
         //  and the variants of this kernel have to agree bit for bit)
         float lam = fmaf(n0, tau0, n1 * tau1), smu = fmaf(n0, mt0, n1 * mt1);
-        if constexpr (EXT) {
+        if constexpr (EXT && XCOND) {
             if (p.pre_stats) {
                 lam = 0.f; smu = 0.f; nobs = 0.f;
                 if (live) {
@@ -555,18 +591,16 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         }
-        if constexpr (EXT) {
-            if (p.given_post) {
-                lam = 0.f; smu = 0.f; nobs = (float)p.I_total;
-                if (live) {
-                    const float* po = p.given_post + (size_t)(row0 + pp) * 2 * A;
-                    lam = expf(-po[A + ed]);
-                    smu = po[ed] * lam;
-                }
+        if constexpr (EXT && XGIVEN) {
+            lam = 0.f; smu = 0.f; nobs = (float)p.I_total;
+            if (live) {
+                const float* po = p.given_post + (size_t)(row0 + pp) * 2 * A;
+                lam = expf(-po[A + ed]);
+                smu = po[ed] * lam;
             }
         }
         if constexpr (EXTRA && !EXT && kPrs) {
-            if (p.pre_stats || p.given_post) { lam = prs0; smu = prs1; nobs = prs2; }
+            if (XGIVEN || p.pre_stats) { lam = prs0; smu = prs1; nobs = prs2; }
         }
         const float nmiss = (float)p.I_total - nobs;
         lam = fmaf(nmiss, prior_w, lam);
@@ -705,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             glv[1] = gz1 * h - 0.5f;
         }
         if (!reg_on) { gmu[1] = 0.f; glv[1] = 0.f; }
-        if (EXTRA && p.given_grad) {
+        if (XGIVEN && p.given_grad) {
             if (live) {
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
@@ -715,9 +749,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         }
-        if (EXTRA && p.post_coef) {
+        if (XCOND && post_coef) {
             if (live) {
-                float* pc = p.post_coef + (size_t)(row0 + pp) * 4 * A;
+                float* pc = post_coef + (size_t)(row0 + pp) * 4 * A;
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     pc[(st * 2 + 0) * A + ed] = gmu[st] * inv_lam;
@@ -747,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         my_slots(par, s0, s1, step);
         if constexpr (EXTRA || !NW8) {
             bool ext = nw < 4;                                   // (wave-uniform)
-            if constexpr (EXTRA) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
+            if constexpr (XCOND) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
             if (ext) {
                 // (without the EXTRA hooks the plain variant serves the narrow workgroups too: eps is loaded here)
 #pragma unroll 1
@@ -896,6 +930,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         } else {
+            // (the address goes through an empty asm so that the loop-invariant read is not hoisted back into registers)
+            int go = (u * 4 + t) * 16 + i16;
+            asm volatile("" : "+v"(go));
+            const float gs_ut = gsl[go], om_ut = 1.0f - gs_ut;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float w = wc[k];
@@ -908,16 +946,16 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 const float er_ = ee * rr_;
                 const float sp = (l >= 0.f) ? rr_ : er_;
                 const float sn = (l >= 0.f) ? er_ : rr_;
-                const float prb = fmaf(om[u][t], sp, gs[u][t]);
-                const float qr = om[u][t] * sn;
+                const float prb = fmaf(om_ut, sp, gs_ut);
+                const float qr = om_ut * sn;
                 const float pc = med3(prb, kEps32, 1.0f - kEps32);
                 const float arg = (w > 0.f) ? pc : med3(qr, kEps32, 1.0f - kEps32);
                 pr *= (w != 0.f) ? arg : 1.0f;
                 if constexpr (GRAD) {
                     const float wlv = (prb == pc) ? w : 0.f;
-                    const float common = wlv * fast_rcp(arg) * om[u][t] * sn;
+                    const float common = wlv * fast_rcp(arg) * om_ut * sn;
                     gl[k] = common * sp;
-                    acc_g[u][t] = fmaf(common, gs[u][t], acc_g[u][t]);
+                    acc_g[u][t] = fmaf(common, gs_ut, acc_g[u][t]);
                 }
             }
         }
@@ -929,15 +967,18 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             if constexpr (IRT == 3) asm volatile("" : "+v"(acc_g[u][t]));
             KTileOps ko;              // (the transposed reads fly under the split below)
             if constexpr (pend) ktile_read(std::integral_constant<int, (t == 2 ? u : 0)>{}, std::integral_constant<int, (t == 2 ? 0 : 1)>{}, ko);
-            // f16 hi/lo pieces of g: hi = rtz(g), lo = f16(g - hi) by two mixed-precision fmas writing the two halves
+            // f16 hi/lo pieces of g: hi = rtz(g), lo = f16(g - hi) (lo_pieces4: one hazard-safe asm block, see vibo_device.hpp)
             half2v hh[4], ll[4];
+            {
+                uint32_t hw[4], lw[4];
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                hh[k2] = pkrtz(gl[2 * k2], gl[2 * k2 + 1]);
-                uint32_t lw;
-                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hh[k2]), "v"(gl[2 * k2]));
-                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hh[k2]), "v"(gl[2 * k2 + 1]));
-                ll[k2] = __builtin_bit_cast(half2v, lw);
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    hh[k2] = pkrtz(gl[2 * k2], gl[2 * k2 + 1]);
+                    hw[k2] = __builtin_bit_cast(uint32_t, hh[k2]);
+                }
+                lo_pieces4(hw, gl, lw);
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) ll[k2] = __builtin_bit_cast(half2v, lw[k2]);
             }
             const half8 a2h = cat8(hh[0], hh[1], hh[2], hh[3]), a2l = cat8(ll[0], ll[1], ll[2], ll[3]);
             if constexpr (pend) ktile_mfma(ko);
@@ -986,7 +1027,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // ================= prologue: first batch =================
     uint32_t cwA0[8], cwA1[8], cwB0[8], cwB1[8];
     int pk[4];
-    const int G = (int)gridDim.x;
     if (bt < n_batches) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = 0;
@@ -1056,7 +1096,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             // 8 waves: the four waves without a forward slot in this batch own the backward slots of the previous one -- they
             // run it here, while the others compute theta, instead of after the second barrier (where it delayed their math
             // by ~1 000 cycles and the whole workgroup at the next barrier)
-            if (bt >= G + (int)blockIdx.x) person_backward(bt - G, par ^ 1);
+            if (bt >= G + wg) person_backward(bt - G, par ^ 1);
         }
         MS_T(9)
         __syncthreads();
@@ -1064,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         read_theta_ops();
         MS_T(8)
         if constexpr (GRAD && !NW8) {
-            if (bt >= G + (int)blockIdx.x) person_backward(bt - G, par ^ 1);   // nobody waits for this
+            if (bt >= G + wg) person_backward(bt - G, par ^ 1);   // nobody waits for this
         }
         f32x4 da0, da1, db0, db1;
         logits(bopA, da0, da1);
@@ -1096,7 +1136,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     if constexpr (GRAD) {
         // backward of the workgroup's last batch
         __syncthreads();
-        if (bt >= G + (int)blockIdx.x) person_backward(bt - G, par ^ 1);
+        if (bt >= G + wg) person_backward(bt - G, par ^ 1);
     }
 
 #ifdef VIBO_MS_TIMING
@@ -1104,15 +1144,21 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop_end) :: "memory");
 #endif
     // ================= workgroup reduction -> partial record =================
-    float* out = p.partial + (size_t)blockIdx.x * p.lay.stride;
+    // The lane-derived indices are formed afresh here (from an opaque copy of the thread id): shared with the prologue's, the ones
+    // the batch loop has no use for stayed live across it -- in the instantiations at the 256-register limit they were spilled
+    // to scratch (the kernel trace's `scratch` column), however rarely reloaded.
+    int tid_e = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, i16_e = lane_e & 15, g_e = lane_e >> 4;
+    float* out = p.partial + (size_t)rec * p.lay.stride;
     {
         // 1PL/2PL: every cell without an observation contributed exactly log2(1 + 2^0) = 1 to s_log
         const float ll = (IRT == 3 ? kLn2 : -kLn2) * wave_total(s_log - (float)unobs);
-        if (lane == 0) wl.red[0] = range_fault ? __builtin_nanf("") : ll;      // (operands beyond the rescaling range: loud)
+        if (lane_e == 0) wl.red[0] = range_fault ? __builtin_nanf("") : ll;      // (operands beyond the rescaling range: loud)
     }
     __syncthreads();
     // scalars: 0 ll | 1 kl | 2 logq0 | 3 logp | 4 ladj | 5 nobs
-    if (tid == 0) {
+    if (tid_e == 0) {
         float t = 0.f;
         for (int w = 0; w < nw; ++w) t += wls[w].red[0];
         out[0] = t;
@@ -1131,13 +1177,13 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
         for (int par2 = 0; par2 < 2; ++par2)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v += cl.tacc[par2][k][lane + 64 * j];
+            for (int j = 0; j < 4; ++j) v += cl.tacc[par2][k][lane_e + 64 * j];
         const float t = wave_total(v);
-        if (lane == 0) out[k == 8 ? 1 : k == 9 ? 2 : k == 10 ? 3 : 5] = t;
+        if (lane_e == 0) out[k == 8 ? 1 : k == 9 ? 2 : k == 10 ? 3 : 5] = t;
     }
     if constexpr (GRAD) {
-        if (tid < 8 * A) {
-            const int a = tid >> 3, k = tid & 7;
+        if (tid_e < 8 * A) {
+            const int a = tid_e >> 3, k = tid_e & 7;
             float t = 0.f;
             for (int par2 = 0; par2 < 2; ++par2)
                 for (int e = a; e < 256; e += 8) t += cl.tacc[par2][k][e];
@@ -1146,7 +1192,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         if constexpr (FLOWS) {
             const int per = 2 * A + 1;
-            for (int idx = tid; idx < 2 * p.n_flows * per; idx += (int)blockDim.x) {
+            for (int idx = tid_e; idx < 2 * p.n_flows * per; idx += (int)blockDim.x) {
                 const int st = idx / (p.n_flows * per), f = (idx / per) % p.n_flows, j = idx % per;
                 const int kind = j < A ? 0 : j < 2 * A ? 1 : 2;
                 const int a = kind == 0 ? j : kind == 1 ? j - A : 0;
@@ -1171,19 +1217,19 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = (acc_ga[u][t][j] + dpp_f<0x128>(acc_ga[u][t][j])) * sc_a;       // sum g theta' = 2^-jsh sum g theta
-                        if (i16 < A) stage[i16 * kStage + 64 * u + 4 * (4 * g + j) + t] = -v;
+                        if (i16_e < A) stage[i16_e * kStage + 64 * u + 4 * (4 * g_e + j) + t] = -v;
                     }
                 }
                 // d LL/d b (and d/d guess-logit): the lane's 8 persons per batch -> sum over the 4 lane groups
                 float b = acc_b[u][t];
                 b += __shfl_xor(b, 16);
                 b += __shfl_xor(b, 32);
-                if (g == 0) stage[brow * kStage + 64 * u + 4 * i16 + t] = b;
+                if (g_e == 0) stage[brow * kStage + 64 * u + 4 * i16_e + t] = b;
                 if constexpr (IRT == 3) {
                     float gg = acc_g[u][t];
                     gg += __shfl_xor(gg, 16);
                     gg += __shfl_xor(gg, 32);
-                    if (g == 0) stage[(A + 1) * kStage + 64 * u + 4 * i16 + t] = gg;
+                    if (g_e == 0) stage[(A + 1) * kStage + 64 * u + 4 * i16_e + t] = gg;
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS writes, in order: visible to its reads)
@@ -1191,8 +1237,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         for (int row = 0; row < n_rows; ++row) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int il = kMsSpan * q + 64 * h + lane;
-                if (il < I) out[p.lay.off_item + (size_t)row * p.lay.i_pad + il] = stage[row * kStage + 64 * h + lane];
+                const int il = kMsSpan * q + 64 * h + lane_e;
+                if (il < I) out[p.lay.off_item + (size_t)row * p.lay.i_pad + il] = stage[row * kStage + 64 * h + lane_e];
             }
         }
     }
@@ -1209,27 +1255,32 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #endif
 }
 
-template <int IRT, bool GRAD, int RM, bool FLOWS, bool NW8, bool EXTRA>
+template <int IRT, bool GRAD, int RM, bool FLOWS, bool NW8, int XM>
 static hipError_t launch_msplit_inst(const ElboParams& p, int nw, int grid, hipStream_t s) {
     // more than 64 KB of dynamic LDS has to be opted into (once per kernel; gfx950 has 160 KB per CU)
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msplit_kernel<IRT, GRAD, RM, FLOWS, NW8, EXTRA>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)msplit_lds_bytes(8, FLOWS));
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msplit_kernel<IRT, GRAD, RM, FLOWS, NW8, XM>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)msplit_lds_bytes(8, FLOWS, IRT == 3));
         if (e != hipSuccess) return e;
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM, FLOWS, NW8, EXTRA>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw, FLOWS), s, p);
+    hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM, FLOWS, NW8, XM>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw, FLOWS, IRT == 3), s, p);
     return hipGetLastError();
 }
 template <int IRT, bool GRAD, int RM, bool FLOWS>
 static hipError_t launch_msplit_one(const ElboParams& p, int nw, int grid, hipStream_t s) {
-    // EXTRA: the panel / conditional / given hooks (see the kernel); NW8: exactly 8 waves per workgroup
-    const bool extra = p.row_cnt || p.pre_stats || p.post_coef || p.given_post || p.given_grad || !p.primary;
-    if (nw == 8) return extra ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, true>(p, nw, grid, s)
-                              : launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, false>(p, nw, grid, s);
-    return extra ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, true>(p, nw, grid, s)
-                 : launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, false>(p, nw, grid, s);
+    // XM: the hook mode (see the kernel): 2 = the slot lanes read / write a caller-supplied posterior, 1 = panel / conditional hooks;
+    // NW8: exactly 8 waves per workgroup
+    const int xm = (p.given_post || p.given_grad) ? 2
+                   : (p.row_cnt || p.pre_stats || p.post_coef || !p.primary || p.panel_count > 1) ? 1 : 0;
+    if (xm == 2 && (!p.given_post || p.row_cnt || p.pre_stats || p.post_coef || !p.primary || p.panel_count > 1)) return hipErrorInvalidValue;
+    if (nw == 8) return xm == 2 ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, 2>(p, nw, grid, s)
+                      : xm == 1 ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, 1>(p, nw, grid, s)
+                                : launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, 0>(p, nw, grid, s);
+    return xm == 2 ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, 2>(p, nw, grid, s)
+         : xm == 1 ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, 1>(p, nw, grid, s)
+                   : launch_msplit_inst<IRT, GRAD, RM, FLOWS, false, 0>(p, nw, grid, s);
 }
 template <int RM, bool FLOWS>
 static hipError_t launch_msplit_rm(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s) {

@@ -64,6 +64,8 @@ struct ElboParams {
     int item0;                // first item of this panel
     int I_total;              // items of the whole row (PoE prior experts, nmiss)
     int primary;              // 1: this launch writes the per-person outputs and owns the KL / REG terms
+    int panel_count;          // matrix row-split kernel: > 1 = ALL panels in this launch (grid = panel_count x workgroups per panel;
+                              // item0 / I / primary / post_coef / the record slot follow from blockIdx.x, see the kernel)
     // conditional posterior (vibo_cond.hip): product-of-experts sums come from cond_pre_kernel, the backward
     // hands per-person coefficients to cond_post_kernel instead of accumulating the 2-row table gradient
     const float* pre_stats;   // [pre_panels][B][2A+1] = lam[A] | s[A] | nobs, or null

@@ -577,8 +577,13 @@ def _hip_cond_mean_sum(feature, response, mask, row_index):
         if row_index is not None:
             r, m = r[row_index], (None if m is None else m[row_index])
         cc = pack_cell_codes(r, m)
-    counts = _BACKEND['counts'](cc.codes, cc.codes, _lib.MASK_CODES, None)
-    nobs = (counts & 0xffff).to(feature.dtype)
+    if cc.codes.shape[1] > 32767:
+        # (vibo_row_counts packs n_correct << 16 | n_observed into an int32: wider rows are counted by torch -- one more pass over
+        #  the codes, on a width the reference itself never trains at)
+        nobs = (cc.codes != 2).sum(dim=1).to(feature.dtype)
+    else:
+        counts = _BACKEND['counts'](cc.codes, cc.codes, _lib.MASK_CODES, None)
+        nobs = (counts & 0xffff).to(feature.dtype)
     return CodeTableSumFn.apply(feature, cc), nobs
 
 

@@ -201,6 +201,7 @@ class GraphedTrainStep:
         self.trainer, self.data, self.batch_size = trainer, data, batch_size
         self.rows = torch.zeros(batch_size, dtype=torch.int64, device=data.device)
         self.graph, self.loss, self.seen = None, None, 0
+        self.generation = getattr(trainer, 'generation', 0)
 
     def __call__(self, rows, beta):
         tr = self.trainer
@@ -211,6 +212,9 @@ class GraphedTrainStep:
             return tr.step(self.data.response, self.data.mask, beta=beta, row_index=rows)
         tr.set_beta(beta)
         self.rows.copy_(rows)
+        if self.graph is not None and getattr(tr, 'generation', 0) != self.generation:
+            self.graph = None                 # a buffer the capture points at was replaced (trainer.generation): capture again
+        self.generation = getattr(tr, 'generation', 0)
         if self.graph is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -475,17 +479,15 @@ def main(argv=None):
     if world > 1:
         model.enable_person_sharding(lambda flat: dist.all_reduce(flat), seed=args.seed, rank=rank)
     trainer = None
-    plain = not args.conditional_posterior and args.n_norm_flows == 0
-    mean_native = (args.ability_merge == 'mean' and not args.conditional_posterior and args.n_norm_flows == 0
-                   and args.hidden_dim <= 128 and args.ability_dim <= 8 and world == 1)
-    if (args.cuda and args.generative_model == 'irt' and not args.torch_optimizer and
-            (mean_native if args.ability_merge == 'mean' else
-             (args.hidden_dim <= 256 if plain else (args.hidden_dim in (32, 64) and args.ability_dim <= 8)))):      # (else: module + torch.optim.Adam)
+    plain = args.ability_merge == 'product' and not args.conditional_posterior and args.n_norm_flows == 0
+    from ..trainer import fused_trainer_covers
+    if (args.cuda and not args.torch_optimizer and fused_trainer_covers(model, args.hidden_dim)
+            and (args.hidden_dim <= 256 or not plain)):      # (else: module + torch.optim.Adam)
         # the whole step natively: FusedTrainer's kernels, (conditional posterior / planar flows) FusedCondFlowTrainer's, or
         # (--ability-merge mean, unconditional posterior, one GPU) FusedMeanTrainer's -- same Adam arithmetic, 2-12 launches
         # per step, no PyTorch autograd inside the replayed graph
         from ..trainer import FusedTrainer
-        trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)
+        trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed, max_batch=local_bs)
     graphed = None
     # The captured module step is opt-in (--graph-module-step): it is 3-4 x faster at small minibatches and follows the eager
     # step exactly in every configuration tests/test_gpu_trainer.py replays 60-150 times, but on this PyTorch / ROCm stack a

@@ -11,8 +11,14 @@ What runs (the folded step, `fold=True` with rng='native', the default of the CL
                                noise, item sample, item KL, the 2-row encoder table from the parameters just updated
 The step is software-pipelined across its own iterations: when the ELBO kernel starts, everything it reads is in memory.  The
 first step's head comes from vibo_fill_normal x 2 + vibo_train_prime ("priming"), repeated whenever the parameters were
-changed from outside between two steps (load_state_dict: detected through the tensors' version counters) or a larger
-minibatch than ever before arrives.
+changed from outside between two steps (load_state_dict, optimizers, `.copy_`: detected through the tensors' version
+counters) or a larger minibatch than ever before arrives.  Writes torch does not count -- through `p.data`, through
+`trainer.mlp_flat`, from another native kernel -- are NOT seen: call `trainer.invalidate()` after them (the next step then
+re-primes), or build the trainer with fold=False, whose four-launch step recomputes its head from the parameters every time.
+A folded forward_backward() has to be followed by update() before the next one (it raises otherwise: the second call would
+tick Adam's counter and flip the double-buffered item-KL half under the pending update).  The ability-noise buffer never
+moves once a hipGraph may have captured it: size it up front with `max_batch`, a larger minibatch arriving later bumps
+`trainer.generation` (GraphedTrainStep re-captures when it changes).
 `fold=False`, rng='torch' (noise from torch's generators: not known a step ahead) and shapes the folded step does not cover
 (more than 1024 items, int64 masks, unaligned rows) take the four-launch form (vibo_train_prologue[_noise] ->
 vibo_elbo_fwd_bwd = kernel + finalize -> vibo_train_epilogue); the two forms agree bit for bit (tests/test_gpu_trainer.py).
@@ -20,7 +26,9 @@ Same arithmetic as the PyTorch path (tests/test_gpu_trainer.py compares paramete
 populated.
 FusedTrainer covers the unconditional posterior without flows; `FusedTrainer(model)` returns its sibling
 FusedCondFlowTrainer (same interface, vibo_ctrain_* kernels) for --conditional-posterior / --n-norm-flows models.
---ability-merge mean and the MLP decoders train through the module + torch.optim path (fused_trainer_covers()).
+FusedMeanTrainer (vibo_mtrain_* kernels) is the same for --ability-merge mean with the unconditional posterior on one GPU.
+The MLP decoders, mean x conditional and person-sharded mean-merge models train through the module + torch.optim path
+(fused_trainer_covers() tells which).
 """
 import ctypes
 
@@ -58,7 +66,7 @@ class FusedTrainer:
             return super().__new__(FusedCondFlowTrainer)
         return super().__new__(cls)
 
-    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True):
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True, max_batch=None):
         if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
             raise NotImplementedError('the fused trainers cover the product-of-experts encoder with the IRT decoder; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
@@ -67,6 +75,9 @@ class FusedTrainer:
         self._primed_for = None               # folded step: (noise capacity, parameter versions) the next step's head was prepared for
         self._eps_cap = None                  # ... the ability-noise buffer [capacity] every step's epilogue refills
         self._eps_keep = []                   # (outgrown buffers stay alive: a captured graph may still write to them)
+        self._max_batch = int(max_batch) if max_batch else 0      # persons of the largest minibatch to expect (sizes _eps_cap once)
+        self.generation = 0                   # bumped when a buffer a captured hipGraph points at was replaced (re-capture then)
+        self._folded_open = False             # a folded forward_backward() whose update() has not run yet
         mlp = model.ability_encoder.mlp
         self.hidden = mlp[0].weight.shape[0]
         if self.hidden > 256:
@@ -116,6 +127,15 @@ class FusedTrainer:
         if float(beta) != self._beta_host:
             self.beta.fill_(float(beta))
             self._beta_host = float(beta)
+
+    def invalidate(self):
+        """Tell the folded step that the parameters were written behind torch's back (`p.data` edits, `trainer.mlp_flat`,
+        another kernel): the head the previous epilogue left behind -- item sample, item KL, expert table, saved activations --
+        is stale, the next step rebuilds it from the parameters as they are then (vibo_train_prime).  load_state_dict and other
+        writes torch counts are detected without this call.  The pending noise draws are repeated for the same step counter."""
+        self._primed_for = None
+
+    reprime = invalidate
 
     @torch.no_grad()
     def step(self, response, mask, beta=None, row_index=None, eps_item=None, eps_ability=None):
@@ -210,11 +230,18 @@ class FusedTrainer:
         # capacity -- the streams are indexed by element, so a step of fewer persons reads a prefix of the same values a fresh
         # draw would give (the epoch's last, shorter minibatch between two replays).  Before the first step, when a larger
         # batch than ever before arrives, or when somebody else wrote the parameters, the head is (re)built here.
+        if self._folded_open:
+            raise RuntimeError('FusedTrainer: forward_backward() was called twice without update() in between (the folded step '
+                               'ticks Adam\'s counter in its first launch; use fold=False to evaluate gradients without updating)')
         need = B * A
         if self._eps_cap is None or self._eps_cap.numel() < need:
             if self._eps_cap is not None:
+                # a hipGraph captured before this moment keeps reading -- and its epilogue refilling -- the old buffer, while
+                # eager steps move on with the new one: captured steps have to be re-captured (GraphedTrainStep does, on
+                # `generation`); pass max_batch to the constructor to never get here
                 self._eps_keep.append(self._eps_cap)
-            self._eps_cap = torch.empty(need, device=dev)
+                self.generation += 1
+            self._eps_cap = torch.empty(max(need, self._max_batch * A), device=dev)
             self._primed_for = None
         state = (self._eps_cap.numel(),) + self._param_versions()
         if self._primed_for != state:
@@ -230,6 +257,7 @@ class FusedTrainer:
         raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None, _lib.REG_KL, True, B,
                                    train_step=(self._steps, fused_finalize))
         self._pending = (d, eps_item, raw, ab_stream)
+        self._folded_open = True
         self.last = raw
         return raw
 
@@ -245,6 +273,7 @@ class FusedTrainer:
         lib, p = _lib.load(), ops._ptr
         stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
         if folded_stream is not None:
+            self._folded_open = False
             rc = lib.vibo_train_epilogue_fused(ctypes.byref(d), self.hidden, p(raw.workspace), p(raw.flat), p(self.saved_h),
                                                p(self.kl_parts), p(eps_item), p(self.beta), p(self.lr), p(self._steps),
                                                p(self.mlp_flat), p(self.mlp_m), p(self.mlp_v), p(self.item_mu), p(self.item_lv),
@@ -268,12 +297,13 @@ class FusedCondFlowTrainer(FusedTrainer):
     everything).  No PyTorch autograd node: the step replays from a hipGraph like FusedTrainer's.  Same interface
     (`FusedTrainer(model, ...)` returns this class for such models).  Hidden width <= 64."""
 
-    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True):
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True, max_batch=None):
         # (fold: FusedTrainer's two-launch form; this class's step is prologue / ELBO call / epilogue either way)
         if model.ability_merge != 'product' or getattr(model, 'generative_model', 'irt') != 'irt':
             raise NotImplementedError('the fused trainers cover the product-of-experts encoder with the IRT decoder; '
                                       'use model.elbo_step + torch.optim.Adam otherwise')
         self.model = model
+        self.generation = 0                   # (no buffer of this step ever moves: see FusedTrainer.generation)
         mlp = model.ability_encoder.mlp
         self.hidden = mlp[0].weight.shape[0]
         if self.hidden > 64:
@@ -397,11 +427,12 @@ class FusedMeanTrainer(FusedTrainer):
     The packed row counts of the resident matrix are computed once (ops.row_counts keeps them while the same tensors come back).
     One GPU: person-sharded mean-merge models keep the module path."""
 
-    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True):
+    def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True, max_batch=None):
         if not fused_trainer_covers(model):
             raise NotImplementedError('FusedMeanTrainer: --ability-merge mean with the unconditional posterior, the IRT decoder, no '
                                       'flows, hidden_dim <= 128, ability_dim <= 8, one GPU; use model.elbo_step + torch.optim.Adam otherwise')
         self.model = model
+        self.generation = 0
         enc = model.ability_encoder
         self.hidden = enc.mlp1[0].weight.shape[0]
         plist = [enc.mlp1[0].weight, enc.mlp1[0].bias, enc.mlp1[2].weight, enc.mlp1[2].bias,
