@@ -105,7 +105,8 @@ enum { VIBO_KERNEL_MATRIX = 1,        /* msplit_kernel: contractions as f16 hi/l
        VIBO_KERNEL_VALU = 2,          /* split_kernel: VALU row-split kernel                                          */
        VIBO_KERNEL_ROW = 3,           /* wave-per-row kernel (int64 masks)                                            */
        VIBO_KERNEL_TILED = 4,         /* tiled fp32-MFMA fallback (ragged rows)                                       */
-       VIBO_KERNEL_GENERAL = 5 };     /* wave-per-person fallback                                                     */
+       VIBO_KERNEL_GENERAL = 5,       /* wave-per-person fallback                                                     */
+       VIBO_KERNEL_NARROW = 6 };      /* narrow_kernel: 4..128 items, ability_dim <= 4, plain model: a row per 16 lanes */
 int vibo_plan_kernel(const vibo_desc* d);
 /* Conditional posterior: which of its two extra passes would run on the matrix pipe (csrc/vibo_cmean.hip) for `d` -- bit 0 the
  * experts' per-person sums, bit 1 the scatter of the table gradient; 0 = both on the VALU kernels (csrc/vibo_cond.hip, or not a

@@ -60,7 +60,12 @@ def test_planner_reports_its_kernel_and_honours_the_flags():
 
     assert plan(1_000_000, 1000, 8) == 1 and plan(1_000_000, 1000, 1) == 1          # bench.py's two shapes
     assert plan(4096, 1000, 8) == 1                                                  # ... and its elbo_rel_err sample
-    assert plan(16, 1000, 8) == 2 and plan(535_598, 96, 1) == 2
+    assert plan(16, 1000, 8) == 2
+    # narrow rows of the plain model (BASELINE configs[0] / [3]: 100 / 95 items) go to the narrow-row kernel at any minibatch size,
+    # unless a flag pins a row-split kernel or the posterior is wider than 4 dims
+    assert plan(535_598, 96, 1) == 6 and plan(16, 100, 1) == 6 and plan(8000, 95, 4) == 6 and plan(1000, 128, 2) == 6
+    assert plan(535_598, 96, 1, _lib.FLAG_KERNEL_VALU) == 2 and plan(535_598, 96, 1, _lib.FLAG_KERNEL_MATRIX) == 1
+    assert plan(535_598, 96, 8) == 2 and plan(535_598, 132, 1) == 2
     assert plan(16, 1000, 8, _lib.FLAG_KERNEL_MATRIX) == 1 and plan(1_000_000, 1000, 8, _lib.FLAG_KERNEL_VALU) == 2
     assert plan(1000, 1000, 2, 0, _lib.MASK_I64) == 3
     assert plan(16, 1000, 8, 3) < 0 and plan(16, 1000, 8, 64) < 0                    # contradictory / unknown flags

@@ -589,6 +589,142 @@ def test_full_size_shard_additivity_permutation_determinism(A, P):
     compare_raw(run(sl), ref, (I, A + 1))
 
 
+def _device_problem(irt, A, P, I, missing, seed, cond):
+    """A simulated response matrix built on the GPU in person slices (the full-size cases do not fit the host-side helper's
+    temporaries): responses from the model's own link (models.py:729-766), `missing` of the cells unobserved."""
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(seed)
+    D = O.item_feat_dim(irt, A)
+    theta = torch.randn(P, A, device=d, generator=g)
+    item_true = torch.randn(I, D, device=d, generator=g)
+    resp = torch.empty(P, I, device=d)
+    mask = torch.empty(P, I, dtype=torch.bool, device=d)
+    step = max(1, 100_000_000 // I)
+    for s0 in range(0, P, step):
+        sl = slice(s0, min(P, s0 + step))
+        if irt == 1:
+            logit = theta[sl].sum(1, keepdim=True) + item_true[:, 0]
+        else:
+            logit = -(theta[sl] @ item_true[:, :A].t()) + item_true[:, A]
+        probs = torch.sigmoid(logit)
+        if irt == 3:
+            gs = torch.sigmoid(item_true[:, A + 1])
+            probs = gs + (1 - gs) * probs
+        resp[sl] = torch.bernoulli(probs, generator=g)
+        mask[sl] = torch.rand(probs.shape, device=d, generator=g) >= missing
+        del logit, probs
+    table = (torch.randn((2, I, 2 * A) if cond else (2, 2 * A), device=d, generator=g) * 0.5).contiguous()
+    item = torch.randn(I, D, device=d, generator=g)
+    eps = torch.randn(P, A, device=d, generator=g)
+    return resp, mask, table, item, eps
+
+
+@pytest.mark.parametrize('codes', [False, True], ids=['fp32-rows', 'cell-codes'])
+def test_config5_pipeline_at_the_planner_large_call_size(codes):
+    """BASELINE configs[4]'s row shape at a size the planner's large-call paths see (100 000 persons x 10 000 items, 3PL,
+    ability_dim 1, --conditional-posterior, 4 planar flows, 20 % missing; models.py:695-710,758-765, flows.py:21-66): the
+    count-and-emit pass over all ten 1024-item panels, the panel sums, the matrix kernel's one-launch panel mode with the flow and
+    conditional hooks, and the table-gradient pass -- bitwise reproducible, additive over two person shards (what the 8-GPU
+    sharding relies on), the same through an in-kernel row gather, and equal to the CPU oracle on a 48-person slice.
+    (The 9-person GENERAL_SHAPES case of this configuration never leaves the small-call kernels.)"""
+    irt, A, P, I, n_flows = 3, 1, 100_000, 10_000, 4
+    d = dev()
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=True, n_flows=n_flows)
+    resp, mask, table, item, eps = _device_problem(irt, A, P, I, 0.2, seed=55, cond=True)
+    g = torch.Generator().manual_seed(5)
+    flow = (torch.randn(n_flows, 2 * A + 1, generator=g) * 0.5).to(d).contiguous()
+    if codes:
+        cells = ops.pack_cell_codes(resp, mask).codes
+
+    def run(rows=None, row_index=None):
+        e = eps if rows is None else eps[rows].contiguous()
+        if row_index is not None:
+            e = eps[row_index].contiguous()
+        B = P if rows is None and row_index is None else int((rows if rows is not None else row_index).numel())
+        if codes:
+            c = cells if rows is None else cells[rows].contiguous()
+            out = ops._hip_launch_elbo(spec, c, c, _lib.MASK_CODES, row_index, table, item, e, flow, _lib.REG_SAMPLED, True, B)
+        else:
+            r = resp if rows is None else resp[rows].contiguous()
+            m = mask if rows is None else mask[rows].contiguous()
+            mm, code = ops.prepare_mask(m)
+            out = ops._hip_launch_elbo(spec, r, mm, code, row_index, table, item, e, flow, _lib.REG_SAMPLED, True, B)
+        torch.cuda.synchronize()
+        return out
+
+    full, again = run(), run()
+    assert torch.equal(full.flat, again.flat) and torch.equal(full.grad_table(0), again.grad_table(0)), 'must be bitwise deterministic'
+    assert torch.equal(full.ability_mu, again.ability_mu) and torch.equal(full.ability_k, again.ability_k)
+    allrows = torch.arange(P, device=d)
+    h = P // 2 + 37
+    a, b = run(allrows[:h]), run(allrows[h:])
+    summed = a.flat + b.flat
+    assert rel_err(summed[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(summed[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    for s_ in range(2):
+        assert rel_err((a.grad_table(s_) + b.grad_table(s_)).cpu(), full.grad_table(s_).cpu()) < 1e-4
+    assert (torch.cat([a.ability_mu, b.ability_mu]) - full.ability_mu).abs().max() < 1e-6
+    # a person permutation through the in-kernel gather: the same sums, the persons' posteriors permuted
+    perm = torch.randperm(P, device=d, generator=torch.Generator(device=d).manual_seed(9))
+    pg = run(row_index=perm)
+    assert rel_err(pg.flat[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(pg.flat[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    assert (pg.ability_mu - full.ability_mu[perm]).abs().max() < 1e-6
+    # the CPU oracle on a slice (its own small-call kernels) and the same persons inside the large call
+    n = 48
+    flows = [(f[:A].double().cpu(), f[A:2 * A].double().cpu(), f[2 * A:].double().cpu()) for f in flow]
+    ref = T.fused_elbo_ref(table.cpu().double(), item.cpu().double(), resp[:n].cpu().double(), mask[:n].cpu(),
+                           eps[:n].cpu().double(), irt_model=irt, ability_dim=A, conditional_posterior=True, mode='sampled',
+                           flow_uhat_w_b=flows)
+    compare_raw(run(allrows[:n]), ref, (I, spec.item_dim), tol=5e-4)
+    for k, t in (('ability_mu', full.ability_mu), ('ability_logvar', full.ability_logvar), ('ability', full.ability),
+                 ('ability_k', full.ability_k)):
+        assert (t[:n].cpu() - ref[k].float()).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
+    assert (full.ability_ladj[:n].cpu() - ref['ladj'].float()).abs().max() < 5e-5
+
+
+def test_config4_shape_at_full_size():
+    """BASELINE configs[3]'s matrix shape at its full size (CritLangAcq: 535 598 persons x 95 items, 2PL, ability_dim 1,
+    --artificial-missing-perc 0.2; datasets.py:283-440, masked log-likelihood models.py:596-629): narrow rows with padded
+    16-byte strides -- bitwise reproducible, additive over two person shards, invariant under a person permutation (in-kernel
+    gather), equal to the CPU oracle on a slice."""
+    irt, A, P, I = 2, 1, 535_598, 95
+    d = dev()
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = _device_problem(irt, A, P, I, 0.2, seed=44, cond=False)
+    rp, mp = ops.pad_rows(resp, mask)
+
+    def run(rows=None, row_index=None):
+        r = rp if rows is None else rp[rows]
+        m = mp if rows is None else mp[rows]
+        e = eps if rows is None else eps[rows].contiguous()
+        if row_index is not None:
+            e = eps[row_index].contiguous()
+        r2, m2, code = ops.prepare_rows(r, m)
+        B = int(row_index.numel()) if row_index is not None else r.shape[0]
+        out = ops._hip_launch_elbo(spec, r2, m2, code, row_index, table, item, e, None, _lib.REG_KL, True, B)
+        torch.cuda.synchronize()
+        return out
+
+    full, again = run(), run()
+    assert torch.equal(full.flat, again.flat) and torch.equal(full.ability_mu, again.ability_mu)
+    h = P // 2 + 37
+    a, b = run(slice(0, h)), run(slice(h, P))
+    summed = a.flat + b.flat
+    assert rel_err(summed[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(summed[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    perm = torch.randperm(P, device=d, generator=torch.Generator(device=d).manual_seed(9))
+    pg = run(row_index=perm)
+    assert rel_err(pg.flat[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(pg.flat[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    assert (pg.ability_mu - full.ability_mu[perm]).abs().max() < 1e-6
+    n = 512
+    ref = T.fused_elbo_ref(table.cpu().double(), item.cpu().double(), resp[:n].cpu().double(), mask[:n].cpu(),
+                           eps[:n].cpu().double(), irt_model=irt, ability_dim=A, mode='kl')
+    compare_raw(run(slice(0, n)), ref, (I, A + 1))
+    assert (full.ability_mu[:n].cpu() - ref['ability_mu'].float()).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize('A,I,codes', [(8, 1000, False), (6, 1100, False), (8, 420, True), (5, 2100, True)])
 def test_wide_conditional_posterior_is_deterministic(A, I, codes):
     """conditional_posterior with ability_dim 5..8 (utils.py:85-113 product of per-cell experts, models.py:607-640):

@@ -8,8 +8,9 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 W=/tmp/vibo_prof; rm -rf $W; mkdir -p $W
 cd /tmp && export TMPDIR=/tmp
-# (--also-ability-dim 0: ability_dim 1 runs the same kernel instantiation and would blur the per-kernel averages)
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --also-ability-dim 0 $BENCH_ARGS"
+# (--also-ability-dim 0 --no-also-config2: those legs run the same kernel instantiation and would blur the per-kernel averages;
+#  config 2 -- 100k x 1k, ability_dim 1 -- gets its own kernel trace at the end)
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --also-ability-dim 0 --no-also-config2 $BENCH_ARGS"
 S=$OUT/profile_summary.txt
 {
 echo "# command: rocprofv3 --kernel-trace --stats -- $B"
@@ -26,6 +27,13 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_
   rocprofv3 --pmc $pass -d $W/$n -o p -- $B > /dev/null 2>&1
   python $R/tools/rocpd_summary.py $W/$n/p_results.db vibo | grep -E "ElboParams|msplit_kernel|split_kernel|finalize|epilogue|prologue"
 done
+echo; echo "# BASELINE configs[1] (100k x 1k, ability_dim 1) as the main workload of the same command:"
+C2="python $R/bench.py --steps 20 --warmup 3 --persons 100000 --ability-dim 1 --no-cpu-baseline --no-extra --also-ability-dim 0 --no-also-config2 --no-format-p"
+echo "# command: rocprofv3 --kernel-trace --stats -- $C2"
+rocprofv3 --kernel-trace --stats -d $W/k2 -o kt -- $C2 > $W/k2.log 2>&1
+grep "^{" $W/k2.log | cut -c1-400
+python $R/tools/rocpd_summary.py $W/k2/kt_results.db vibo
+python $R/tools/rocpd_sequence.py $W/k2/kt_results.db ELi0ELb0E
 } > $S 2>&1
 rm -rf $W
 echo "wrote $S"

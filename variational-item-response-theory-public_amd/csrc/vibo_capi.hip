@@ -74,6 +74,7 @@ struct Plan {
     int cond_post_nblk;       // ... of cond_post: 3 per CU when it reads cell codes at template width <= 2 (its launch bound there)
     bool msplit;              // the row-split launches go to the matrix-pipe kernel (vibo_msplit_kernel.hpp): split_nq = waves of
                               // 128 items per workgroup, batches of 32 rows
+    bool narrow;              // ... to the narrow-row kernel (vibo_narrow.hip: <= 128 items, a row per 16 lanes); split_nblk = its grid
     int panels;               // > 0: more than 1024 items, one row-split launch per panel of 1024 items
     size_t off_cnt;           // panel mode: per-person packed counts of the whole row
     bool cond;                // panel mode with the conditional posterior: cond_pre / split / cond_post per panel
@@ -178,6 +179,23 @@ static bool want_msplit(const vibo_desc* d) {
     if (width > 384 && width <= 512 && !many) return false;
     return true;
 }
+// Narrow rows (4..128 items: BASELINE configs[0] and [3]) of the plain model: the kernel that gives a row to 16 lanes instead of a
+// whole wave (vibo_narrow.hip).  Either pinning flag keeps the row-split kernels (tests and A/B runs of those paths).
+static bool want_narrow(const vibo_desc* d) {
+    if (d->flags & (VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX)) return false;
+    return d->num_item >= 4 && d->num_item <= 128 && d->ability_dim <= 4 && d->n_flows == 0 &&
+           d->posterior == VIBO_POSTERIOR_UNCONDITIONAL && d->mask_dtype != VIBO_MASK_I64;
+}
+static int narrow_blocks(int num_cu, const vibo_desc* d) {
+    // a workgroup = 4 waves = one per SIMD; workgroups per CU = the waves per SIMD the instantiation is compiled for
+    // (narrow_waves_per_simd in vibo_narrow.hip); under 1024 records so that the fused train epilogue can finalize them
+    const int il = d->num_item <= 64 ? 4 : 8, at = d->ability_dim <= 1 ? 1 : d->ability_dim <= 2 ? 2 : 4;
+    const int wps = at == 1 ? (il == 4 ? 4 : 3) : at == 2 ? (il == 4 ? 3 : 2) : 2;
+    long long nblk = (long long)num_cu * wps;
+    if (nblk > 768) nblk = 768;
+    const long long need = (d->num_person + 31) / 32;          // 8 rows per wave and round
+    return (int)(nblk < need ? nblk : (need > 0 ? need : 1));
+}
 static int msplit_blocks(int num_cu, int items, long long persons) {
     const int nw = (items + 127) / 128;
     // workgroups per CU = what is resident at once: 2 waves per SIMD (the kernel's register budget) = 8 waves per CU, and the
@@ -193,6 +211,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
     const int num_cu = device_cus();
     const int I = d->num_item, A = d->ability_dim;
     pl->msplit = false;
+    pl->narrow = false;
     if (A > VIBO_MAX_ABILITY_DIM) {
         // ability_dim 9..16: the wave-per-person kernel's wide instantiation (every row-split / tiled kernel holds 8 dims)
         memset(pl, 0, sizeof(*pl));
@@ -379,6 +398,10 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
         pl->AT = 8;
         pl->DP = prepped_item_width(d->irt_model, 8);
         pl->split_nblk = msplit_blocks(num_cu, I, d->num_person);
+    }
+    if (pl->split_ok && allow_msplit && !pl->msplit && want_narrow(d)) {
+        pl->narrow = true;
+        pl->split_nblk = narrow_blocks(num_cu, d);
     }
     pl->lds_main = (int)main_b;
     pl->geom.waves = waves;
@@ -900,7 +923,7 @@ int vibo_plan_kernel(const vibo_desc* d) {
     rc = make_plan(d, &pl);
     if (rc < 0) return rc;
     if (pl.general) return VIBO_KERNEL_GENERAL;
-    if (pl.panels > 0 || pl.split_ok) return pl.msplit ? VIBO_KERNEL_MATRIX : VIBO_KERNEL_VALU;
+    if (pl.panels > 0 || pl.split_ok) return pl.msplit ? VIBO_KERNEL_MATRIX : pl.narrow ? VIBO_KERNEL_NARROW : VIBO_KERNEL_VALU;
     if (pl.row_ok && d->num_item % 4 == 0 && pl.AT == d->ability_dim) return VIBO_KERNEL_ROW;
     return VIBO_KERNEL_TILED;
 }
@@ -1159,7 +1182,8 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
         bpp = pl.split_nblk;
     } else if (pl.split_ok && vec) {
         nblk_used = pl.split_nblk;
-        e = launch_split(p, pl.AT, codes, d->irt_model, grad, pl.split_nq, pl.split_nblk, s, pl.msplit);
+        if (pl.narrow) e = launch_elbo_narrow(p, codes, d->irt_model, grad, pl.split_nblk, s);
+        else e = launch_split(p, pl.AT, codes, d->irt_model, grad, pl.split_nq, pl.split_nblk, s, pl.msplit);
     } else if (pl.row_ok && vec && I % 4 == 0 && pl.AT == A) {
         nblk_used = pl.row_nblk;
         e = launch_elbo_rows(p, d->irt_model, grad, pl.row_nblk, s);

@@ -45,6 +45,10 @@ hipError_t launch_elbo_msplit_fa(const ElboParams& p, int irt, bool grad, int nw
 hipError_t launch_elbo_msplit_fg(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 hipError_t launch_elbo_msplit_fc(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 
+// narrow-row kernel (vibo_narrow.hip): 4 <= I <= 128, ability_dim <= 4, unconditional posterior, no flows; a row per 16 lanes;
+// fp32 rows in order / through p.row_index / 1-byte cell codes (codes: through p.mask); grid workgroups of 4 independent waves
+hipError_t launch_elbo_narrow(const ElboParams& p, bool codes, int irt, bool grad, int grid, hipStream_t s);
+
 // the folded train step's epilogue (vibo_trainer.hip): finalize + loss + MLP / item backward + Adam + the next step's noise
 hipError_t launch_train_epilogue_fused(const EpiParams& e, hipStream_t s);
 int train_epilogue_item_blocks(int n_item_entries);

@@ -142,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     constexpr int R = kMsRows;
     constexpr float kLoS = kLogitLo * kLog2e, kHiS = kLogitHi * kLog2e;
     // fp8 (e4m3) look-up tables of the pack.  fp32 rows: selector {missing, wrong, -, right}; cell codes: {wrong, right, missing}.
-    // 1PL/2PL carry -w (the exponent is -w x logit: one VOP2 multiply), 3PL +w.
-    constexpr uint32_t kLutFp32 = IRT != 3 ? 0xB8003800u : 0x3800B800u;
-    constexpr uint32_t kLutCode = IRT != 3 ? 0x0000B838u : 0x000038B8u;
+    // Every model carries -w (the exponent is -w x logit: one VOP2 multiply).
+    constexpr uint32_t kLutFp32 = 0xB8003800u;
+    constexpr uint32_t kLutCode = 0x0000B838u;
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_smem[];
     MsCommonLds& cl = *reinterpret_cast<MsCommonLds*>(ms_smem);
     MsWaveLds* wls = reinterpret_cast<MsWaveLds*>(ms_smem + sizeof(MsCommonLds));
@@ -304,6 +304,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     const bool lv = ed < A && row < p.B;
                     const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
                     prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
+                } else if (p.row_cnt) {
+                    // wide rows of the plain model: the whole-row answer counts (row_count_kernel) travel the same way, as bits
+                    // (round 5; the slot lanes used to load them between the two barriers of every batch)
+                    const bool lv = ed < A && row < p.B;
+                    prs0 = __int_as_float(lv ? p.row_cnt[row] : 0);
                 }
             }
         }
@@ -469,6 +474,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
     float s_log = 0.f;
     int unobs = 0;
+    bool sat3 = false;                  // 3PL: this wave met a probability past the clamp (wave-uniform, sticky: see the tile)
     __syncthreads();
 
     // LDS image offsets (halfs): producer row 16 t + i16, piece g; consumer rows 32 kt + 4 g + (i16 >> 2) (+ 16), piece i16 & 3
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             t += dpp_i<0x140>(t);                   // row_mirror
             v[k] = t;
         }
-        if constexpr (IRT != 3) {
+        {
             int obs = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) obs += (pk[k] & 0xff) + ((pk[k] >> 8) & 0xff);
@@ -560,6 +566,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if constexpr (EXT && XCOND) {
             if (p.row_cnt) {
                 cnt = live ? p.row_cnt[row0 + pp] : 0;
+                have_cnt = true;
+            }
+        }
+        if constexpr (XCOND && !EXT && kPrs) {
+            if (p.row_cnt) {
+                cnt = __float_as_int(prs0);
                 have_cnt = true;
             }
         }
@@ -781,7 +793,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         my_slots(par, s0, s1, step);
         if constexpr (EXTRA || !NW8) {
             bool ext = nw < 4;                                   // (wave-uniform)
-            if constexpr (XCOND) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
+            if constexpr (XCOND) ext = ext || (p.row_cnt && !kPrs) || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
             if (ext) {
                 // (without the EXTRA hooks the plain variant serves the narrow workgroups too: eps is loaded here)
 #pragma unroll 1
@@ -930,36 +942,106 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         } else {
+            // 3PL (models.py:758-765):  p = guess + (1 - guess) sigmoid(l).  With E = 2^u, u = -w l (the 2PL exponent):
+            //   answered right:  p     = (1 + guess E) / (1 + E)        answered wrong:  1 - p = (1 - guess) / (1 + E)
+            // i.e. both are v = n / t with t = 1 + E and n = 1 + guess sel, sel = E (right) | -1 (wrong) | 0 (missing: v = 1/2, a
+            // log2 of exactly -1 that the count of unobserved cells takes back, as in 1PL/2PL).  ONE exponential and ONE reciprocal
+            // (of n t: 1/t = n / (n t), 1/n = t / (n t)) per cell instead of an exponential, two reciprocals and the sign selects of
+            // the sigmoid-first form (rounds 2-4: ~20 plain + 3.25 quarter-rate instructions per cell; now ~12 + 2.25):
+            //   d ll/d l      = wc (1/t - [right] 1/n - [wrong or missing] 1)       (log2 units, wc = -w)
+            //   d ll/d guess  = sel / n;  its chain factor guess (1 - guess) is applied once per item in the epilogue.
+            // The reference's probability clamp (p to [eps32, 1 - eps32], gradient zero where it bites) is "v left [eps32, 1 - eps32]"
+            // for right and wrong cells alike: a wave-uniform second path over the tile, as in 2PL.
             // (the address goes through an empty asm so that the loop-invariant read is not hoisted back into registers)
             int go = (u * 4 + t) * 16 + i16;
             asm volatile("" : "+v"(go));
-            const float gs_ut = gsl[go], om_ut = 1.0f - gs_ut;
+            const float gs_ut = gsl[go];
+            // (the four cells of an M-tile at a time, everything consumed on the spot: with all eight in flight the reciprocals,
+            //  selections and ratios of the tile -- 40 registers -- sat on top of the logits and codes the second path needs, and
+            //  the instantiations at the 256-register limit (flows, hooks, gathered rows) spilled 40-430 registers)
+            float dgs = 0.f;                              // the tile's d ll / d guess (added to the accumulator once, below)
+            bool redo = sat3;
+            if (!sat3) {
+                float vhi = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float w = wc[k];
-                float& pr = (k & 1) ? pr1 : pr0;
-                gl[k] = 0.f;
-                // 3PL: p = guess + (1 - guess) sigmoid(l)  (models.py:758-765), probability clamp on p itself
-                const float l = lg[k];
-                const float ee = fast_exp2(-fabsf(l));
-                const float rr_ = fast_rcp(1.0f + ee);
-                const float er_ = ee * rr_;
-                const float sp = (l >= 0.f) ? rr_ : er_;
-                const float sn = (l >= 0.f) ? er_ : rr_;
-                const float prb = fmaf(om_ut, sp, gs_ut);
-                const float qr = om_ut * sn;
-                const float pc = med3(prb, kEps32, 1.0f - kEps32);
-                const float arg = (w > 0.f) ? pc : med3(qr, kEps32, 1.0f - kEps32);
-                pr *= (w != 0.f) ? arg : 1.0f;
-                if constexpr (GRAD) {
-                    const float wlv = (prb == pc) ? w : 0.f;
-                    const float common = wlv * fast_rcp(arg) * om_ut * sn;
-                    gl[k] = common * sp;
-                    acc_g[u][t] = fmaf(common, gs_ut, acc_g[u][t]);
+                for (int h = 0; h < 2; ++h) {
+                    float vq[4];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const int k = 4 * h + k4;
+                        const float ek = fast_exp2(wc[k] * lg[k]);
+                        const float tk = 1.0f + ek;
+                        const bool right = wc[k] < 0.f;
+                        const float sel = right ? ek : -wc[k];
+                        const float nk = fmaf(gs_ut, sel, 1.0f);
+                        const float iq = fast_rcp(nk * tk);
+                        const float rtk = nk * iq, rnk = tk * iq;
+                        vq[k4] = nk * rtk;
+                        if constexpr (GRAD) {
+                            gl[k] = wc[k] * (rtk - (right ? rnk : 1.0f));
+                            dgs = fmaf(sel, rnk, dgs);
+                        }
+                    }
+                    pr0 *= vq[0] * vq[2];
+                    pr1 *= vq[1] * vq[3];
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vhi) : "v"(vhi), "v"(vq[0]), "v"(vq[1]));
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vhi) : "v"(vhi), "v"(vq[2]), "v"(vq[3]));
+                    if constexpr (GRAD) {
+                        asm volatile("" : "+v"(gl[4 * h]), "+v"(gl[4 * h + 1]), "+v"(gl[4 * h + 2]), "+v"(gl[4 * h + 3]), "+v"(dgs), "+v"(pr0), "+v"(pr1));
+                    } else {
+                        asm volatile("" : "+v"(pr0), "+v"(pr1));
+                    }
+                }
+                // Out of [eps32, 1 - eps32] anywhere in the wave's tile?  Below: every v <= 1, so a product of four >= eps32 has no
+                // factor under it (four answers of probability < 2 % each in one lane's quad trip it too: rare, and only slow);
+                // an exponential that overflowed leaves a NaN in a product, which fails the same comparison.
+                if (__any(!(fminf(pr0, pr1) >= kEps32 && vhi <= 1.0f - kEps32))) redo = sat3 = true;      // (wave-uniform)
+            }
+            if (redo) {
+                // The same quantities with the clamp applied cell by cell: v clamped IS the reference's clamp of p (right: v = p;
+                // wrong: v = 1 - p, and 1 - clamp(p) = clamp(1 - p)), gradient zero where it bit; the exponent is held inside
+                // +-60 first (n t <= 2^121; beyond it v is 0, 1, guess or 1 - guess to the last bit anyway).  Unclamped cells
+                // come out bit for bit as above.  Not rare everywhere: ONE cell in the wave's 512 sends a tile here, which with
+                // flows that push theta out, or items past |logit| 16, is most tiles -- so a wave that got here once stays
+                // here (sat3: its items and the model's saturation persist across batches) and never pays both forms again.
+                pr0 = pr1 = 1.0f;
+                dgs = 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float vq[4];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const int k = 4 * h + k4;
+                        const float ek = fast_exp2(med3(wc[k] * lg[k], -60.f, 60.f));
+                        const float tk = 1.0f + ek;
+                        const bool right = wc[k] < 0.f;
+                        const float sel = right ? ek : -wc[k];
+                        const float nk = fmaf(gs_ut, sel, 1.0f);
+                        const float iq = fast_rcp(nk * tk);
+                        const float rtk = nk * iq, rnk = tk * iq;
+                        const float v = nk * rtk;
+                        vq[k4] = med3(v, kEps32, 1.0f - kEps32);
+                        if constexpr (GRAD) {
+                            const bool keep = vq[k4] == v;
+                            gl[k] = keep ? wc[k] * (rtk - (right ? rnk : 1.0f)) : 0.f;
+                            dgs = fmaf(keep ? sel : 0.f, rnk, dgs);
+                        }
+                    }
+                    pr0 *= vq[0] * vq[2];               // (the first form's order of products and sums: same bits)
+                    pr1 *= vq[1] * vq[3];
+                    if constexpr (GRAD) {
+                        asm volatile("" : "+v"(gl[4 * h]), "+v"(gl[4 * h + 1]), "+v"(gl[4 * h + 2]), "+v"(gl[4 * h + 3]), "+v"(dgs), "+v"(pr0), "+v"(pr1));
+                    } else {
+                        asm volatile("" : "+v"(pr0), "+v"(pr1));
+                    }
                 }
             }
+            if constexpr (GRAD) acc_g[u][t] += dgs;
         }
-        s_log += fast_log2(pr0) + fast_log2(pr1);
+        // (1PL/2PL: pr = products of t = 1 + E >= 1; 3PL: of v = n / t <= 1 -- s_log is the negative log-likelihood in log2 units
+        //  plus one per unobserved cell either way)
+        if constexpr (IRT != 3) s_log += fast_log2(pr0) + fast_log2(pr1);
+        else s_log -= fast_log2(pr0) + fast_log2(pr1);
         asm volatile("" : "+v"(s_log));          // (keeps hipcc from sinking the whole batch's products to the loop end)
         if constexpr (GRAD) {
             acc_b[u][t] += ((gl[0] + gl[1]) + (gl[2] + gl[3])) + ((gl[4] + gl[5]) + (gl[6] + gl[7]));
@@ -1152,8 +1234,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int lane_e = tid_e & 63, i16_e = lane_e & 15, g_e = lane_e >> 4;
     float* out = p.partial + (size_t)rec * p.lay.stride;
     {
-        // 1PL/2PL: every cell without an observation contributed exactly log2(1 + 2^0) = 1 to s_log
-        const float ll = (IRT == 3 ? kLn2 : -kLn2) * wave_total(s_log - (float)unobs);
+        // every cell without an observation contributed exactly log2(1 + 2^0) = 1 to s_log
+        const float ll = -kLn2 * wave_total(s_log - (float)unobs);
         if (lane_e == 0) wl.red[0] = range_fault ? __builtin_nanf("") : ll;      // (operands beyond the rescaling range: loud)
     }
     __syncthreads();
@@ -1229,7 +1311,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     float gg = acc_g[u][t];
                     gg += __shfl_xor(gg, 16);
                     gg += __shfl_xor(gg, 32);
-                    if (g_e == 0) stage[(A + 1) * kStage + 64 * u + 4 * i16_e + t] = gg;
+                    // (the tiles summed d ll / d guess; the parameter is the guess logit: x guess (1 - guess), models.py:758)
+                    const float gs_e = gsl[(u * 4 + t) * 16 + i16_e];
+                    if (g_e == 0) stage[(A + 1) * kStage + 64 * u + 4 * i16_e + t] = gg * (gs_e * (1.0f - gs_e));
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS writes, in order: visible to its reads)
