@@ -39,6 +39,7 @@ Adds to the contract line:
                 (a launch of 12.2 batches per workgroup: the kernel's one-shot prologue / end code and the 12-vs-13-round
                 quantisation show), with its own kernel and step fractions of the 8 TB/s roofline (N = 1 only).
   extra         config5_path: BASELINE configs[4]'s path (3PL, 10 000 items, conditional, 4 flows) on 100 000 persons;
+                other_shapes: configs[3]'s and configs[0]'s matrix shapes (narrow-row kernel), a wide plain matrix, the 3PL link;
                 decoder_kernel: the per-term MLP decoder kernel (fwd + bwd, algorithmic TFLOP/s, MFMA issue rate);
                 train-step throughput at minibatches of 16 / 4096 / 65536 persons of the resident matrix (SURVEY.md 8d;
                 rows gathered in the kernel, hipGraph replay); the headline is the full shard.
@@ -193,7 +194,7 @@ def cpu_baseline(args, irt):
     }
 
 
-PROFILE_FILE = 'r04_bench_profile.txt'      # rocprofv3 summary of this command on this round's build (tools/collect_profile.sh)
+PROFILE_FILE = 'r05_bench_profile.txt'      # rocprofv3 summary of this command on this round's build (tools/collect_profile.sh)
 
 
 def parse_traffic(kernel_tag):
@@ -638,6 +639,44 @@ def main():
                 'hbm_bytes_per_term_by_construction': 8.0,
                 'note': 'cond_pre reads 5 B and writes 1 B of cell codes per term, the matrix kernel and the table-gradient pass (matrix pipe, vibo_cmean.hip) read 1 B each'}
 
+    def shapes_probe():
+        """The other BASELINE shapes as one forward + backward call each (kernel path only, HIP events over 5 calls): configs[3]'s
+        CritLangAcq matrix shape (535 598 x 95, 20 % missing, padded 16-byte row strides) and configs[0]'s train split (8 000 x 100)
+        on the narrow-row kernel (csrc/vibo_narrow.hip), a wide plain matrix (100 000 x 10 000: count pass + all panels in one
+        launch) and the 3PL link on the headline shape."""
+        from vibo_amd import _lib
+        from vibo_amd.ops import ElboSpec
+        out = {}
+        for name, irt_, Pc, Ic, Ac, miss in (('config4_shape_535598x95', 2, 535_598, 95, 1, 0.2), ('config1_shape_8000x100', 2, 8_000, 100, 1, 0.0),
+                                             ('plain_2pl_100000x10000', 2, 100_000, 10_000, 1, args.missing),
+                                             ('link_3pl_1Mx1k_ability_dim_8', 3, min(args.persons, 1_000_000), 1000, 8, args.missing)):
+            g = torch.Generator(device=dev).manual_seed(args.seed + 7)
+            r = (torch.rand(Pc, Ic, device=dev, generator=g) < 0.5).float()
+            mk = torch.rand(Pc, Ic, device=dev, generator=g) >= miss
+            r, mk = ops.pad_rows(r, mk)
+            spec = ElboSpec(irt_model=irt_, ability_dim=Ac)
+            table = torch.randn(2, 2 * Ac, device=dev, generator=g) * 0.5
+            item = torch.randn(Ic, spec.item_dim, device=dev, generator=g)
+            eps = torch.randn(Pc, Ac, device=dev, generator=g)
+            r2, m8, code = ops.prepare_rows(r, mk)
+            call = lambda: ops._hip_launch_elbo(spec, r2, m8, code, None, table, item, eps, None, _lib.REG_KL, True, Pc)
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            bpt = 5.0 + 12.0 * Ac / Ic
+            out[name] = {'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3), 'bytes_per_term': bpt,
+                         'roofline_frac': bpt * Pc * Ic / (ms * 1e-3) / 8e12, 'kernel': ops.plan_kernel(spec, Pc, Ic, code, True)}
+            del r, mk, r2, m8
+        out['note'] = ('one fused forward + backward call per shape, inputs resident, HIP events over 5 back-to-back calls (launch gaps '
+                       'included: the 8 000 x 100 call is launch-bound); fractions of the 8 TB/s roofline on 5 + 12 A / I bytes per term')
+        return out
+
     def conditional_probe():
         """--conditional-posterior on the headline shape (2PL, 1M x 1k): one forward + backward call at ability_dim 1 and 8, on
         fp32 rows and on cell codes (the experts' per-person sums and the table-gradient scatter run as one-hot x table
@@ -778,7 +817,7 @@ def main():
             line['elbo_rel_err'] = m['rel']['vs_reference_op_sequence_fp32']
             line['elbo_rel_err_detail'] = m['rel']
         if m.get('sweep'):
-            line['extra'] = {'decoder_kernel': decoder_probe(), 'config5_path': config5_probe(), 'conditional_posterior': conditional_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
+            line['extra'] = {'decoder_kernel': decoder_probe(), 'config5_path': config5_probe(), 'conditional_posterior': conditional_probe(), 'other_shapes': shapes_probe(), 'minibatch_sweep': m['sweep'], 'note': 'train steps on minibatches of the resident matrix, rows gathered in the kernel through row_index, one hipGraph replay per step; the headline is the full shard'}
         if also is not None:
             line['also'] = also
         if also_config2 is not None:

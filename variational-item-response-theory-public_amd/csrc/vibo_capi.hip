@@ -190,10 +190,10 @@ static int narrow_blocks(int num_cu, const vibo_desc* d) {
     // a workgroup = 4 waves = one per SIMD; workgroups per CU = the waves per SIMD the instantiation is compiled for
     // (narrow_waves_per_simd in vibo_narrow.hip); under 1024 records so that the fused train epilogue can finalize them
     const int il = d->num_item <= 64 ? 4 : 8, at = d->ability_dim <= 1 ? 1 : d->ability_dim <= 2 ? 2 : 4;
-    const int wps = at == 1 ? (il == 4 ? 4 : 3) : at == 2 ? (il == 4 ? 3 : 2) : 2;
+    const int wps = at == 1 ? 4 : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2);
     long long nblk = (long long)num_cu * wps;
-    if (nblk > 768) nblk = 768;
-    const long long need = (d->num_person + 31) / 32;          // 8 rows per wave and round
+    if (nblk > 1020) nblk = 1020;
+    const long long need = (d->num_person + 15) / 16;          // 4 rows per wave and round
     return (int)(nblk < need ? nblk : (need > 0 ? need : 1));
 }
 static int msplit_blocks(int num_cu, int items, long long persons) {

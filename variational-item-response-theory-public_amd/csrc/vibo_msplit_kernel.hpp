@@ -304,11 +304,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     const bool lv = ed < A && row < p.B;
                     const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
                     prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
-                } else if (p.row_cnt) {
-                    // wide rows of the plain model: the whole-row answer counts (row_count_kernel) travel the same way, as bits
-                    // (round 5; the slot lanes used to load them between the two barriers of every batch)
-                    const bool lv = ed < A && row < p.B;
-                    prs0 = __int_as_float(lv ? p.row_cnt[row] : 0);
                 }
             }
         }
@@ -474,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     for (int k = tid; k < 2 * 12 * 256; k += (int)blockDim.x) (&cl.tacc[0][0][0])[k] = 0.f;
     float s_log = 0.f;
     int unobs = 0;
-    bool sat3 = false;                  // 3PL: this wave met a probability past the clamp (wave-uniform, sticky: see the tile)
+    bool sat3 = false;                  // 3PL: this wave met a probability past the clamp in this batch (wave-uniform: see the tile)
     __syncthreads();
 
     // LDS image offsets (halfs): producer row 16 t + i16, piece g; consumer rows 32 kt + 4 g + (i16 >> 2) (+ 16), piece i16 & 3
@@ -566,12 +561,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if constexpr (EXT && XCOND) {
             if (p.row_cnt) {
                 cnt = live ? p.row_cnt[row0 + pp] : 0;
-                have_cnt = true;
-            }
-        }
-        if constexpr (XCOND && !EXT && kPrs) {
-            if (p.row_cnt) {
-                cnt = __float_as_int(prs0);
                 have_cnt = true;
             }
         }
@@ -793,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         my_slots(par, s0, s1, step);
         if constexpr (EXTRA || !NW8) {
             bool ext = nw < 4;                                   // (wave-uniform)
-            if constexpr (XCOND) ext = ext || (p.row_cnt && !kPrs) || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
+            if constexpr (XCOND) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
             if (ext) {
                 // (without the EXTRA hooks the plain variant serves the narrow workgroups too: eps is loaded here)
 #pragma unroll 1
@@ -962,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             float dgs = 0.f;                              // the tile's d ll / d guess (added to the accumulator once, below)
             bool redo = sat3;
             if (!sat3) {
-                float vhi = 0.f;
+                float vhi = 0.f, vlo = 1.0f;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     float vq[4];
@@ -986,24 +975,29 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     pr1 *= vq[1] * vq[3];
                     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vhi) : "v"(vhi), "v"(vq[0]), "v"(vq[1]));
                     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vhi) : "v"(vhi), "v"(vq[2]), "v"(vq[3]));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(vlo) : "v"(vlo), "v"(vq[0]), "v"(vq[1]));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(vlo) : "v"(vlo), "v"(vq[2]), "v"(vq[3]));
                     if constexpr (GRAD) {
                         asm volatile("" : "+v"(gl[4 * h]), "+v"(gl[4 * h + 1]), "+v"(gl[4 * h + 2]), "+v"(gl[4 * h + 3]), "+v"(dgs), "+v"(pr0), "+v"(pr1));
                     } else {
                         asm volatile("" : "+v"(pr0), "+v"(pr1));
                     }
                 }
-                // Out of [eps32, 1 - eps32] anywhere in the wave's tile?  Below: every v <= 1, so a product of four >= eps32 has no
-                // factor under it (four answers of probability < 2 % each in one lane's quad trip it too: rare, and only slow);
-                // an exponential that overflowed leaves a NaN in a product, which fails the same comparison.
-                if (__any(!(fminf(pr0, pr1) >= kEps32 && vhi <= 1.0f - kEps32))) redo = sat3 = true;      // (wave-uniform)
+                // Out of [eps32, 1 - eps32] anywhere in the wave's tile?  (The extrema, not the products: a product of four below
+                // eps32 says nothing -- four answers of probability 2 % in one lane's quad get there, which simulated or badly
+                // fitted responses do all the time: config 5's benchmark matrix sent every tile down the second path that way.)
+                // min3 / max3 drop a NaN operand (an exponential that overflowed: inf / inf), the products keep it.
+                if (__any(!(vlo >= kEps32 && vhi <= 1.0f - kEps32 && pr0 * pr1 > 0.f))) redo = sat3 = true;      // (wave-uniform)
             }
             if (redo) {
                 // The same quantities with the clamp applied cell by cell: v clamped IS the reference's clamp of p (right: v = p;
                 // wrong: v = 1 - p, and 1 - clamp(p) = clamp(1 - p)), gradient zero where it bit; the exponent is held inside
                 // +-60 first (n t <= 2^121; beyond it v is 0, 1, guess or 1 - guess to the last bit anyway).  Unclamped cells
                 // come out bit for bit as above.  Not rare everywhere: ONE cell in the wave's 512 sends a tile here, which with
-                // flows that push theta out, or items past |logit| 16, is most tiles -- so a wave that got here once stays
-                // here (sat3: its items and the model's saturation persist across batches) and never pays both forms again.
+                // flows that push theta out, or items past |logit| 16, is most tiles -- so a wave that got here stays here for
+                // the rest of the batch (sat3) and pays both forms once per batch at most.  (Sticky for the whole kernel was
+                // measured too: one early hit in any of its 8 waves then slows a workgroup for good -- they meet at two barriers
+                // per batch -- and the plain 3PL call lost most of what the first form wins: 1.25 -> 1.33 ms per 1M x 1k.)
                 pr0 = pr1 = 1.0f;
                 dgs = 0.f;
 #pragma unroll
@@ -1144,6 +1138,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // the loads behind the pack that frees their registers.
     for (; bt < n_batches; bt += G, par ^= 1) {
         const int nxt = bt + G;
+        sat3 = false;                                 // (3PL: see the tile)
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = 0;
         if constexpr (RM != 0) {

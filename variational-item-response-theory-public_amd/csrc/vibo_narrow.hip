@@ -50,10 +50,13 @@ __device__ __forceinline__ float quad_bcast(float v) {
 }
 
 constexpr int kNwWaves = 4;            // waves per workgroup (they only meet in the epilogue)
-constexpr int kNwPass = 2;             // passes (of 4 rows) per loop iteration = rows in flight per buffer / 4
+#ifndef VIBO_NW_PASS
+#define VIBO_NW_PASS 1
+#endif
+constexpr int kNwPass = VIBO_NW_PASS;  // passes (of 4 rows) per loop iteration = rows in flight per wave / 4
 
 // waves per SIMD each instantiation is compiled for (registers: items x (parameters + gradient accumulators) + one unit of rows)
-constexpr int narrow_waves_per_simd(int at, int il) { return at == 1 ? (il == 4 ? 4 : 3) : at == 2 ? (il == 4 ? 3 : 2) : 2; }
+constexpr int narrow_waves_per_simd(int at, int il) { return at == 1 ? 4 : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2); }
 
 struct alignas(16) NarrowLds {
     float red[kNwWaves][8];
@@ -340,8 +343,9 @@ __global__ __launch_bounds__(64 * kNwWaves, narrow_waves_per_simd(AT, IL)) void 
     };
 
     {
-        // One unit (8 rows) of loads in flight per wave, 12-16 waves per CU: a second buffer of raw rows (22 registers) was what
-        // pushed the widest instantiations over their budget (150-360 spilled registers).
+        // One unit of loads in flight per wave, 8-16 waves per CU.  Measured (same-box A/B, 535 596 x 96): a unit of one pass
+        // (4 rows) runs as fast as one of two at ability_dim 1 (87 us) and 1.6x faster at ability_dim 4 (188 -> 118 us: no
+        // spills, one more wave per SIMD); four passes or a second buffer of raw rows spill 150-360 registers (260 us).
         float4 xa[NX];
         uint32_t ma[NM];
         float ea[kNwPass];
