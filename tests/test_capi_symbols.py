@@ -130,3 +130,17 @@ def test_decoder_desc_struct_matches_header():
     assert lib.vibo_decoder_person_chunks(0, 10) == 0 and lib.vibo_decoder_person_chunks(1000, 100) >= 1
     d = _lib.ViboDecoderDesc(16, 100, 32, 0, 1, 0.0, 100, 100)          # hidden_dim 32: refused before any launch
     assert lib.vibo_decoder_fwd_bwd(ctypes.byref(d), *([None] * 20)) == -6
+
+
+def test_planner_thresholds_agree_with_the_committed_calibration_tables():
+    """want_msplit's thresholds (csrc/vibo_capi.hip) are hand-written from tools/calibrate_planner.py's tables; tools/check_planner_table.py
+    replays the committed tables (two MI355X boxes, profiles/*planner_calibration*.txt) against vibo_plan_kernel: no calibrated
+    shape may go to the kernel that was measured more than 15 % slower on every box (the one island the rules do not follow --
+    16 384 x 256 at ability_dim 8, 11-12 % -- stays under that; the tool's default 8 % lists it)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import check_planner_table
+    bad, n = check_planner_table.check(tol=0.15, verbose=False)
+    assert n >= 70 and not bad, bad

@@ -19,7 +19,12 @@ run --persons 1000000 --items 1000 --ability-dim 1 --flows 4
 run --persons 1000000 --items 1000 --ability-dim 1 --cond
 run --persons 100000 --items 10000 --ability-dim 1
 run --persons 100000 --items 10000 --ability-dim 1 --irt 3 --cond --flows 4
+# narrow rows (BASELINE configs[3] / [0] shapes): the narrow-row kernel (planner's choice), and the VALU row-split kernel it replaced
 run --persons 535596 --items 96 --ability-dim 1 --missing 0.2
+run --persons 535596 --items 96 --ability-dim 1 --missing 0.2 --kernel valu
+run --persons 535596 --items 96 --ability-dim 4 --missing 0.2
+run --persons 535596 --items 96 --ability-dim 1 --missing 0.2 --codes
+run --persons 8000 --items 100 --ability-dim 1 --missing 0
 run --persons 1000000 --items 1000 --ability-dim 8 --no-grad
 # shuffled minibatch (rows through row_index), Format P cell codes, caller-supplied posterior (--ability-merge mean)
 run --persons 1000000 --items 1000 --ability-dim 8 --gather

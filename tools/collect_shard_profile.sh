@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
 W=/tmp/vibo_shard; rm -rf $W; mkdir -p $W
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --persons ${PERSONS:-125000} --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-format-p --also-ability-dim 0 $BENCH_ARGS"
+B="python $R/bench.py --persons ${PERSONS:-125000} --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-format-p --also-ability-dim 0 --no-also-config2 $BENCH_ARGS"
 S=$OUT/shard125k_step_sequence.txt
 {
 echo "# bench line WITHOUT the profiler:  $B"

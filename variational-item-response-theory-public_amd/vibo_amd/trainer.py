@@ -423,7 +423,7 @@ class FusedMeanTrainer(FusedTrainer):
     mlp2[0]; optionally the Philox noise) -> vibo_mean_encoder_forward (per-person posterior from the row counts) ->
     vibo_elbo_fwd_bwd in VIBO_POSTERIOR_GIVEN mode -> vibo_mean_encoder_backward_sets -> vibo_mtrain_epilogue (loss, the
     backward through u, v and mlp1 by hand, Adam on everything).  No PyTorch autograd node: the step replays from a hipGraph
-    like FusedTrainer's (about ten launches).  Same interface (`FusedTrainer(model, ...)` returns this class for such models).
+    like FusedTrainer's (eight launches since the GIVEN call reads / writes the posterior itself: DESIGN 3.6).  Same interface (`FusedTrainer(model, ...)` returns this class for such models).
     The packed row counts of the resident matrix are computed once (ops.row_counts keeps them while the same tensors come back).
     One GPU: person-sharded mean-merge models keep the module path."""
 
