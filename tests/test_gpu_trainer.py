@@ -632,13 +632,15 @@ def test_fused_mean_trainer_replays_bitwise_from_a_hipgraph():
 
 
 @pytest.mark.gpu
-def test_fused_cond_flow_trainer_replays_bitwise_from_a_hipgraph():
+@pytest.mark.parametrize('P,I,A,B,replays', [(512, 1000, 1, 16, 200), (8300, 2500, 1, 4100, 12)],
+                         ids=['16-persons-x-1000', '4100-persons-x-2500-large-call-paths'])
+def test_fused_cond_flow_trainer_replays_bitwise_from_a_hipgraph(P, I, A, B, replays):
     """The conditional + flows step (BASELINE configs[4]'s flag set) captured once and replayed: bitwise the parameters of the
     same steps launched eagerly (native noise: the counters live on the device), 200 replays -- the captured autograd step
-    this replaces went wrong after a dozen replays on the same stack."""
+    this replaces went wrong after a dozen replays on the same stack.  Second case: a minibatch the
+    planner's large-call paths see -- three 1024-item panels in one launch per pass, the matrix-pipe table-gradient pass."""
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(5)
-    P, I, A, B = 512, 1000, 1, 16
     resp, mask = O.simulate_responses(3, P, I, A, generator=g, missing_frac=0.1)
     resp, mask = resp.to(dev), mask.bool().to(dev)
     torch.manual_seed(4)
@@ -652,7 +654,8 @@ def test_fused_cond_flow_trainer_replays_bitwise_from_a_hipgraph():
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for it in range(3):
-            rows.copy_(perm[it * B:(it + 1) * B])
+            lo = (it * B) % (P - B)
+            rows.copy_(perm[lo:lo + B])
             t1.step(resp, mask, row_index=rows)
             t2.step(resp, mask, row_index=rows)
     torch.cuda.current_stream().wait_stream(side)
@@ -662,8 +665,9 @@ def test_fused_cond_flow_trainer_replays_bitwise_from_a_hipgraph():
         t1.step(resp, mask, row_index=rows)
     t2.step(resp, mask, row_index=rows)                    # (the capture ran step 4 once for t1 as well? no: capture records only)
     gr.replay()
-    for it in range(4, 204):
-        rows.copy_(perm[(it * B) % P:(it * B) % P + B])
+    for it in range(4, 4 + replays):
+        lo = (it * B) % (P - B)
+        rows.copy_(perm[lo:lo + B])
         gr.replay()
         t2.step(resp, mask, row_index=rows)
     torch.cuda.synchronize()

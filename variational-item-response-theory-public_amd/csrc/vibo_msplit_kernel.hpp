@@ -703,18 +703,22 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 const float zin = fmaf(-ud, t, znext);       // its input (to an ulp of the forward's value)
                 znext = zin;
                 const float omt = 1.0f - t * t;
-                const float unit = ((psi >= 0.f) ? 1.0f : -1.0f) / (fabsf(psi) + 1e-8f);
                 // set 0 (LL): no log-det term
                 const float g_a0 = ms_group_sum(gz0 * ud) * omt;
                 const float f00 = gz0 * t, f01 = lv * g_a0 * zin, f02 = lv * g_a0;
                 gz0 = fmaf(g_a0, wd, gz0) * lv;
-                // set 1 (REG = log q0 - sum log|det| - log p): d REG / d ladj = -1
-                const float dl_dpsi = -unit;
-                const float g_t = dl_dpsi * (-2.0f * t * cwu) + ms_group_sum(gz1 * ud);
-                const float g_c = dl_dpsi * omt;
-                const float g_a1 = g_t * omt;
-                const float f10 = lv1 * (gz1 * t + g_c * wd), f11 = lv1 * (g_a1 * zin + g_c * ud), f12 = lv1 * g_a1;
-                gz1 = fmaf(g_a1, wd, gz1) * lv1;
+                // set 1 (REG = log q0 - sum log|det| - log p): d REG / d ladj = -1.  Only the primary panel owns the regulariser
+                // (wave-uniform): the other nine panels of a 10 000-item row skip its arithmetic and its three folds per flow.
+                float f10 = 0.f, f11 = 0.f, f12 = 0.f;
+                if (primary) {
+                    const float unit = ((psi >= 0.f) ? 1.0f : -1.0f) / (fabsf(psi) + 1e-8f);
+                    const float dl_dpsi = -unit;
+                    const float g_t = dl_dpsi * (-2.0f * t * cwu) + ms_group_sum(gz1 * ud);
+                    const float g_c = dl_dpsi * omt;
+                    const float g_a1 = g_t * omt;
+                    f10 = lv1 * (gz1 * t + g_c * wd); f11 = lv1 * (g_a1 * zin + g_c * ud); f12 = lv1 * g_a1;
+                    gz1 = fmaf(g_a1, wd, gz1) * lv1;
+                }
                 // the slot's 8 persons (lanes 8 apart) -> lanes 0..7, then one running sum per (slot, set, kind, dim)
                 auto fold = [&](float v, float* dst) {
                     v += dpp_f<0x128>(v);               // row_ror 8
@@ -723,7 +727,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     if (lane < 8) lds_add(dst, v);
                 };
                 fold(f00, &fl.facc[par][sl][0][f][0][ed]); fold(f01, &fl.facc[par][sl][0][f][1][ed]); fold(f02, &fl.facc[par][sl][0][f][2][ed]);
-                fold(f10, &fl.facc[par][sl][1][f][0][ed]); fold(f11, &fl.facc[par][sl][1][f][1][ed]); fold(f12, &fl.facc[par][sl][1][f][2][ed]);
+                if (primary) {
+                    fold(f10, &fl.facc[par][sl][1][f][0][ed]); fold(f11, &fl.facc[par][sl][1][f][1][ed]); fold(f12, &fl.facc[par][sl][1][f][2][ed]);
+                }
             };
 #pragma unroll 1
             for (int f = p.n_flows - 1; f >= 0; --f) flow_back(f);
