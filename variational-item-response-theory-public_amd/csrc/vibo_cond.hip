@@ -221,117 +221,6 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
 }
 
 // ---------------------------------------------------------------------------
-// cond_pre for ONE ability dim (the reference default, BASELINE configs[4]) as a stream: a wave per row (round 5).
-// cond_pre_kernel keeps an item in its lane and walks 8-row batches: three 64-lane butterflies, an LDS hand-over and two
-// workgroup barriers per batch couple the four waves of a workgroup, and at 2 workgroups per CU the pass moves its 6 B/cell (5
-// read, 1 written as cell codes) at 5.1 TB/s where the plain count pass (row_count_kernel: a wave per row, nothing shared)
-// streams 6.0.  Here a wave takes a whole <= 1024-item panel of a row -- lane l owns chunks l, 64 + l, 128 + l, 192 + l of EVERY
-// row, its 16 items' tau / mu tau for both codes in 64 registers -- two rows in flight, one 64-lane sum of (lam, s, nobs) per
-// row, no LDS, no barrier; 3 waves per SIMD.  Same arithmetic per item as cond_pre_kernel<1>; the row sums add in a different
-// order (fp32 rounding: the two forms agree to ~1e-6 relative, each is bitwise reproducible).
-template <bool CODES>
-__global__ __launch_bounds__(256, 3) void cond_pre_row_kernel(const CondParams p_in) {
-    CondParams p = p_in;
-    const int lane = threadIdx.x & 63;
-    long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), wstep = (long long)gridDim.x * 4;     // this wave, all waves
-    if (p_in.panel_count > 1) {                  // (the grid's wave count is a multiple of panel_count)
-        const int panel = (int)(w % p_in.panel_count);
-        w /= p_in.panel_count;
-        wstep /= p_in.panel_count;
-        p.item0 = panel * 1024;
-        p.I = p.I_total - p.item0 < 1024 ? p.I_total - p.item0 : 1024;
-        p.pre_out = p_in.pre_out + (size_t)panel * p.B * 3;
-    }
-    const int n4 = (p.I + 3) >> 2;
-    float tau[4][4][2], mt[4][4][2];
-    uint32_t tailm[4];
-    int cc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int chunk = lane + 64 * u;
-        const bool ok = chunk < n4;
-        cc[u] = ok ? chunk : n4 - 1;
-        tailm[u] = !ok ? 0u : ((p.I & 3) && chunk == (p.I >> 2)) ? ((1u << (8 * (p.I & 3))) - 1u) : 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int item = p.item0 + 4 * chunk + j;
-                const bool item_ok = ok && item < p.I_total;
-                const float* te = p.table + ((size_t)c * p.I_total + (item_ok ? item : 0)) * 2;
-                float t = 0.f, mm = 0.f;
-                if (item_ok) {
-                    t = 1.0f / (expf(te[1]) + kPoeEps);                  // utils.py:105-113
-                    mm = te[0] * t;
-                }
-                tau[u][j][c] = t;
-                mt[u][j][c] = mm;
-            }
-    }
-    const bool have_mask = CODES || p.mask_dtype == 0;
-    // loads carry no predicate: rows past the end read the last row, chunks past the row's end its last chunk; masked at use
-    auto load_row = [&](const long long row, float4 (&x)[CODES ? 1 : 4], uint32_t (&m)[4]) __attribute__((always_inline)) {
-        const long long rc = row < p.B ? row : (long long)p.B - 1;
-        const long long src = p.row_index ? p.row_index[rc] : rc;
-        const uint8_t* mb = static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if constexpr (!CODES) x[u] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[cc[u]];
-            m[u] = have_mask ? reinterpret_cast<const uint32_t*>(mb)[cc[u]] : 0x01010101u;
-        }
-    };
-    auto process = [&](const long long row, float4 (&x)[CODES ? 1 : 4], uint32_t (&m)[4], const long long refill) __attribute__((always_inline)) {
-        const bool rok = row < p.B;
-        float v0 = 0.f, v1 = 0.f;
-        int nobs = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t keep = rok ? tailm[u] : 0u;
-            float wp[4], wn[4];
-            int nb = 0;
-            if constexpr (CODES) {
-                word_indicators<true>(m[u], keep, wp, wn, nb);
-            } else {
-                int pk = 0;
-                const uint32_t cw = pack_codes4(x[u], m[u] & keep, pk);
-                nb = pk & 0xffff;
-                if (p.codes_out && rok && tailm[u] != 0u)
-                    reinterpret_cast<uint32_t*>(p.codes_out + row * p.codes_stride + p.item0)[lane + 64 * u] = cell_codes4(x[u], m[u] & keep);
-                word_indicators<false>(cw, keep, wp, wn, nb);
-            }
-            nobs += nb;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v0 = fmaf(wp[j], tau[u][j][1], fmaf(wn[j], tau[u][j][0], v0));
-                v1 = fmaf(wp[j], mt[u][j][1], fmaf(wn[j], mt[u][j][0], v1));
-            }
-        }
-        load_row(refill, x, m);           // (clamped inside: always a valid address; the row after next, into the registers just freed)
-        __builtin_amdgcn_sched_barrier(0);
-        const float s0 = wave_sum63(v0), s1 = wave_sum63(v1);
-        const int sn = wave_sum63(nobs);
-        if (lane == 63 && rok) {
-            float* o = p.pre_out + row * 3;
-            o[0] = s0; o[1] = s1; o[2] = (float)sn;
-        }
-    };
-    float4 xa[CODES ? 1 : 4], xb[CODES ? 1 : 4];
-    uint32_t ma[4], mb_[4];
-    long long row = w;
-    if (row < p.B) {
-        load_row(row, xa, ma);
-        load_row(row + wstep, xb, mb_);
-    }
-    while (row < p.B) {
-        process(row, xa, ma, row + 2 * wstep);
-        row += wstep;
-        if (row >= p.B) break;
-        process(row, xb, mb_, row + 2 * wstep);
-        row += wstep;
-    }
-}
-
-// ---------------------------------------------------------------------------
 template <int AT, bool CODES>
 __global__ __launch_bounds__(256, AT <= 2 ? (CODES ? 3 : 2) : 1) void cond_post_kernel(const CondParams p) {
     constexpr int NC = 4 * AT;                       // coefficients per person: [head][P1|P2][dim]
@@ -434,16 +323,6 @@ __global__ __launch_bounds__(1024) void cond_finalize_kernel(const CondFinTail t
 
 hipError_t launch_cond_pre(const CondParams& p, int at, int nq, int grid, hipStream_t s) {
     const bool codes = p.mask_dtype == 3;      // VIBO_MASK_CODES
-    // one ability dim, a call large enough to fill the chip with waves: the wave-per-row stream (cond_pre_row_kernel)
-    if (p.A == 1 && at <= 1 && p.a0 == 0 && (long long)p.B * (p.panel_count > 1 ? p.panel_count : 1) >= 16384) {
-        const int panels = p.panel_count > 1 ? p.panel_count : 1;
-        int wgs = 768;                           // 3 waves per SIMD on 256 CUs
-        wgs = wgs / panels * panels;             // (whole multiples of panel_count waves: 4 waves per workgroup x wgs)
-        if (wgs < panels) wgs = panels;
-        if (codes) hipLaunchKernelGGL((cond_pre_row_kernel<true>), dim3(wgs), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((cond_pre_row_kernel<false>), dim3(wgs), dim3(256), 0, s, p);
-        return hipGetLastError();
-    }
     if (at <= 1) {
         if (codes) hipLaunchKernelGGL((cond_pre_kernel<1, true>), dim3(grid), dim3(64 * nq), 0, s, p);
         else hipLaunchKernelGGL((cond_pre_kernel<1, false>), dim3(grid), dim3(64 * nq), 0, s, p);
