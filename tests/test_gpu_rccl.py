@@ -141,10 +141,12 @@ TWO_RANK_SCRIPT = textwrap.dedent('''
     g = torch.Generator(device=dev).manual_seed(5)
     resp = (torch.rand(P, I, device=dev, generator=g) < 0.5).float()
     mask = torch.rand(P, I, device=dev, generator=g) >= 0.2
-    for kind, A in (('plain', 8), ('cond_flows', 2)):
+    for kind, A in (('plain', 8), ('cond_flows', 2), ('mean', 2)):
         torch.manual_seed(11)
         if kind == 'plain':
             base = VIBO_2PL(A, I, ability_merge='product').to(dev)
+        elif kind == 'mean':            # FusedMeanTrainer: the per-person posterior gradients stay local, one collective of the sums
+            base = VIBO_2PL(A, I, ability_merge='mean').to(dev)
         else:
             base = VIBO_3PL(A, I, ability_merge='product', conditional_posterior=True, n_norm_flows=2).to(dev)
         D = base.spec.item_dim
@@ -179,7 +181,8 @@ TWO_RANK_SCRIPT = textwrap.dedent('''
 
 def test_two_ranks_sharded_fused_trainers_equal_the_single_process_step(tmp_path):
     """Person sharding through the native trainers on two processes (both on the one GPU, gloo): FusedTrainer (plain 2PL,
-    ability_dim 8) and FusedCondFlowTrainer (3PL, conditional posterior, 2 flows, two item panels) run three recorded-noise steps
+    ability_dim 8), FusedCondFlowTrainer (3PL, conditional posterior, 2 flows, two item panels) and FusedMeanTrainer (--ability-merge
+    mean, round 5: `reduce_shards`) run three recorded-noise steps
     on uneven person shards with ONE all-reduce of the flat [scalars | gradients] buffer per step (vibo.py:243-268 under
     sharding) -- losses and parameters equal the single-process steps on all persons to fp32 summation order, and the two
     replicas stay bit-identical to each other."""

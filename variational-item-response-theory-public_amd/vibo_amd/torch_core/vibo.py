@@ -484,7 +484,7 @@ def main(argv=None):
     if (args.cuda and not args.torch_optimizer and fused_trainer_covers(model, args.hidden_dim)
             and (args.hidden_dim <= 256 or not plain)):      # (else: module + torch.optim.Adam)
         # the whole step natively: FusedTrainer's kernels, (conditional posterior / planar flows) FusedCondFlowTrainer's, or
-        # (--ability-merge mean, unconditional posterior, one GPU) FusedMeanTrainer's -- same Adam arithmetic, 2-12 launches
+        # (--ability-merge mean, unconditional posterior) FusedMeanTrainer's -- same Adam arithmetic, 2-12 launches
         # per step, no PyTorch autograd inside the replayed graph
         from ..trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed, max_batch=local_bs)

@@ -26,8 +26,8 @@ Same arithmetic as the PyTorch path (tests/test_gpu_trainer.py compares paramete
 populated.
 FusedTrainer covers the unconditional posterior without flows; `FusedTrainer(model)` returns its sibling
 FusedCondFlowTrainer (same interface, vibo_ctrain_* kernels) for --conditional-posterior / --n-norm-flows models.
-FusedMeanTrainer (vibo_mtrain_* kernels) is the same for --ability-merge mean with the unconditional posterior on one GPU.
-The MLP decoders, mean x conditional and person-sharded mean-merge models train through the module + torch.optim path
+FusedMeanTrainer (vibo_mtrain_* kernels) is the same for --ability-merge mean with the unconditional posterior (person-sharded too).
+The MLP decoders and mean x conditional train through the module + torch.optim path
 (fused_trainer_covers() tells which).
 """
 import ctypes
@@ -41,13 +41,13 @@ def fused_trainer_covers(model, hidden_dim=None):
     """True when one of the fused trainers of this module runs the model's whole train step natively: the product-of-experts
     encoder with the IRT decoder -- plain (FusedTrainer's kernels), or with the conditional posterior and / or planar flows
     (FusedCondFlowTrainer's, hidden width <= 64) -- or the --ability-merge mean encoder with the unconditional posterior
-    (FusedMeanTrainer's, one GPU).  The MLP decoders and mean x conditional train through the module + torch.optim.Adam."""
+    (FusedMeanTrainer's; person-sharded too since round 5).  The MLP decoders and mean x conditional train through the module + torch.optim.Adam."""
     if getattr(model, 'generative_model', 'irt') != 'irt':
         return False
     if model.ability_merge == 'mean':          # FusedMeanTrainer: unconditional posterior, no flows, hidden width <= 128
         H = hidden_dim if hidden_dim is not None else model.ability_encoder.mlp1[0].weight.shape[0]
         return (not model.conditional_posterior and model.n_norm_flows == 0 and H <= 128
-                and model.ability_dim <= _lib.MAX_ABILITY_DIM_FAST and model._reducer is None)
+                and model.ability_dim <= _lib.MAX_ABILITY_DIM_FAST)
     if model.ability_merge != 'product':
         return False
     if model.conditional_posterior or model.n_norm_flows > 0:
@@ -425,12 +425,13 @@ class FusedMeanTrainer(FusedTrainer):
     backward through u, v and mlp1 by hand, Adam on everything).  No PyTorch autograd node: the step replays from a hipGraph
     like FusedTrainer's (eight launches since the GIVEN call reads / writes the posterior itself: DESIGN 3.6).  Same interface (`FusedTrainer(model, ...)` returns this class for such models).
     The packed row counts of the resident matrix are computed once (ops.row_counts keeps them while the same tensors come back).
-    One GPU: person-sharded mean-merge models keep the module path."""
+    Person-sharded (round 5): `reduce_shards()` between the two halves all-reduces [scalars | item gradient | encoder gradient sums]
+    in one collective; the per-person posterior gradients stay on their rank."""
 
     def __init__(self, model, lr=5e-3, rng='torch', seed=0, fused_noise=True, fold=True, max_batch=None):
         if not fused_trainer_covers(model):
             raise NotImplementedError('FusedMeanTrainer: --ability-merge mean with the unconditional posterior, the IRT decoder, no '
-                                      'flows, hidden_dim <= 128, ability_dim <= 8, one GPU; use model.elbo_step + torch.optim.Adam otherwise')
+                                      'flows, hidden_dim <= 128, ability_dim <= 8; use model.elbo_step + torch.optim.Adam otherwise')
         self.model = model
         self.generation = 0
         enc = model.ability_encoder
@@ -487,8 +488,6 @@ class FusedMeanTrainer(FusedTrainer):
         if beta is not None:
             self.set_beta(beta)
         model, spec, lib, p = self.model, self.model.spec, _lib.load(), ops._ptr
-        if model._reducer is not None:
-            raise NotImplementedError('FusedMeanTrainer: person-sharded mean-merge models train through model.elbo_step')
         counts = ops.row_counts(response, mask)             # packed (n_correct << 16 | n_observed) of every resident row, cached
         if row_index is not None:
             counts = counts[row_index]
@@ -514,8 +513,9 @@ class FusedMeanTrainer(FusedTrainer):
             # reference draw order: item eps, then ability eps (models.py:361,368)
             eps_item = model._randn(self.item_mu.shape, self.item_mu, model._item_gen)
             eps_ab = None
+        ab_stream = 1 + getattr(model, '_shard_rank', 0)      # (person-sharded: item noise identical on every rank, ability noise per rank)
         rc = lib.vibo_mtrain_prologue(ctypes.byref(d), H, p(self.par_flat), p(self.item_mu), p(self.item_lv), p(eps_item), self.seed,
-                                      1 if native else 0, p(eps_ab) if native else ctypes.c_void_p(0), 1, p(self.item_feat), p(self.uv),
+                                      1 if native else 0, p(eps_ab) if native else ctypes.c_void_p(0), ab_stream, p(self.item_feat), p(self.uv),
                                       p(self.saved), p(self.kl_parts), p(self._steps), stream)
         _lib.check(rc, 'vibo_mtrain_prologue')
         if eps_ab is None:
@@ -537,6 +537,33 @@ class FusedMeanTrainer(FusedTrainer):
         self._pending = (d, eps_item, raw, parts, n_part)
         self.last = raw
         return raw
+
+    @torch.no_grad()
+    def reduce_shards(self):
+        """Person sharding (round 5): ONE all-reduce per step of [8 scalars | item gradient | the encoder's gradient sums] -- what
+        is a sum over persons.  The per-person posterior gradients inside raw.flat (2 x B x 2A: this rank's persons) stay local;
+        the per-wave encoder partial records are summed on this rank first (their count depends on the shard size)."""
+        model = self.model
+        if model._reducer is None:
+            return
+        d, eps_item, raw, parts, n_part = self._pending
+        B, A = raw.ability_mu.shape[0], model.ability_dim
+        ns = _lib.NUM_SCALARS
+        o = ns + 2 * B * 2 * A                              # item gradient behind the per-person sets
+        n_item = self.item_mu.numel()
+        psum = parts[:n_part].sum(0, keepdim=True)
+        buf = torch.cat([raw.flat[:ns], raw.flat[o:o + n_item], psum.reshape(-1)])
+        model._reducer(buf)
+        raw.flat[:ns].copy_(buf[:ns])
+        raw.flat[o:o + n_item].copy_(buf[ns:ns + n_item])
+        psum.copy_(buf[ns + n_item:].view_as(psum))
+        self._pending = (d, eps_item, raw, psum, 1)
+
+    @torch.no_grad()
+    def step(self, response, mask, beta=None, row_index=None, eps_item=None, eps_ability=None):
+        self.forward_backward(response, mask, beta=beta, row_index=row_index, eps_item=eps_item, eps_ability=eps_ability)
+        self.reduce_shards()
+        return self.update()
 
     @torch.no_grad()
     def update(self):
