@@ -20,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
 ap.add_argument('--seed', type=int, default=0)
 ap.add_argument('--target', choices=['elbo', 'multi', 'module', 'trainer'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
-ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only codes" of a reported failure')
+ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only codes given kflag" of a reported failure')
 a = ap.parse_args()
 rng = random.Random(a.seed)
 d = torch.device('cuda:0')
@@ -262,6 +262,9 @@ while time.time() - t0 < a.seconds:
     fwd_only = rng.random() < 0.2
     codes = rng.random() < 0.35 and not no_mask and not (cond and A > 4) and A <= 8      # rows as 1-byte cell codes (Format P)
     given = (not cond) and A <= 8 and rng.random() < 0.25      # caller-supplied posterior (VIBO_POSTERIOR_GIVEN, --ability-merge mean)
+    # which row-split kernel: the planner's choice (the narrow-row kernel for <= 128 items at ability_dim <= 4, else by size), or one
+    # pinned through vibo_desc.flags -- at these minibatch sizes the planner alone never picks the matrix kernel (round 5)
+    kflag = rng.choice([0, 0, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU])
     if a.replay:
         f = a.replay.split()
         irt, A, B, I, n_flows, dataseed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])
@@ -269,6 +272,7 @@ while time.time() - t0 < a.seconds:
         gather, no_mask, fwd_only = f[11] == 'True', f[12] == 'True', f[13] == 'True'
         codes = len(f) > 14 and f[14] == 'True'
         given = len(f) > 15 and f[15] == 'True'
+        kflag = int(f[16]) if len(f) > 16 else 0
     if given:
         pad = True                 # this mode exists on the row-split path only: rows padded like the resident data path does
     spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=cond, drop_missing=drop, n_flows=n_flows, given=given)
@@ -306,6 +310,7 @@ while time.time() - t0 < a.seconds:
     if codes:
         r_, m_ = ops.pack_cell_codes(resp_all.to(d), mask_all.bool().to(d)), None
     r, m, code = ops.prepare_rows(r_, None if no_mask else m_)
+    ops.DESC_FLAGS = kflag
     raw = ops._hip_launch_elbo(spec, r, m, code, rows.to(d) if gather else None, table.to(d).contiguous(), item.to(d).contiguous(),
                                eps.to(d).contiguous(), flow.to(d).contiguous() if flow is not None else None,
                                _lib.REG_SAMPLED if n_flows else _lib.REG_KL, not fwd_only, B)
@@ -364,7 +369,7 @@ while time.time() - t0 < a.seconds:
               '| d LL / d theta range:', (float(ref['g_item'].abs().max()) if 'g_item' in ref else None))
         sys.exit(1 if bad else 0)
     if bad:
-        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only} codes={codes} given={given}: {bad}')
-        print(f'replay: --replay "{irt} {A} {B} {I} {cond} {n_flows} {drop} {missing} {pad} {scale} {dataseed} {gather} {no_mask} {fwd_only} {codes} {given}"')
+        print(f'FAIL irt={irt} A={A} B={B} I={I} cond={cond} flows={n_flows} drop={drop} missing={missing} pad={pad} gather={gather} no_mask={no_mask} fwd_only={fwd_only} codes={codes} given={given} kflag={kflag}: {bad}')
+        print(f'replay: --replay "{irt} {A} {B} {I} {cond} {n_flows} {drop} {missing} {pad} {scale} {dataseed} {gather} {no_mask} {fwd_only} {codes} {given} {kflag}"')
         sys.exit(1)
 print(f'fuzz ok: {n} random configurations, worst relative error {worst:.2e}')
