@@ -71,7 +71,8 @@ def test_golden_adam_trajectory(golden):
         assert (model.state_dict()[k].cpu() - v).abs().max() < 5e-4, k
 
 
-def test_golden_adam_trajectory_through_the_fused_trainers(golden):
+@pytest.mark.parametrize('rows', ['direct', 'gathered', 'cell-codes'])
+def test_golden_adam_trajectory_through_the_fused_trainers(golden, rows):
     """The reference's own recorded Adam steps (tools/gen_golden.py: parameters after 1 and 3 steps of vibo.py:243-268 with
     the case's noise replayed) through the NATIVE train step -- FusedTrainer's kernels for the plain model,
     FusedCondFlowTrainer's (vibo_ctrain_*: table MLP / flow backward + Adam by hand) for --conditional-posterior /
@@ -83,13 +84,29 @@ def test_golden_adam_trajectory_through_the_fused_trainers(golden):
         pytest.skip('configuration trains through the module path')
     if m['n_norm_flows'] == 0 and not m['use_kl_divergence']:
         pytest.skip('the fused trainers use the analytic KL regulariser (the CLI default)')
+    if rows != 'direct' and m['ability_dim'] > 8:
+        pytest.skip('ability_dim 9..16 runs on the wave-per-person kernel: fp32 rows handed over directly')
     d = dev()
     model = model.to(d)
     tr = FusedTrainer(model, lr=5e-3)
     resp, mask = ops.pad_rows(golden.response.to(d), golden.mask.to(d).bool())      # (row strides padded to 4 cells, as the CLI's resident splits)
     eps_i, eps_a = golden.eps_item.to(d), golden.eps_ability.to(d)
+    # rows: the golden's minibatch handed over directly, or the way the CLI's resident data path does it -- as a
+    # row_index vector into a larger resident matrix (the golden's rows scattered among decoys), or as 1-byte cell codes
+    row_index = None
+    if rows == 'gathered':
+        B, I = golden.response.shape
+        g = torch.Generator().manual_seed(B * I)
+        big_r = (torch.rand(3 * B + 5, I, generator=g) < 0.5).float()
+        big_m = torch.rand(3 * B + 5, I, generator=g) < 0.8
+        where = torch.randperm(3 * B + 5, generator=g)[:B]
+        big_r[where], big_m[where] = golden.response, golden.mask.bool()
+        resp, mask = ops.pad_rows(big_r.to(d), big_m.to(d))
+        row_index = where.to(d)
+    elif rows == 'cell-codes':
+        resp, mask = ops.pack_cell_codes(golden.response.to(d), golden.mask.to(d).bool()), None
     for step in range(3):
-        loss = tr.step(resp, mask, beta=m['annealing_factor'], eps_item=eps_i, eps_ability=eps_a)
+        loss = tr.step(resp, mask, beta=m['annealing_factor'], row_index=row_index, eps_item=eps_i, eps_ability=eps_a)
         if step == 0:
             assert rel_err(loss, golden.out['loss']) < TOL_ELBO
             for k, v in golden.adam1.items():
