@@ -95,6 +95,8 @@ typedef struct vibo_desc {
  * descriptor -- no environment variables, no state between calls. */
 enum { VIBO_FLAG_KERNEL_VALU = 1,     /* row-split work goes to the VALU kernel (vibo_split_kernel.hpp)              */
        VIBO_FLAG_KERNEL_MATRIX = 2,   /* ... to the matrix-pipe kernel (vibo_msplit_kernel.hpp) whatever the size    */
+                                      /* (either flag also keeps narrow rows -- 4..128 items, ability_dim <= 4, plain model -- off the
+                                       *  narrow-row kernel, vibo_narrow.hip, which the planner picks for them otherwise)            */
        VIBO_FLAG_NO_EMIT_CODES = 4,   /* multi-pass paths re-read the fp32 rows instead of the first pass's cell codes */
        VIBO_FLAG_COND_VALU = 8,       /* conditional posterior: the VALU passes (vibo_cond.hip) instead of the matrix-pipe ones */
        VIBO_FLAG_COND_MATRIX = 16 };  /* ... the matrix-pipe passes (vibo_cmean.hip) whatever the size, wherever the rows allow  */
