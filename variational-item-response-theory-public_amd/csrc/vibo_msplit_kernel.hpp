@@ -138,6 +138,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // Two modes instead of one EXTRA flag (round 4): each carries the other's pointers, branches and -- the given mode's expf /
     // logvar loads -- spilled registers no longer.
     constexpr bool EXTRA = XM != 0, XCOND = XM == 1, XGIVEN = XM == 2;
+    // The flow instantiations that spilled (3PL, the hook modes, gathered rows) form their LDS addresses in the slot code
+    // instead of keeping them loop-invariant in registers: see backward_slot.  (The others -- 2PL / 1PL flows on rows in
+    // order, no spills -- measured 2 % slower with the same pins, so they keep the hoisted addresses.)
+    constexpr bool kPinFlowAddr = FLOWS && (IRT == 3 || XM != 0 || RM == 1);
     constexpr bool CODES = RM == 2;
     constexpr int R = kMsRows;
     constexpr float kLoS = kLogitLo * kLog2e, kHiS = kLogitHi * kLog2e;
@@ -385,14 +389,24 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int il = kMsSpan * q + xl;
         const bool ok = il < I;
         const size_t ir = (size_t)(item0 + (ok ? il : 0)) * p.D;     // (entry index into the caller's item sample)
+        // All of the lane's entries are asked for at once, from clamped (always valid) indices, and masked afterwards: written
+        // as `if (ok && kk < A) na = item_raw[..]` each load sat in its own branch behind an s_waitcnt vmcnt(0) -- 18 memory
+        // round trips in a row at the start of every workgroup (cold TLB, cold L2), most of the kernel's one-shot prologue.
+        float a_raw[8];
+        if constexpr (IRT != 1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) a_raw[kk] = p.item_raw[ir + min(kk, A - 1)];
+        }
+        const float b_raw = p.item_raw[ir + (IRT == 1 ? 0 : A)];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float na = 0.f;
-            if (ok && kk < A) na = IRT == 1 ? kLog2e : -p.item_raw[ir + kk] * kLog2e;      // models.py:731 / 744,759
+            if constexpr (IRT == 1) na = (ok && kk < A) ? kLog2e : 0.f;                     // models.py:731
+            else na = (ok && kk < A) ? -a_raw[kk] * kLog2e : 0.f;                          // models.py:744,759
             na_raw[h][kk] = na;
             amax = !(fabsf(na) <= 3.0e38f) ? 3.0e38f : fmaxf(amax, fabsf(na));       // (NaN / Inf: "too large", sticky)
         }
-        nb_raw[h] = ok ? p.item_raw[ir + (IRT == 1 ? 0 : A)] * kLog2e : 0.f;
+        nb_raw[h] = ok ? b_raw * kLog2e : 0.f;
         bmax = !(fabsf(nb_raw[h]) <= 3.0e38f) ? 3.0e38f : fmaxf(bmax, fabsf(nb_raw[h]));
     }
     {
@@ -440,17 +454,24 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         *reinterpret_cast<half8*>(dst + 8) = lo8;
         *reinterpret_cast<half8*>(dst + 16) = half8{b0, b1, b2, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     }
+    if constexpr (IRT == 3) {
+        float g_raw[2][4];                  // (all eight loads first, clamped and unconditional, as above)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
-            const bool ok = IRT == 3 && il < I;
-            if constexpr (IRT == 3) {
-                const float gv = ok ? 1.0f / (1.0f + expf(-p.item_raw[(size_t)(item0 + il) * p.D + A + 1])) : 0.f;   // models.py:758
+            for (int t = 0; t < 4; ++t) {
+                const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
+                g_raw[u][t] = p.item_raw[(size_t)(item0 + (il < I ? il : 0)) * p.D + A + 1];
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
+                const float gv = il < I ? 1.0f / (1.0f + expf(-g_raw[u][t])) : 0.f;           // models.py:758
                 if (g == 0) gsl[(u * 4 + t) * 16 + i16] = gv;
             }
-        }
+    }
     // per-lane offsets (halfs) into the operand image
     const int b1ofs = i16 * kMsItemLane + (g == 1 ? 8 : g == 3 ? 16 : 0);
     const int b3ofs = (4 * g + (i16 >> 2)) * kMsItemLane + 4 * (i16 & 3);
@@ -566,8 +587,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         if (!have_cnt) {
             if constexpr (NW8) {
+                int ppo = pp;
+                if constexpr (kPinFlowAddr) asm volatile("" : "+v"(ppo));     // (see backward_slot)
 #pragma unroll
-                for (int w = 0; w < 8; ++w) cnt += wls[w].cnt[pp];
+                for (int w = 0; w < 8; ++w) cnt += wls[w].cnt[ppo];
             } else {
 #pragma unroll 1
                 for (int w = 0; w < nw; ++w) cnt += wls[w].cnt[pp];
@@ -613,17 +636,19 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         float thv = th0;
         float ladj = 0.f;
         if constexpr (FLOWS) {              // z <- z + uhat tanh(w.z + b)
+            int ppf = pp, edf = ed;             // (opaque copies: see backward_slot)
+            if constexpr (kPinFlowAddr) asm volatile("" : "+v"(ppf), "+v"(edf));
 #pragma unroll
             for (int f = 0; f < kMsMF; ++f) {
                 if (f < p.n_flows) {
-                    const float ud = fl.fpar[f][0][ed], wd = fl.fpar[f][1][ed];
+                    const float ud = fl.fpar[f][0][edf], wd = fl.fpar[f][1][edf];
                     const float aa = ms_group_sum(thv * wd) + fl.fsc[f][0];
                     // tanh(x) = 1 - 2 / (1 + e^2x), |x| clamped so that e^2x stays finite (tanh(+-15) = +-1 in fp32)
                     const float t = 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2((2.0f * kLog2e) * med3(aa, -15.f, 15.f)));
                     const float psi = 1.0f + (1.0f - t * t) * fl.fsc[f][1];
                     if (GRAD && ed == 0) {
-                        fl.tps[par][f][0][pp] = t;
-                        fl.tps[par][f][1][pp] = psi;
+                        fl.tps[par][f][0][ppf] = t;
+                        fl.tps[par][f][1][ppf] = psi;
                     }
                     ladj += kLn2 * fast_log2(fabsf(psi) + 1e-8f);
                     thv = fmaf(ud, t, thv);
@@ -672,8 +697,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const bool live = ed < A && (row0 + pp) < p.B;
         float g0 = 0.f;
         if constexpr (NW8) {
+            // (flows: the element index behind an opaque copy -- the eight record addresses are then formed here from one base
+            //  and immediate offsets; left to itself the compiler keeps eight loop-invariant addresses in registers for the
+            //  whole batch loop, which the flow instantiations, already at the 256-register budget, pay for in spills)
+            int go = pp * 8 + ed;
+            if constexpr (kPinFlowAddr) asm volatile("" : "+v"(go));
+            const float* const g8 = &wls[0].gth[par][0][0] + go;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) g0 += wls[w].gth[par][pp][ed];
+            for (int w = 0; w < 8; ++w) g0 += g8[w * (int)(sizeof(MsWaveLds) / sizeof(float))];
         } else {
 #pragma unroll 1
             for (int w = 0; w < nw; ++w) g0 += wls[w].gth[par][pp][ed];
@@ -688,18 +719,23 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if constexpr (!FLOWS) {
             gz1 = (reg_on && p.reg_mode != 0) ? thv : 0.f;        // d REG / d theta_K (-log p)
         } else {
-            // the sample after the flows again (the forward's arithmetic on the kept tanh values: same bits)
+            // the sample after the flows again (the forward's arithmetic on the kept tanh values: same bits).  (ppf, edf: the row
+            // and dim indices behind opaque copies, so that the record and parameter addresses are formed here -- one base,
+            // immediate offsets -- instead of being hoisted out of the batch loop, one register per address: 16 and more
+            // loop-invariant registers that the 3PL instantiations, at the 256-register budget, paid for in spills)
+            int ppf = pp, edf = ed;
+            if constexpr (kPinFlowAddr) asm volatile("" : "+v"(ppf), "+v"(edf));
 #pragma unroll
             for (int f = 0; f < kMsMF; ++f)
-                if (f < p.n_flows) thv = fmaf(fl.fpar[f][0][ed], fl.tps[par][f][0][pp], thv);
+                if (f < p.n_flows) thv = fmaf(fl.fpar[f][0][edf], fl.tps[par][f][0][ppf], thv);
             gz1 = (reg_on && p.reg_mode != 0) ? thv : 0.f;
             float znext = thv;                  // output of the flow being backpropagated
             const float lv = live ? 1.0f : 0.f, lv1 = reg_on ? 1.0f : 0.f;
             const int sl = (e >> 6) & 3;
             auto flow_back = [&](const int f) {
-                const float ud = fl.fpar[f][0][ed], wd = fl.fpar[f][1][ed];
+                const float ud = fl.fpar[f][0][edf], wd = fl.fpar[f][1][edf];
                 const float cwu = fl.fsc[f][1];
-                const float t = fl.tps[par][f][0][pp], psi = fl.tps[par][f][1][pp];
+                const float t = fl.tps[par][f][0][ppf], psi = fl.tps[par][f][1][ppf];
                 const float zin = fmaf(-ud, t, znext);       // its input (to an ulp of the forward's value)
                 znext = zin;
                 const float omt = 1.0f - t * t;
