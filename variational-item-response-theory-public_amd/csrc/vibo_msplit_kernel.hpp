@@ -275,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // barriers of every batch: VIBO_POSTERIOR_GIVEN 1.25 -> 1.21 ms at 8 dims, 1.06 -> 0.99 at 1; +5 spilled registers there)
     constexpr bool kPrs = true;
     float prs0 = 0.f, prs1 = 0.f, prs2 = 0.f;
+    int prc = 0;                                      // whole-row answer counts of the panel mode (p.row_cnt), the same way
     // slots of this wave for a batch: [s0, s1) in steps of `step` (one slot at most with 4 or more waves)
     auto my_slots = [&](const int par, int& s0, int& s1, int& step) {
         if (NW8 || nw == 8) {
@@ -308,6 +309,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     const bool lv = ed < A && row < p.B;
                     const float* st = p.pre_stats + (size_t)(lv ? row : 0) * (2 * A + 1);
                     prs0 = lv ? st[ed] : 0.f; prs1 = lv ? st[A + ed] : 0.f; prs2 = lv ? st[2 * A] : 0.f;
+                }
+                if (p.row_cnt) {
+                    const bool lv = ed < A && row < p.B;
+                    prc = p.row_cnt[lv ? row : 0];
+                    if (!lv) prc = 0;
                 }
             }
         }
@@ -585,6 +591,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 have_cnt = true;
             }
         }
+        if constexpr (EXTRA && !EXT && XCOND) {
+            // (panel mode: the whole-row counts came a batch ahead with eps.  Read here, between the barriers, the load's
+            //  s_waitcnt vmcnt(0) also waited for the first half of the next batch's rows, requested just before barrier A:
+            //  forward phase 1 690 -> 690 cycles per batch, wide plain rows 1.83 -> 1.73 ms)
+            if (p.row_cnt) { cnt = prc; have_cnt = true; }
+        }
         if (!have_cnt) {
             if constexpr (NW8) {
                 int ppo = pp;
@@ -824,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         my_slots(par, s0, s1, step);
         if constexpr (EXTRA || !NW8) {
             bool ext = nw < 4;                                   // (wave-uniform)
-            if constexpr (XCOND) ext = ext || p.row_cnt || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post: prs)
+            if constexpr (XCOND) ext = ext || (p.pre_stats && !(kPrs && p.pre_panels == 1));      // (given_post, row_cnt: prs / prc)
             if (ext) {
                 // (without the EXTRA hooks the plain variant serves the narrow workgroups too: eps is loaded here)
 #pragma unroll 1
@@ -973,6 +985,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         } else {
+#pragma clang fp contract(off)
+            // (no implicit contraction in this block: whether hipcc fuses `n iq - x` into one fma depends on the code around it,
+            //  and the row modes -- which schedule the tile differently, see below -- have to agree bit for bit; the fused
+            //  forms below are written out)
             // 3PL (models.py:758-765):  p = guess + (1 - guess) sigmoid(l).  With E = 2^u, u = -w l (the 2PL exponent):
             //   answered right:  p     = (1 + guess E) / (1 + E)        answered wrong:  1 - p = (1 - guess) / (1 + E)
             // i.e. both are v = n / t with t = 1 + E and n = 1 + guess sel, sel = E (right) | -1 (wrong) | 0 (missing: v = 1/2, a
@@ -987,9 +1003,13 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             int go = (u * 4 + t) * 16 + i16;
             asm volatile("" : "+v"(go));
             const float gs_ut = gsl[go];
-            // (the four cells of an M-tile at a time, everything consumed on the spot: with all eight in flight the reciprocals,
-            //  selections and ratios of the tile -- 40 registers -- sat on top of the logits and codes the second path needs, and
-            //  the instantiations at the 256-register limit (flows, hooks, gathered rows) spilled 40-430 registers)
+            // (Gathered rows: the four cells of an M-tile at a time, everything consumed on the spot -- an empty asm after each
+            //  half.  With all eight in flight the reciprocals, selections and ratios of the tile -- 40 registers -- sit on top of
+            //  the logits and codes the second path needs; until the translation units were built with
+            //  -sink-insts-to-avoid-spills (Makefile) that spilled 40-430 registers in the flow / hook / gathered instantiations and
+            //  every row mode kept the halves apart.  With the flag the 3PL kernels use 211-241 registers and the other row modes
+            //  let the compiler interleave the eight cells: 3PL 1M x 1k 1.27 -> 1.24 ms; gathered rows 1.32 -> 1.37, so they
+            //  keep the pins.)
             float dgs = 0.f;                              // the tile's d ll / d guess (added to the accumulator once, below)
             bool redo = sat3;
             if (!sat3) {
@@ -1009,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                         const float rtk = nk * iq, rnk = tk * iq;
                         vq[k4] = nk * rtk;
                         if constexpr (GRAD) {
-                            gl[k] = wc[k] * (rtk - (right ? rnk : 1.0f));
+                            gl[k] = wc[k] * fmaf(nk, iq, -(right ? rnk : 1.0f));
                             dgs = fmaf(sel, rnk, dgs);
                         }
                     }
@@ -1019,10 +1039,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vhi) : "v"(vhi), "v"(vq[2]), "v"(vq[3]));
                     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(vlo) : "v"(vlo), "v"(vq[0]), "v"(vq[1]));
                     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(vlo) : "v"(vlo), "v"(vq[2]), "v"(vq[3]));
-                    if constexpr (GRAD) {
-                        asm volatile("" : "+v"(gl[4 * h]), "+v"(gl[4 * h + 1]), "+v"(gl[4 * h + 2]), "+v"(gl[4 * h + 3]), "+v"(dgs), "+v"(pr0), "+v"(pr1));
-                    } else {
-                        asm volatile("" : "+v"(pr0), "+v"(pr1));
+                    if constexpr (RM == 1) {              // (gathered rows only: see above)
+                        if constexpr (GRAD) {
+                            asm volatile("" : "+v"(gl[4 * h]), "+v"(gl[4 * h + 1]), "+v"(gl[4 * h + 2]), "+v"(gl[4 * h + 3]), "+v"(dgs), "+v"(pr0), "+v"(pr1));
+                        } else {
+                            asm volatile("" : "+v"(pr0), "+v"(pr1));
+                        }
                     }
                 }
                 // Out of [eps32, 1 - eps32] anywhere in the wave's tile?  (The extrema, not the products: a product of four below
@@ -1059,7 +1081,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                         vq[k4] = med3(v, kEps32, 1.0f - kEps32);
                         if constexpr (GRAD) {
                             const bool keep = vq[k4] == v;
-                            gl[k] = keep ? wc[k] * (rtk - (right ? rnk : 1.0f)) : 0.f;
+                            gl[k] = keep ? wc[k] * fmaf(nk, iq, -(right ? rnk : 1.0f)) : 0.f;
                             dgs = fmaf(keep ? sel : 0.f, rnk, dgs);
                         }
                     }
@@ -1155,6 +1177,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         put_counts(pk, true);
         asm volatile("" : "+v"(epn));                 // (in before the loop: no wait on it behind the loop's own loads)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
+        if constexpr (XCOND && kPrs) asm volatile("" : "+v"(prc));
     }
     int par = 0;                                      // parity of the workgroup's batch counter: LDS double buffers, slot owners
     // item operands of the first two tiles' logits (every batch reads the same image: carried across the back edge)
@@ -1242,6 +1265,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         pack_half(nxt, 1, cwB0, cwB1, pk);
         asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
+        if constexpr (XCOND && kPrs) asm volatile("" : "+v"(prc));
         if constexpr (RM != 0) {                      // (nor the row numbers: they were requested before this batch's rows)
 #pragma unroll
             for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(ridx_n[k]));
