@@ -190,7 +190,8 @@ static int narrow_blocks(int num_cu, const vibo_desc* d) {
     // a workgroup = 4 waves = one per SIMD; workgroups per CU = the waves per SIMD the instantiation is compiled for
     // (narrow_waves_per_simd in vibo_narrow.hip); under 1024 records so that the fused train epilogue can finalize them
     const int il = d->num_item <= 64 ? 4 : 8, at = d->ability_dim <= 1 ? 1 : d->ability_dim <= 2 ? 2 : 4;
-    const int wps = at == 1 ? 4 : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2);
+    const bool g3 = d->irt_model == 3 && d->want_grad;
+    const int wps = at == 1 ? ((g3 && il == 8) ? 3 : 4) : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2);      // (narrow_waves_per_simd)
     long long nblk = (long long)num_cu * wps;
     if (nblk > 1020) nblk = 1020;
     const long long need = (d->num_person + 15) / 16;          // 4 rows per wave and round

@@ -56,7 +56,10 @@ constexpr int kNwWaves = 4;            // waves per workgroup (they only meet in
 constexpr int kNwPass = VIBO_NW_PASS;  // passes (of 4 rows) per loop iteration = rows in flight per wave / 4
 
 // waves per SIMD each instantiation is compiled for (registers: items x (parameters + gradient accumulators) + one unit of rows)
-constexpr int narrow_waves_per_simd(int at, int il) { return at == 1 ? 4 : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2); }
+// (3PL with gradients at 8 items per lane: 128 registers were 4-12 short -- spilled, and a spill reload waits behind the row loads)
+constexpr int narrow_waves_per_simd(int at, int il, bool g3 = false) {
+    return at == 1 ? ((g3 && il == 8) ? 3 : 4) : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2);
+}
 
 struct alignas(16) NarrowLds {
     float red[kNwWaves][8];
@@ -67,7 +70,7 @@ struct alignas(16) NarrowLds {
 // AT: template ability width (1, 2, 4; runtime p.A <= AT).  IL: items per lane (4: I <= 64, 8: I <= 128).
 // RM: 0 fp32 rows in order, 1 fp32 rows through p.row_index, 2 cell codes (through p.mask), with or without p.row_index.
 template <int AT, int IRT, bool GRAD, int RM, int IL>
-__global__ __launch_bounds__(64 * kNwWaves, narrow_waves_per_simd(AT, IL)) void narrow_kernel(const ElboParams p) {
+__global__ __launch_bounds__(64 * kNwWaves, narrow_waves_per_simd(AT, IL, IRT == 3 && GRAD)) void narrow_kernel(const ElboParams p) {
     constexpr bool CODES = RM == 2;
     constexpr int NC = IL / 4;                     // 16-byte chunks per lane and row
     constexpr float kLoS = kLogitLo * kLog2e, kHiS = kLogitHi * kLog2e;
