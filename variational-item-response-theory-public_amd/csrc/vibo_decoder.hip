@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
                     opart = fmaf(w3v[4 * nt + j], h2[4 * nt + j], opart);
                 }
             }
-            opart += __shfl_xor(opart, 16);
-            opart += __shfl_xor(opart, 32);
+            opart = xor16_add(opart);
+            opart = xor32_add(opart);
             float o = opart + b3;
             if constexpr (HASL) o = fmaf(p.resid, l, o);
             // ---- link + masked Bernoulli log-likelihood (utils.py:46-49) ----
@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
                     dl = fmaf(w1v[a], dz1[a], dl);
                     dw1[a] = fmaf(dz1[a], lgt[r], dw1[a]);
                 }
-                dl += __shfl_xor(dl, 16);
-                dl += __shfl_xor(dl, 32);
+                dl = xor16_add(dl);
+                dl = xor32_add(dl);
                 dl = fmaf(p.resid, dov[r], dl);
                 if (g == 0 && item_ok && pr < p_end) p.dL[pr * (long long)p.I + item] = dl;
             }

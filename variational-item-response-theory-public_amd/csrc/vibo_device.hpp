@@ -40,6 +40,24 @@ __device__ __forceinline__ int dpp_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
 
+// v + (the value of the lane 16 / 32 away) through v_permlane16_swap / v_permlane32_swap (gfx950): VALU instructions, where
+// `v += __shfl_xor(v, 16)` compiles to a ds_bpermute -- an LDS round trip and an s_waitcnt lgkmcnt in the middle of the stream.
+// The instruction swaps the odd rows (upper half) of its first operand with the even rows (lower half) of its second: with two
+// copies of v going in, the two registers coming out hold "own" and "partner" in one order or the other -- the same two addends
+// as the shuffle form, the same bits (checked lane by lane on the hardware).  Inline asm: hipcc 7.2's
+// __builtin_amdgcn_permlane16_swap hands back the FIRST result register twice.  (s_nop: the copies are fresh VALU results, and
+// the compiler does not see which instruction reads them.)
+__device__ __forceinline__ float xor16_add(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float xor32_add(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (read lane 63).
 __device__ __forceinline__ float wave_sum63(float v) {
     v += dpp_f<0xb1>(v);         // quad_perm [1,0,3,2]

@@ -770,8 +770,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 // the slot's 8 persons (lanes 8 apart) -> lanes 0..7, then one running sum per (slot, set, kind, dim)
                 auto fold = [&](float v, float* dst) {
                     v += dpp_f<0x128>(v);               // row_ror 8
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
+                    v = xor16_add(v);
+                    v = xor32_add(v);
                     if (lane < 8) lds_add(dst, v);
                 };
                 fold(f00, &fl.facc[par][sl][0][f][0][ed]); fold(f01, &fl.facc[par][sl][0][f][1][ed]); fold(f02, &fl.facc[par][sl][0][f][2][ed]);
