@@ -1365,13 +1365,13 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
                 // d LL/d b (and d/d guess-logit): the lane's 8 persons per batch -> sum over the 4 lane groups
                 float b = acc_b[u][t];
-                b += __shfl_xor(b, 16);
-                b += __shfl_xor(b, 32);
+                b = xor16_add(b);
+                b = xor32_add(b);
                 if (g_e == 0) stage[brow * kStage + 64 * u + 4 * i16_e + t] = b;
                 if constexpr (IRT == 3) {
                     float gg = acc_g[u][t];
-                    gg += __shfl_xor(gg, 16);
-                    gg += __shfl_xor(gg, 32);
+                    gg = xor16_add(gg);
+                    gg = xor32_add(gg);
                     // (the tiles summed d ll / d guess; the parameter is the guess logit: x guess (1 - guess), models.py:758)
                     const float gs_e = gsl[(u * 4 + t) * 16 + i16_e];
                     if (g_e == 0) stage[(A + 1) * kStage + 64 * u + 4 * i16_e + t] = gg * (gs_e * (1.0f - gs_e));
