@@ -169,7 +169,7 @@ def fuzz_trainer():
     import copy
     from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
     from vibo_amd.trainer import FusedTrainer
-    t0, n, worst = time.time(), 0, 0.0
+    t0, n, worst, n_band = time.time(), 0, 0.0, 0
     while time.time() - t0 < a.seconds:
         irt = rng.choice([1, 2, 2, 3])
         A = rng.choice([1, 2, 3, 5, 8])
@@ -193,6 +193,19 @@ def fuzz_trainer():
                 ref.item_encoder.mu_lookup.weight.mul_(0.5 if A <= 3 else 0.25)      # (the logit's spread grows with sqrt(A): seed 777 found
                 #  3PL, 8 dims, 256 items at 1.2 % of the encoder's first moment with 0.5 -- tests/test_gpu_trainer.py notes the same band)
         fus = copy.deepcopy(ref)
+        # 3PL: cells of the first step whose probability (float64, from the module's own samples) sits within a few fp32 ulps of
+        # the clamp bound 1 - eps32 -- where a 1-ulp difference of the item sample decides whether the cell's O(1) gradient
+        # counts.  A report with band == 0 is a real discrepancy; with band > 0 it is that class.
+        band = 0
+        if irt == 3:
+            torch.manual_seed(100)
+            with torch.no_grad():
+                out0 = ref.forward(resp, mask, row_index=rows)
+            pr = O.irt_link(3, out0[3].double().cpu(), out0[6].double().cpu())
+            mk = ((mask[rows] if rows is not None else mask)[:, :pr.shape[1]] != 0).cpu()
+            e32 = 1.1920929e-07
+            band = int(((pr > 1.0 - 5 * e32) & mk).sum()) + int(((pr < 5 * e32) & mk).sum())
+            n_band += band > 0
         opt = torch.optim.Adam(ref.parameters(), lr=lr)
         trainer = FusedTrainer(fus, lr=lr)
         for step in range(3):
@@ -217,7 +230,7 @@ def fuzz_trainer():
                     em = float((x - y).abs().max()) / max(1e-1, float(y.abs().max()))     # (0.1 g; vanishing gradients: absolute floor)
                     worst = max(worst, em)
                     if not em < 1e-4:
-                        print(f'FAIL trainer {name} irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed}: {em}')
+                        print(f'FAIL trainer {name} irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed}: {em}  (cells in the clamp band: {band})')
                         sys.exit(1)
             if not e < (5e-5 if step == 0 else 3e-2):
                 print(f'FAIL trainer loss irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed} step={step}: {e}')
@@ -228,7 +241,7 @@ def fuzz_trainer():
                 print(f'FAIL trainer param {k} irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed}: {e}')
                 sys.exit(1)
         n += 1
-    print(f'fuzz trainer ok: {n} random configurations, worst error {worst:.2e}')
+    print(f'fuzz trainer ok: {n} random configurations, worst error {worst:.2e} ({n_band} of them 3PL with cells in the clamp band)')
 
 
 if a.target == 'multi':
