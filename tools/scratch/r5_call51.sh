@@ -1,0 +1,10 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
+{
+for a in "--persons 1000000 --items 1000 --ability-dim 8" \
+         "--persons 1000000 --items 1000 --ability-dim 8 --codes" \
+         "--persons 125000 --items 1000 --ability-dim 8"; do
+  timeout 600 bash tools/ab_libs.sh "$a" cur ont
+done
+} > $O/r5_ab51.txt 2>&1
+cat $O/r5_ab51.txt

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
                 m[u] = 0u;
                 keep[u] = 0u;
                 if (c < n4) {
-                    if (!cell_codes) x[u] = rp[c];
+                    if (!cell_codes) x[u] = nt_load4(rp + c);       // (streamed once: see nt_load4)
                     m[u] = (mask_dtype == 0 || cell_codes) ? mp[c] : 0x01010101u;
                     keep[u] = ((I & 3) && c == (I >> 2)) ? (1u << (8 * (I & 3))) - 1u : 0xFFFFFFFFu;      // padded tail of the row
                 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void load_rows(const CondParams& p, const long long b
         rb.m[r] = CODES ? kAllMissing4 : 0u;
         if (row < p.B && chunk_ok) {
             const long long src = p.row_index ? p.row_index[row] : row;
-            if constexpr (!CODES) rb.x[r] = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0)[chunk];
+            if constexpr (!CODES) rb.x[r] = nt_load4(reinterpret_cast<const float4*>(p.response + src * p.resp_stride + p.item0) + chunk);
             if (CODES || p.mask_dtype == 0)
                 rb.m[r] = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + p.item0)[chunk];
             else
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256, CODES ? 3 : 2) void cond_pre_kernel(const Cond
             const uint32_t cw = row_word(rb, r, tail_mask, nobs);
             if constexpr (!CODES) {          // leave the row behind as cell codes for the passes that follow (1 B/cell instead of 5)
                 if (p.codes_out && chunk_ok && row0 + r < p.B)
-                    reinterpret_cast<uint32_t*>(p.codes_out + (row0 + r) * p.codes_stride + p.item0)[chunk] =
-                        cell_codes4(rb.x[r], rb.m[r] & tail_mask);
+                    nt_store1(reinterpret_cast<uint32_t*>(p.codes_out + (row0 + r) * p.codes_stride + p.item0) + chunk,
+                              cell_codes4(rb.x[r], rb.m[r] & tail_mask));
             }
             float wp[4], wn[4];                                              // [correct], [wrong]
             word_indicators<CODES>(cw, tail_mask, wp, wn, nobs);

@@ -40,6 +40,18 @@ __device__ __forceinline__ int dpp_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
 
+// Streaming accesses (every byte touched once by one lane: the conditional posterior's pre pass, the row-count pass): the
+// non-temporal hint keeps them from displacing what the next kernel wants in L2 / MALL: cond_pre -2 %, the row-count pass -8 %.
+// (NOT for the matrix kernel's row loads -- neighbouring waves share the cache lines at the edges of their 512-byte segments:
+// +4..8 % with the hint -- nor for cm_forward_fp32, where four lanes share a row's 256 bytes: +30 %; the narrow-row kernel: +-1 %.)
+typedef float vibo_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const vibo_f4v t = __builtin_nontemporal_load(reinterpret_cast<const vibo_f4v*>(p));
+    return float4{t[0], t[1], t[2], t[3]};
+}
+__device__ __forceinline__ uint32_t nt_load1(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void nt_store1(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 // v + (the value of the lane 16 / 32 away) through v_permlane16_swap / v_permlane32_swap (gfx950): VALU instructions, where
 // `v += __shfl_xor(v, 16)` compiles to a ds_bpermute -- an LDS round trip and an s_waitcnt lgkmcnt in the middle of the stream.
 // The instruction swaps the odd rows (upper half) of its first operand with the even rows (lower half) of its second: with two

@@ -671,9 +671,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if (live && primary) {
             const long long o = (long long)(row0 + pp) * A + ed;
             const float alv = -kLn2 * fast_log2(lam);
-            p.ability_mu[o] = amu;
-            p.ability_logvar[o] = alv;
-            p.ability[o] = th0;
+            // (non-temporal: 96 MB of per-person outputs per 1M x 8 launch that nothing on the device reads back soon -- kept out
+            //  of the L2 the row loads share their segment-edge lines through: -0.9 % on the headline call)
+            __builtin_nontemporal_store(amu, p.ability_mu + o);
+            __builtin_nontemporal_store(alv, p.ability_logvar + o);
+            __builtin_nontemporal_store(th0, p.ability + o);
             if constexpr (FLOWS) {
                 p.ability_k[o] = thv;
                 if (ed == 0) {
