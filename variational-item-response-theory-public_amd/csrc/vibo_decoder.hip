@@ -294,6 +294,10 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(const DecParams p) {
                     v += dpp_f<0x4e>(v);         // quad_perm [2,3,0,1]
                     v += dpp_f<0x141>(v);        // row_half_mirror
                     v += dpp_f<0x140>(v);        // row_mirror
+                    // (kept scalar: left to the SLP vectoriser the sixteen chains became v_pk_add_f32 pairs, which cannot take a
+                    //  DPP operand -- two zero moves + two v_mov_dpp + one packed add per pair and step, 320 instructions of the
+                    //  loop's 1 680, instead of two v_add_f32_dpp)
+                    asm volatile("" : "+v"(v));
                     dz1[a] = v;
                 }
                 if (i16 == 0 && pr < p_end) {
