@@ -144,3 +144,37 @@ def test_planner_thresholds_agree_with_the_committed_calibration_tables():
     import check_planner_table
     bad, n = check_planner_table.check(tol=0.15, verbose=False)
     assert n >= 70 and not bad, bad
+
+
+def test_matrix_kernel_instantiations_carry_no_scratch():
+    """Every instantiation of the matrix row-split kernel (and the narrow-row kernel) is built without spilled registers or private
+    memory: a spill reload in the batch loop is a scratch load + s_waitcnt vmcnt(0) that also drains the row prefetch (DESIGN 8.2:
+    it cost the wide 3PL + flows instantiation 30 %).  Read from the code-object notes of the in-tree objects (tools/kernel_regs.sh
+    does the same by hand); skipped when the build directory or the LLVM tools are not there."""
+    import glob
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    bdir = os.path.join(root, 'variational-item-response-theory-public_amd', 'csrc', 'build')
+    llvm = '/opt/rocm/lib/llvm/bin'
+    objs = sorted(glob.glob(os.path.join(bdir, 'vibo_msplit_*.o'))) + sorted(glob.glob(os.path.join(bdir, 'vibo_narrow.o')))
+    if not objs or not os.path.exists(os.path.join(llvm, 'llvm-readelf')):
+        pytest.skip('no in-tree objects / LLVM tools')
+    seen = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            fat, co = os.path.join(tmp, 'fat.bin'), os.path.join(tmp, 'dev.co')
+            subprocess.run([os.path.join(llvm, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fat, o], check=True)
+            subprocess.run([os.path.join(llvm, 'clang-offload-bundler'), '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                            '--input=' + fat, '--output=' + co, '--unbundle'], check=True)
+            notes = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes', co], check=True, capture_output=True, text=True).stdout
+            for blk in notes.split('  - .agpr_count:')[1:]:
+                name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+                if 'msplit_kernel' not in name and 'narrow_kernel' not in name:
+                    continue
+                spill = int(re.search(r'\.vgpr_spill_count:\s+(\d+)', blk).group(1))
+                scratch = int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk).group(1))
+                assert spill == 0 and scratch == 0, (os.path.basename(o), name, spill, scratch)
+                seen += 1
+    assert seen >= 216
