@@ -68,6 +68,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--blocks', type=int, default=5, help='the timed region is run this many times back to back, each exactly --steps steps between barrier + synchronize pairs; value / ms_per_step = the MEDIAN block, all of them listed (ms_per_step_blocks)')
     ap.add_argument('--persons', type=int, default=1_000_000, help='persons of the whole matrix (--scaling strong) / per GPU (--scaling weak)')
     ap.add_argument('--items', type=int, default=1000)
     ap.add_argument('--ability-dim', type=int, default=8)
@@ -271,6 +272,12 @@ def main():
             from vibo_amd.trainer import FusedTrainer
             trainer = FusedTrainer(model, lr=args.lr, rng=args.rng, seed=args.seed)
 
+        # in-situ timer: the matrix kernel stamps its own entry / exit (100 MHz chip-wide clock) inside whatever it runs in --
+        # the replayed graphs of the timed region included (ops.InsituTimer, vibo_set_insitu_timer); armed before the captures
+        # so that the captured launches carry the block's address
+        insitu_tm = ops.InsituTimer(dev) if trainer is not None else None
+        if insitu_tm is not None:
+            insitu_tm.arm()
         # HIP events around the native call, on the stream it is launched on
         events = []
         native = ops._BACKEND['elbo']
@@ -355,6 +362,7 @@ def main():
                             raise
                         print(f'[bench] capturing the collective failed ({type(exc).__name__}: {exc}); eager all-reduce between two graphs', file=sys.stderr)
                         torch.cuda.synchronize()
+                        trainer.invalidate()        # (the aborted capture ran forward_backward() on the host: forget the half-open step)
                         eager_collective = True
                         forms = None
                         g = torch.cuda.CUDAGraph()
@@ -378,6 +386,8 @@ def main():
                 graph = None
                 step = eager_step
                 torch.cuda.synchronize()
+                if trainer is not None:
+                    trainer.invalidate()
 
         for _ in range(args.warmup):
             loss = step()
@@ -397,23 +407,53 @@ def main():
             if dist is not None:
                 dist.broadcast(pick, 0)
             step, launch_mode = forms['one' if int(pick) == 0 else 'two']
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        # The timed region, `--blocks` times back to back: each block is exactly --steps steps between barrier + synchronize
+        # pairs (max over ranks); the line's value / ms_per_step are the MEDIAN block, every block is listed.  (One block of
+        # 20 steps is an 18 ms sample: round 5's three clocks disagreed by more than the margin they were quoted with.)
         recording['on'] = graph is None
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        block_dt, block_kern = [], []
+        for blk in range(max(1, args.blocks)):
+            if insitu_tm is not None:
+                insitu_tm.reset()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dtb], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtb = float(t)
+            block_dt.append(dtb)
+            if insitu_tm is not None:
+                block_kern.append(insitu_tm.read())
         recording['on'] = False
-        if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t)
+        order = sorted(range(len(block_dt)), key=lambda k: block_dt[k])
+        med = order[len(order) // 2]
+        dt = block_dt[med]
+        # the kernel inside the timed steps, by its own clock: mean over all launches of all blocks (+ the median block's own)
+        insitu = None
+        if block_kern and all(b.get('launches', 0) == args.steps for b in block_kern):
+            means = [b['mean_ms'] for b in block_kern]
+            insitu = {'mean_ms': sum(means) / len(means), 'median_block_mean_ms': block_kern[med]['mean_ms'],
+                      'min_ms': min(b['min_ms'] for b in block_kern), 'max_ms': max(b['max_ms'] for b in block_kern),
+                      'launches': sum(b['launches'] for b in block_kern), 'per_block_mean_ms': means,
+                      'note': 'the fused kernel timed by itself INSIDE the timed region\'s replayed steps: earliest workgroup entry to latest '
+                              'workgroup exit on the chip-wide 100 MHz clock (s_memrealtime), two device-scope atomics per workgroup, no events, '
+                              'no tracer (csrc/vibo_device.hpp: insitu_enter / insitu_exit)'}
+            if dist is not None:
+                ph = torch.tensor([insitu['mean_ms'], insitu['median_block_mean_ms']], device=dev, dtype=torch.float64)
+                dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+                insitu['mean_ms'], insitu['median_block_mean_ms'] = float(ph[0]), float(ph[1])
+                insitu['note'] += '; mean = max over ranks'
+        blocks_info = {'blocks': len(block_dt), 'ms_per_step': [b / args.steps * 1e3 for b in block_dt],
+                       'median': dt / args.steps * 1e3, 'min': min(block_dt) / args.steps * 1e3, 'max': max(block_dt) / args.steps * 1e3}
         final_loss = float(loss.detach())
 
         bare_ms, instep, phase_ms = None, None, None
@@ -493,6 +533,11 @@ def main():
                 kern_ms = max(kern_ms, bare_ms)
         if instep is not None:
             kern_ms = instep['mean_ms']
+        events_ms = kern_ms
+        if insitu is not None:
+            kern_ms = insitu['mean_ms']
+        if insitu_tm is not None:
+            insitu_tm.disarm()
         bytes_per_term = 5.0 + 12.0 * A / I
         achieved = bytes_per_term * P * I / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         ops._BACKEND['elbo'] = native
@@ -504,7 +549,8 @@ def main():
         del resp, mask, model, opt, trainer
         torch.cuda.empty_cache()
         return dict(dt=dt, kern_ms=kern_ms, final_loss=final_loss, graph=graph is not None, rel=rel, sweep=sweep,
-                    launch=launch_mode if graph is not None else 'eager', phase_ms=phase_ms, bare_ms=bare_ms, instep=instep, form_probe=form_probe)
+                    launch=launch_mode if graph is not None else 'eager', phase_ms=phase_ms, bare_ms=bare_ms, instep=instep, form_probe=form_probe,
+                    insitu=insitu, events_ms=events_ms, blocks=blocks_info)
 
     def elbo_rel_err(model, resp, mask, A, n=4096):
         """ELBO of the same parameters, rows and noise: HIP step vs the CPU restatement of the reference (fp32 and fp64).
@@ -729,6 +775,7 @@ def main():
         b2 = 5.0 + 12.0 * A2 / I
         also = {'workload': f'same, ability_dim={A2} (BASELINE configs[1] shape at 1M persons)',
                 'value': total_persons * I * args.steps / m2['dt'], 'ms_per_step': m2['dt'] / args.steps * 1e3,
+                'ms_per_step_blocks': m2.get('blocks'), 'kernel_ms_events': m2.get('events_ms'),
                 'kernel_ms': m2['kern_ms'], 'roofline_achieved_GBps': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9,
                 'roofline_frac': b2 * P * I / (m2['kern_ms'] * 1e-3) / 1e9 / 8000.0,
                 'roofline_frac_step': b2 * total_persons * I * args.steps / m2['dt'] / 1e9 / 8000.0 / world,
@@ -747,7 +794,10 @@ def main():
         bc = 5.0 + 12.0 * 1 / I
         also_config2 = {'workload': f'BASELINE configs[1]: {args.irt_model.upper()} simulation, {Pc2} persons x {I} items, ability_dim=1, {args.missing:.0%} missing, one GPU, full-matrix minibatch',
                         'value': float(Pc2) * I * args.steps / mc['dt'], 'unit': 'terms/s', 'ms_per_step': mc['dt'] / args.steps * 1e3,
-                        'kernel_ms': mc['kern_ms'], 'kernel_timing': mc.get('instep'), 'bare_launch_ms': mc.get('bare_ms'),
+                        'ms_per_step_blocks': mc.get('blocks'),
+                        'kernel_ms': mc['kern_ms'], 'kernel_ms_insitu': mc['insitu']['mean_ms'] if mc.get('insitu') else None,
+                        'kernel_ms_events': mc.get('events_ms'), 'kernel_timing_insitu': mc.get('insitu'),
+                        'kernel_timing': mc.get('instep'), 'bare_launch_ms': mc.get('bare_ms'),
                         'bytes_per_term': bc, 'launch': mc['launch'],
                         'roofline_achieved_GBps': bc * Pc2 * I / (mc['kern_ms'] * 1e-3) / 1e9,
                         'roofline_frac': bc * Pc2 * I / (mc['kern_ms'] * 1e-3) / 1e9 / 8000.0,
@@ -778,11 +828,24 @@ def main():
         format_p['traffic'], _ = parse_traffic(f'ILi{irt}ELb{0 if args.eval_only else 1}ELi2ELb0E')
     if rank == 0:
         terms = total_persons * I * args.steps
+        frac_note = ''
+        if m.get('insitu'):
+            frac_note += ('frac = algorithmic bytes / kernel_ms_insitu: the fused kernel\'s mean duration over every launch of the timed region\'s '
+                          'blocks, stamped by the kernel itself (earliest workgroup entry -> latest workgroup exit on the chip-wide 100 MHz clock; '
+                          'kernel_timing_insitu).  kernel_ms_events = the estimate of rounds 4-5, kept beside it: ')
+        if m.get('instep'):
+            frac_note += ('the fused call\'s mean duration in the step captured as its two halves and replayed back to back right after the timed '
+                          'region, HIP events on the launch stream around the first (an upper bound: the event packets cost a few us; kernel_timing '
+                          'has mean / min / max' + (', mean = max over ranks' if world > 1 else '') + '); ')
+        elif not m.get('insitu'):
+            frac_note += 'frac = algorithmic bytes / mean duration of the fused call by HIP events on its stream (eager pass after the timed region); '
+        frac_note += ('bare_launch_ms = the same call in a loop of bare eager launches (a note, not the claim); frac_step = the same bytes / ms_per_step '
+                      f'(median block); the rocprofv3 kernel-trace average of the same command is in profiles/{PROFILE_FILE}')
         line = {
             'metric': 'person x item ELBO terms/sec (train step: fwd + bwd + all-reduce + Adam)'
                       if not args.eval_only else 'person x item ELBO terms/sec (forward ELBO only)',
             'value': terms / dt, 'unit': 'terms/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
+            'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_blocks': m.get('blocks'), 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32 (the three ability-wide contractions of the matrix kernel: 3-pass f16 hi/lo MFMA products, ~22-bit, fp32 accumulate; everything else fp32)',
             'data': 'synthetic',
@@ -798,14 +861,10 @@ def main():
                          'frac': achieved / 8000.0, 'frac_of_measured_copy_peak': achieved / 6290.0,
                          # the same bytes over the whole timed step (kernel with its prologue, [finalize, all-reduce], epilogue + Adam + noise)
                          'frac_step': bytes_per_term * P * I / (dt / args.steps) / 1e9 / 8000.0,
-                         'frac_note': ('frac = algorithmic bytes / the fused call\'s mean duration INSIDE the replayed step: the step captured as its two '
-                                       'halves and replayed back to back right after the timed region, HIP events on the launch stream around the first '
-                                       '(an upper bound: the event packets cost a few us; kernel_timing has mean / min / max'
-                                       + (', mean = max over ranks' if world > 1 else '') + '); '
-                                       if m.get('instep') else
-                                       'frac = algorithmic bytes / mean duration of the fused call by HIP events on its stream (eager pass after the timed region); ')
-                                      + 'bare_launch_ms = the same call in a loop of bare eager launches (a note, not the claim); frac_step = the same '
-                                        f'bytes / ms_per_step; the rocprofv3 kernel-trace average of the same command is in profiles/{PROFILE_FILE}',
+                         'kernel_ms_insitu': m['insitu']['mean_ms'] if m.get('insitu') else None,
+                         'kernel_ms_events': m.get('events_ms'),
+                         'kernel_timing_insitu': m.get('insitu'),
+                         'frac_note': frac_note,
                          'traffic': traffic, 'traffic_note': traffic_note,
                          'kernel': 'vibo::msplit_kernel (its own prologue forms the item sample and the encoder table)' + (' + the finalize helper' if world > 1 else ''),
                          'kernel_ms': kern_ms, 'kernel_timing': m.get('instep'), 'bare_launch_ms': m.get('bare_ms'),

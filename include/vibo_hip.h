@@ -121,6 +121,27 @@ int vibo_version(void);
 /* Message for the last non-zero return on this thread (host pointer, static storage). */
 const char* vibo_last_error_string(void);
 
+/*
+ * Measurement hook: the fused kernel's own duration, measured by the kernel (no reference counterpart; bench.py's
+ * `roofline.kernel_ms_insitu`).  HIP events cannot be recorded inside a replayed hipGraph and a tracer changes what it traces;
+ * with a timer block set, every matrix row-split launch (VIBO_KERNEL_MATRIX) enqueued FROM THIS HOST THREAD afterwards -- eagerly
+ * or while a stream capture records it into a graph -- stamps its earliest workgroup entry and its latest workgroup exit on the
+ * chip-wide 100 MHz clock (s_memrealtime) and the last workgroup to leave adds the difference to the block:
+ *   block[3] sum of the launches' durations | block[4] launches | block[5] shortest | block[6] longest | block[7] the last one
+ *   (ticks of 10 ns; block[0..2] are the launch in flight).  `block` = 8 uint64 of device memory the caller owns, armed by
+ * vibo_insitu_timer_reset (two byte-fills on `stream`) and read back by the caller after synchronising.  NULL switches the hook off
+ * (the default).  The pointer is thread-local host state -- the library's only one besides the error string; the data path never
+ * reads it.  Cost: two device-scope atomics per workgroup and launch.  Launches that share a block must not overlap in time.
+ */
+int vibo_set_insitu_timer(uint64_t* block);
+int vibo_insitu_timer_reset(uint64_t* block, void* stream);
+
+/* Self-test of the kernels' cross-row sums (csrc/vibo_device.hpp: xor16_add / xor32_add = v_permlane16_swap / v_permlane32_swap
+ * through inline asm) against the __shfl_xor form they replace: `in` = 64 floats (one per lane of a wave), `out` = 6 x 64 floats:
+ * [0] swap form of v + v[lane ^ 16], [1] of v + v[lane ^ 32], [2] [3] the same two sums by __shfl_xor, [4] the chained swap form
+ * (16 then 32) as the kernels use it, [5] the chained shuffle form.  Rows 0/2, 1/3 and 4/5 must agree bit for bit. */
+int vibo_selftest_lane_swaps(const float* in, float* out, void* stream);
+
 /* Workspace bytes vibo_elbo_fwd_bwd / vibo_encode need for `d` (0 on bad desc). */
 size_t vibo_workspace_bytes(const vibo_desc* d);
 

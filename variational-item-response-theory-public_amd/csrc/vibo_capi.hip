@@ -21,6 +21,8 @@
 namespace vibo {
 
 static thread_local char g_err[512] = "";
+// measurement hook (vibo_set_insitu_timer): the timer block the matrix row-split launches of THIS host thread stamp; null = none
+static thread_local unsigned long long* g_insitu = nullptr;
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -191,7 +193,7 @@ static int narrow_blocks(int num_cu, const vibo_desc* d) {
     // (narrow_waves_per_simd in vibo_narrow.hip); under 1024 records so that the fused train epilogue can finalize them
     const int il = d->num_item <= 64 ? 4 : 8, at = d->ability_dim <= 1 ? 1 : d->ability_dim <= 2 ? 2 : 4;
     const bool g3 = d->irt_model == 3 && d->want_grad;
-    const int wps = at == 1 ? ((g3 && il == 8) ? 3 : 4) : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2);      // (narrow_waves_per_simd)
+    const int wps = narrow_waves_per_simd(at, il, g3);      // (vibo_launch.hpp: the kernel's launch bounds use the same function)
     long long nblk = (long long)num_cu * wps;
     if (nblk > 1020) nblk = 1020;
     const long long need = (d->num_person + 15) / 16;          // 4 rows per wave and round
@@ -903,6 +905,20 @@ __global__ __launch_bounds__(256) void decode_mean_kernel_strided(const float* _
 
 using namespace vibo;
 
+// xor16_add / xor32_add (v_permlane16_swap / v_permlane32_swap through inline asm, vibo_device.hpp) next to the __shfl_xor form
+// they replace: out[0][lane] | out[1][lane] = the swap forms, out[2] | out[3] = the shuffle forms (tests/test_gpu_parity.py)
+__global__ void lane_swap_selftest_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const float v = in[lane];
+    out[lane] = xor16_add(v);
+    out[64 + lane] = xor32_add(v);
+    out[128 + lane] = v + __shfl_xor(v, 16);
+    out[192 + lane] = v + __shfl_xor(v, 32);
+    // chained, as the kernels use them (the second swap reads the first one's fresh result)
+    out[256 + lane] = xor32_add(xor16_add(v));
+    out[320 + lane] = [&] { const float t = v + __shfl_xor(v, 16); return t + __shfl_xor(t, 32); }();
+}
+
 extern "C" {
 
 int vibo_version(void) { return VIBO_ABI_VERSION; }
@@ -930,6 +946,29 @@ int vibo_plan_kernel(const vibo_desc* d) {
 }
 
 const char* vibo_last_error_string(void) { return g_err; }
+
+int vibo_selftest_lane_swaps(const float* in, float* out, void* stream) {
+    if (!in || !out) return fail(-5, "null required pointer");
+    hipLaunchKernelGGL(lane_swap_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "lane swap selftest launch");
+    return 0;
+}
+
+int vibo_set_insitu_timer(uint64_t* block) {
+    if ((uintptr_t)block & 7) return fail(-5, "vibo_set_insitu_timer: the block must be 8-byte aligned");
+    g_insitu = reinterpret_cast<unsigned long long*>(block);
+    return 0;
+}
+int vibo_insitu_timer_reset(uint64_t* block, void* stream) {
+    if (!block || ((uintptr_t)block & 7)) return fail(-5, "vibo_insitu_timer_reset: null / unaligned block");
+    // words 0 (earliest entry) and 5 (shortest launch) start at all-ones, the rest at zero: two byte-fills, no kernel
+    hipError_t e = hipMemsetAsync(block, 0, 8 * sizeof(uint64_t), (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemsetAsync(block, 0xff, sizeof(uint64_t), (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemsetAsync(block + 5, 0xff, sizeof(uint64_t), (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "insitu timer reset");
+    return 0;
+}
 
 size_t vibo_workspace_bytes(const vibo_desc* d) {
     if (check_desc(d) != 0) return 0;
@@ -1031,6 +1070,7 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
     p.vec_ok = (vec && I % 4 == 0) ? 1 : 0;      // the tiled / wave-per-row kernels' vector loads assume whole chunks
     p.row_cnt = nullptr; p.item0 = 0; p.I_total = I; p.primary = 1;
     p.step_tick = step_count;
+    p.insitu = g_insitu;
 
     const bool grad = d->want_grad != 0;
     int nblk_used = pl.nblk;

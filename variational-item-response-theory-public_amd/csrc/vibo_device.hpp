@@ -59,6 +59,11 @@ __device__ __forceinline__ void nt_store1(uint32_t* p, uint32_t v) { __builtin_n
 // as the shuffle form, the same bits (checked lane by lane on the hardware).  Inline asm: hipcc 7.2's
 // __builtin_amdgcn_permlane16_swap hands back the FIRST result register twice.  (s_nop: the copies are fresh VALU results, and
 // the compiler does not see which instruction reads them.)
+// (gfx950 only: the swap instructions do not exist elsewhere, and the hazard argument above was checked on this target --
+//  tests/test_gpu_parity.py::test_lane_swap_sums_equal_the_shuffle_form compares both forms lane by lane on the hardware)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "vibo_device.hpp: v_permlane16/32_swap (xor16_add / xor32_add) are gfx950 instructions -- build with --offload-arch=gfx950"
+#endif
 __device__ __forceinline__ float xor16_add(float v) {
     float a = v, b = v;
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -68,6 +73,43 @@ __device__ __forceinline__ float xor32_add(float v) {
     float a = v, b = v;
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
+}
+
+// In-situ launch timer (vibo_set_insitu_timer, include/vibo_hip.h): the kernel's own duration measured by the kernel, inside whatever
+// it runs in -- a replayed hipGraph, where HIP events cannot be recorded, no tracer attached.  Eight 64-bit words of device memory:
+//   0 earliest workgroup entry of the launch in flight | 1 latest workgroup exit | 2 workgroups that have left
+//   3 sum of the launches' durations | 4 launches | 5 shortest | 6 longest | 7 the last launch's      (ticks of the 100 MHz
+//   s_memrealtime clock, the same on every XCD)
+// Every access is a relaxed device-scope atomic (performed at the memory side, past the per-XCD L2s), ordered by their round
+// trips -- a workgroup's exit stamp has RETURNED before its ticket goes out -- instead of release / acquire fences, which write
+// back and invalidate whole L2s on eight XCDs.  The workgroup that draws the last ticket closes the launch: it adds exit - entry
+// to the sums and re-arms words 0..2.  Cost with a timer: two atomics per workgroup; without one (null pointer): a scalar test.
+constexpr unsigned long long kInsituIdle = ~0ull;
+__device__ __forceinline__ unsigned long long realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void insitu_enter(unsigned long long* t) {
+    if (t != nullptr && threadIdx.x == 0) atomicMin(&t[0], realtime_ticks());
+}
+// call once per workgroup, from all its threads, after the workgroup's last global store was issued
+__device__ __forceinline__ void insitu_exit(unsigned long long* t, const unsigned n_workgroups) {
+    if (t == nullptr) return;                  // (wave-uniform: a kernel argument)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have landed
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const unsigned long long now = realtime_ticks();
+    const unsigned long long seen = atomicMax(&t[1], now);
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(seen) : "memory");      // the stamp is in before the ticket goes out
+    if (atomicAdd(&t[2], 1ull) + 1ull != (unsigned long long)n_workgroups) return;
+    // every other workgroup's ticket -- hence its stamps -- has been performed
+    const unsigned long long t0 = atomicMin(&t[0], kInsituIdle), t1 = atomicMax(&t[1], 0ull);
+    const unsigned long long dur = t1 - t0;
+    atomicAdd(&t[3], dur);
+    atomicAdd(&t[4], 1ull);
+    atomicMin(&t[5], dur);
+    atomicMax(&t[6], dur);
+    atomicExch(&t[7], dur);
+    atomicExch(&t[0], kInsituIdle);
+    atomicExch(&t[1], 0ull);
+    atomicExch(&t[2], 0ull);
 }
 
 // Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (read lane 63).

@@ -45,6 +45,14 @@ hipError_t launch_elbo_msplit_fa(const ElboParams& p, int irt, bool grad, int nw
 hipError_t launch_elbo_msplit_fg(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 hipError_t launch_elbo_msplit_fc(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 
+// narrow-row kernel: waves per SIMD each instantiation is compiled for (registers: items x (parameters + gradient accumulators) + one
+// unit of rows; 3PL with gradients at 8 items per lane: 128 registers were 4-12 short -- spilled, and a spill reload waits behind the
+// row loads).  ONE definition for the kernel's launch bounds (vibo_narrow.hip) and the planner's grid (vibo_capi.hip: workgroups per
+// CU = waves per SIMD): the grid has to match the occupancy the kernel was compiled for.
+constexpr int narrow_waves_per_simd(int at, int il, bool g3 = false) {
+    return at == 1 ? ((g3 && il == 8) ? 3 : 4) : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2);
+}
+
 // narrow-row kernel (vibo_narrow.hip): 4 <= I <= 128, ability_dim <= 4, unconditional posterior, no flows; a row per 16 lanes;
 // fp32 rows in order / through p.row_index / 1-byte cell codes (codes: through p.mask); grid workgroups of 4 independent waves
 hipError_t launch_elbo_narrow(const ElboParams& p, bool codes, int irt, bool grad, int grid, hipStream_t s);

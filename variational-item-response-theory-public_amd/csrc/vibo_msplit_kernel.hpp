@@ -158,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry), "=s"(t_real_entry) :: "memory");
 #endif
     const int tid = threadIdx.x;
+    insitu_enter(p.insitu);
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = NW8 ? 8 : (int)(blockDim.x >> 6);
@@ -1389,6 +1390,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
     }
+    insitu_exit(p.insitu, gridDim.x);
 #ifdef VIBO_MS_TIMING
     {
         long long t_exit, t_real_exit;

@@ -55,11 +55,7 @@ constexpr int kNwWaves = 4;            // waves per workgroup (they only meet in
 #endif
 constexpr int kNwPass = VIBO_NW_PASS;  // passes (of 4 rows) per loop iteration = rows in flight per wave / 4
 
-// waves per SIMD each instantiation is compiled for (registers: items x (parameters + gradient accumulators) + one unit of rows)
-// (3PL with gradients at 8 items per lane: 128 registers were 4-12 short -- spilled, and a spill reload waits behind the row loads)
-constexpr int narrow_waves_per_simd(int at, int il, bool g3 = false) {
-    return at == 1 ? ((g3 && il == 8) ? 3 : 4) : at == 2 ? (il == 4 ? 4 : 3) : (il == 4 ? 3 : 2);
-}
+// (narrow_waves_per_simd: vibo_launch.hpp, shared with the planner)
 
 struct alignas(16) NarrowLds {
     float red[kNwWaves][8];
@@ -436,6 +432,9 @@ static hipError_t launch_narrow_at(const ElboParams& p, int irt, bool grad, int 
 // rows: fp32 in order / fp32 through p.row_index / cell codes (codes = true: through p.mask, with or without p.row_index)
 hipError_t launch_elbo_narrow(const ElboParams& p, bool codes, int irt, bool grad, int grid, hipStream_t s) {
     if (p.I < 4 || p.I > 128 || p.A > 4 || p.n_flows > 0) return hipErrorInvalidValue;
+    // the plain model on 1-byte masks / cell codes only: no hooks (conditional / given posterior, panels), no int64 mask
+    if (p.row_cnt || p.pre_stats || p.post_coef || p.given_post || p.given_grad || p.panel_count > 1 || !p.primary) return hipErrorInvalidValue;
+    if (!codes && p.mask_dtype == VIBO_MASK_I64) return hipErrorInvalidValue;
     if (codes) return launch_narrow_at<2>(p, irt, grad, grid, s);
     if (p.row_index) return launch_narrow_at<1>(p, irt, grad, grid, s);
     return launch_narrow_at<0>(p, irt, grad, grid, s);

@@ -82,6 +82,7 @@ struct ElboParams {
     int mask_dtype, missing_mode, reg_mode, vec_ok, n_flows;
     PartialLayout lay;
     int32_t* step_tick;       // non-null: workgroup 0 increments it (the train step's Adam counter, vibo_elbo_fwd_bwd_step)
+    unsigned long long* insitu;   // non-null: the in-situ launch timer's eight words (vibo_set_insitu_timer; matrix row-split kernel)
 };
 
 // the conditional posterior's table-gradient finalize riding in the ELBO finalize launch (vibo_cond_finalize.hpp)

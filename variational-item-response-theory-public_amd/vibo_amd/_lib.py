@@ -71,7 +71,8 @@ EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_by
                     'vibo_ctrain_param_floats', 'vibo_ctrain_scratch_floats', 'vibo_ctrain_prologue', 'vibo_ctrain_epilogue',
                     'vibo_code_table_scratch_bytes', 'vibo_code_table_sum_forward', 'vibo_code_table_sum_backward',
                     'vibo_train_step_supported', 'vibo_elbo_fwd_bwd_step', 'vibo_train_epilogue_fused', 'vibo_train_prime',
-                    'vibo_mtrain_param_floats', 'vibo_mtrain_prologue', 'vibo_mean_encoder_backward_sets', 'vibo_mtrain_epilogue')
+                    'vibo_mtrain_param_floats', 'vibo_mtrain_prologue', 'vibo_mean_encoder_backward_sets', 'vibo_mtrain_epilogue',
+                    'vibo_set_insitu_timer', 'vibo_insitu_timer_reset', 'vibo_selftest_lane_swaps')
 
 _lib = None
 
@@ -178,6 +179,12 @@ def load():
     lib.vibo_mean_encoder_backward_sets.argtypes = [dp, ctypes.c_int, vp, fp, fp, fp, fp, fp, fp, ctypes.c_int, vp]
     lib.vibo_mtrain_epilogue.restype = ctypes.c_int
     lib.vibo_mtrain_epilogue.argtypes = [dp, ctypes.c_int, fp, fp, ctypes.c_int, fp, fp, fp, fp, fp, fp, vp] + [fp] * 8 + [vp]
+    lib.vibo_selftest_lane_swaps.restype = ctypes.c_int
+    lib.vibo_selftest_lane_swaps.argtypes = [fp, fp, vp]
+    lib.vibo_set_insitu_timer.restype = ctypes.c_int
+    lib.vibo_set_insitu_timer.argtypes = [vp]
+    lib.vibo_insitu_timer_reset.restype = ctypes.c_int
+    lib.vibo_insitu_timer_reset.argtypes = [vp, vp]
     if lib.vibo_version() != ABI_VERSION:
         raise ViboLibraryError(f'ABI mismatch: library {lib.vibo_version()} != binding {ABI_VERSION}')
     _lib = lib

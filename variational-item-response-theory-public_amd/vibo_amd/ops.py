@@ -234,6 +234,54 @@ def desc_flags(flags):
         DESC_FLAGS = saved
 
 
+class InsituTimer:
+    """The fused kernel's duration measured by the kernel itself (vibo_set_insitu_timer, include/vibo_hip.h): usable where HIP
+    events are not -- inside a replayed hipGraph -- and without a tracer.  While armed (`with timer:`), every matrix row-split
+    launch this host thread enqueues or captures stamps the block; `read()` returns the sums since the last `reset()`.
+    A measurement hook for bench.py and tools/: the data path never looks at it."""
+
+    TICK_MS = 1e-5      # s_memrealtime: 100 MHz
+
+    def __init__(self, device):
+        self.block = torch.zeros(8, dtype=torch.int64, device=device)
+        self.reset()
+
+    def reset(self):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.block.device).cuda_stream)
+        _lib.check(_lib.load().vibo_insitu_timer_reset(_ptr(self.block), stream), 'vibo_insitu_timer_reset')
+
+    def arm(self):
+        _lib.check(_lib.load().vibo_set_insitu_timer(_ptr(self.block)), 'vibo_set_insitu_timer')
+
+    @staticmethod
+    def disarm():
+        _lib.check(_lib.load().vibo_set_insitu_timer(ctypes.c_void_p(0)), 'vibo_set_insitu_timer')
+
+    def __enter__(self):
+        self.arm()
+        return self
+
+    def __exit__(self, *exc):
+        self.disarm()
+        return False
+
+    def counters(self):
+        """(sum of ticks, launches) since the last reset, after synchronising the device."""
+        torch.cuda.synchronize(self.block.device)
+        w = self.block.cpu().tolist()
+        return w[3], w[4]
+
+    def read(self):
+        torch.cuda.synchronize(self.block.device)
+        w = self.block.cpu().tolist()
+        n = w[4]
+        if n <= 0:
+            return {'launches': 0}
+        k = self.TICK_MS
+        return {'launches': n, 'mean_ms': w[3] / n * k, 'min_ms': w[5] * k, 'max_ms': w[6] * k, 'last_ms': w[7] * k,
+                'in_flight': w[2] != 0}
+
+
 def plan_kernel(spec, num_person, num_item, mask_code=_lib.MASK_U8, want_grad=True):
     """Name of the fused kernel the planner picks for a call of this shape (vibo_plan_kernel)."""
     d = _make_desc(spec, num_person, num_item, mask_code, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, want_grad,

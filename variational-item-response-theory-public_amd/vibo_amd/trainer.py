@@ -132,8 +132,12 @@ class FusedTrainer:
         """Tell the folded step that the parameters were written behind torch's back (`p.data` edits, `trainer.mlp_flat`,
         another kernel): the head the previous epilogue left behind -- item sample, item KL, expert table, saved activations --
         is stale, the next step rebuilds it from the parameters as they are then (vibo_train_prime).  load_state_dict and other
-        writes torch counts are detected without this call.  The pending noise draws are repeated for the same step counter."""
+        writes torch counts are detected without this call.  The pending noise draws are repeated for the same step counter.
+        Also the way out after a step that died between its two halves (an exception in the all-reduce, a hipGraph capture that
+        was aborted after forward_backward() had run on the host): the half-open folded step is forgotten."""
         self._primed_for = None
+        self._folded_open = False
+        self._pending = None
 
     reprime = invalidate
 
@@ -180,6 +184,7 @@ class FusedTrainer:
             raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None,
                                        _lib.REG_KL, True, B)
             self._pending = (d, eps_item, raw, None)
+            self._folded_open = False             # (a four-launch step replaces whatever was pending)
             self.last = raw
             return raw
         # reference draw order: item eps, then ability eps (models.py:361,368)
@@ -212,6 +217,7 @@ class FusedTrainer:
         raw = ops._BACKEND['elbo'](spec, response, mask, code, row_index, self.table, self.item_feat, eps_ab, None,
                                    _lib.REG_KL, True, B)
         self._pending = (d, eps_item, raw, None)
+        self._folded_open = False
         self.last = raw
         return raw
 
@@ -269,6 +275,8 @@ class FusedTrainer:
     @torch.no_grad()
     def update(self):
         """Loss, encoder-MLP / item backward and Adam from the (all-reduced) flat buffer of forward_backward()."""
+        if self._pending is None:
+            raise RuntimeError('FusedTrainer.update(): no forward_backward() is pending')
         d, eps_item, raw, folded_stream = self._pending
         lib, p = _lib.load(), ops._ptr
         stream = ctypes.c_void_p(torch.cuda.current_stream(raw.flat.device).cuda_stream)
