@@ -654,14 +654,21 @@ def main():
                 'mfma_util_profile': 'SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles: profiles/r02_decoder_pmc.txt (17 %)'}
 
     def config5_probe():
-        """BASELINE configs[4]'s path on a slice of its shape (3PL, 10 000 items, conditional posterior, 4 planar flows, fp32 rows):
-        one forward + backward call of 100 000 persons; three passes (cond_pre, matrix kernel per 1024-item panel, table-gradient pass)."""
+        """BASELINE configs[4] LITERALLY where the GPU's memory allows (3PL, 1 000 000 persons x 10 000 items, conditional posterior, 4
+        planar flows, fp32 rows: 40 GB of responses + 10 GB of mask bytes resident; 100 000 persons otherwise): one forward +
+        backward call = three passes (cond_pre over all ten 1024-item panels, the matrix kernel's one-launch panel mode, the
+        table-gradient pass on the matrix pipe)."""
         from vibo_amd import _lib
         from vibo_amd.ops import ElboSpec
-        Pc, Ic = 100_000, 10_000
+        Ic = 10_000
+        Pc = 1_000_000 if torch.cuda.mem_get_info(dev)[0] > 120 * 2 ** 30 else 100_000
         g = torch.Generator(device=dev).manual_seed(args.seed + 5)
-        r = (torch.rand(Pc, Ic, device=dev, generator=g) < 0.5).float()
-        mk = torch.rand(Pc, Ic, device=dev, generator=g) >= args.missing
+        r = torch.empty(Pc, Ic, device=dev)
+        mk = torch.empty(Pc, Ic, dtype=torch.bool, device=dev)
+        for s0 in range(0, Pc, 50_000):          # (in person slices: the temporaries of a one-shot draw would be 90 GB)
+            n = min(50_000, Pc - s0)
+            r[s0:s0 + n] = (torch.rand(n, Ic, device=dev, generator=g) < 0.5).float()
+            mk[s0:s0 + n] = torch.rand(n, Ic, device=dev, generator=g) >= args.missing
         spec = ElboSpec(irt_model=3, ability_dim=1, conditional=True, n_flows=4)
         table = torch.randn(2, Ic, 2, device=dev, generator=g) * 0.5
         item = torch.randn(Ic, 3, device=dev, generator=g)
@@ -670,7 +677,7 @@ def main():
         m8, code = ops.prepare_mask(mk)
         call = lambda: ops._hip_launch_elbo(spec, r, m8, code, None, table, item, eps, flow, _lib.REG_SAMPLED, True, Pc)
         for _ in range(2):
-            call()
+            out = call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
@@ -679,11 +686,15 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         bpt = 5.0 + 12.0 / Ic
-        return {'workload': f'3PL, {Pc} persons x {Ic} items, ability_dim 1, conditional posterior, 4 planar flows, fp32 rows: one forward + backward call',
-                'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3), 'bytes_per_term': bpt,
-                'roofline_frac': bpt * Pc * Ic / (ms * 1e-3) / 8e12,
-                'hbm_bytes_per_term_by_construction': 8.0,
-                'note': 'cond_pre reads 5 B and writes 1 B of cell codes per term, the matrix kernel and the table-gradient pass (matrix pipe, vibo_cmean.hip) read 1 B each'}
+        res = {'workload': f'3PL, {Pc} persons x {Ic} items, ability_dim 1, conditional posterior, 4 planar flows, fp32 rows: one forward + backward call'
+                           + (' (BASELINE configs[4] at its literal size)' if Pc == 1_000_000 else ' (a tenth of BASELINE configs[4]: not enough free HBM for 1M persons)'),
+               'ms': ms, 'ms_per_1e9_terms': ms * 1e9 / (Pc * Ic), 'terms_per_s': Pc * Ic / (ms * 1e-3), 'bytes_per_term': bpt,
+               'roofline_frac': bpt * Pc * Ic / (ms * 1e-3) / 8e12, 'loss_is_finite': bool(torch.isfinite(out.scalars).all()),
+               'hbm_bytes_per_term_by_construction': 8.0,
+               'note': 'cond_pre reads 5 B and writes 1 B of cell codes per term, the matrix kernel and the table-gradient pass (matrix pipe, vibo_cmean.hip) read 1 B each'}
+        del r, mk, m8, out
+        torch.cuda.empty_cache()
+        return res
 
     def shapes_probe():
         """The other BASELINE shapes as one forward + backward call each (kernel path only, HIP events over 5 calls): configs[3]'s

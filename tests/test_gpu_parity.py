@@ -636,16 +636,21 @@ def _device_problem(irt, A, P, I, missing, seed, cond):
     return resp, mask, table, item, eps
 
 
+@pytest.mark.parametrize('P', [100_000, 1_000_000], ids=['100k-persons', 'full-size-1M-persons'])
 @pytest.mark.parametrize('codes', [False, True], ids=['fp32-rows', 'cell-codes'])
-def test_config5_pipeline_at_the_planner_large_call_size(codes):
+def test_config5_pipeline_at_the_planner_large_call_size(codes, P):
     """BASELINE configs[4]'s row shape at a size the planner's large-call paths see (100 000 persons x 10 000 items, 3PL,
     ability_dim 1, --conditional-posterior, 4 planar flows, 20 % missing; models.py:695-710,758-765, flows.py:21-66): the
     count-and-emit pass over all ten 1024-item panels, the panel sums, the matrix kernel's one-launch panel mode with the flow and
     conditional hooks, and the table-gradient pass -- bitwise reproducible, additive over two person shards (what the 8-GPU
     sharding relies on), the same through an in-kernel row gather, and equal to the CPU oracle on a 48-person slice.
-    (The 9-person GENERAL_SHAPES case of this configuration never leaves the small-call kernels.)"""
-    irt, A, P, I, n_flows = 3, 1, 100_000, 10_000, 4
+    (The 9-person GENERAL_SHAPES case of this configuration never leaves the small-call kernels.)
+    `full-size-1M-persons` = BASELINE configs[4] LITERALLY: 1 000 000 x 10 000 = 1e10 cells (40 GB of fp32 responses + 10 GB of mask
+    bytes, or 10 GB of cell codes, resident on the one GPU) -- the first shape whose cell index does not fit 32 bits."""
+    irt, A, I, n_flows = 3, 1, 10_000, 4
     d = dev()
+    if P * I > 2_000_000_000 and torch.cuda.mem_get_info(d)[0] < 150 * 2 ** 30:
+        pytest.skip('the full-size case needs ~150 GB of free HBM')
     spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=True, n_flows=n_flows)
     resp, mask, table, item, eps = _device_problem(irt, A, P, I, 0.2, seed=55, cond=True)
     g = torch.Generator().manual_seed(5)
