@@ -35,13 +35,18 @@
 
 #ifdef VIBO_MS_TIMING
 // development build (make TIMING=1): shader-clock time per phase of the batch loop, summed per wave
-__device__ long long g_ms_timing[1024 * 8 * 16];
+constexpr int kMsTSlots = 32;
+__device__ long long g_ms_timing[1024 * 8 * kMsTSlots];
 #define MS_T(i) { __builtin_amdgcn_sched_barrier(0); long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
                   __builtin_amdgcn_sched_barrier(0); tacc[i] += now_ - tlast; tlast = now_; }
 #define MS_WAITV() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// one-shot marks (prologue 16.., end code 24..): shader-clock cycles since the wave's entry / since the loop's end
+#define MS_P(i, base) { __builtin_amdgcn_sched_barrier(0); long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+                  __builtin_amdgcn_sched_barrier(0); tacc[i] = now_ - (base); }
 #else
 #define MS_T(i)
 #define MS_WAITV()
+#define MS_P(i, base)
 #endif
 
 namespace vibo {
@@ -156,6 +161,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #ifdef VIBO_MS_TIMING
     long long t_entry, t_real_entry;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry), "=s"(t_real_entry) :: "memory");
+    long long tacc[kMsTSlots];
+    for (int k = 0; k < kMsTSlots; ++k) tacc[k] = 0;
+    long long tlast;
 #endif
     const int tid = threadIdx.x;
     insitu_enter(p.insitu);
@@ -192,11 +200,13 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const int n_batches = (int)(((long long)p.B + R - 1) / R);
     float4 x[CODES ? 1 : 8];                        // [2 j + u]: person j of the half, chunk u
     uint32_t m[8];
+    float4 x2[CODES ? 1 : 8];                       // the first batch's M-tile 1 (requested with M-tile 0 at the top of the kernel: dead
+    uint32_t m2[8];                                 //  once the prologue has packed it)
     // Gathered rows: the row numbers of a batch are needed before its first row load can go out.  They are fetched TWO batches
     // ahead (ridx_n, a whole iteration before their use) -- fetched right in front of the row loads they feed, every batch
     // waited a memory round trip for them at the top of the loop (gathered rows: +22 % on fp32 rows, +60 % on cell codes).
     int ridx[8], ridx_n[8];
-    auto fetch_idx = [&](const int bt, int (&dst)[8]) {
+    auto fetch_idx = [&](const int bt, int (&dst)[8]) __attribute__((always_inline)) {
         if constexpr (RM != 0) {
             if (!p.row_index) return;
             const int row0 = bt * R;
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         return rs;
     };
     // quarter (h, j) = person 4 h + j of the lane (row 4 g + j + 16 h of the batch), both chunks: 2 x 16 B + 2 x 4 B
-    auto load_quarter = [&](const int bt, const RowSrc& rs, const int h, const int j) {
+    auto load_quarter = [&](const int bt, const RowSrc& rs, const int h, const int j, float4 (&x)[CODES ? 1 : 8], uint32_t (&m)[8]) __attribute__((always_inline)) {
         bool linear = RM == 0;
         if constexpr (RM == 2) linear = p.row_index == nullptr;
         if (linear) {
@@ -261,13 +271,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 const float4* rp = reinterpret_cast<const float4*>(p.response + src * p.resp_stride + item0);
                 x[2 * j] = rp[cc0];
                 x[2 * j + 1] = rp[cc1];
-                if (p.mask_dtype == 0) {
-                    const uint32_t* mp = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + item0);
-                    m[2 * j] = mp[cc0];
-                    m[2 * j + 1] = mp[cc1];
-                } else {
-                    m[2 * j] = m[2 * j + 1] = 0u;
-                }
+                // (no branch around the mask loads: without a mask they read the response row again -- a valid address -- and a
+                //  select drops the value; with the two-way form hipcc merged the stores of the two paths into one with a run-time
+                //  offset, which put the whole register array into scratch memory)
+                const bool hm = p.mask_dtype == 0;
+                const uint32_t* mp = hm ? reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p.mask) + src * p.mask_stride + item0)
+                                        : reinterpret_cast<const uint32_t*>(rp);
+                const uint32_t w0 = mp[cc0], w1 = mp[cc1];
+                m[2 * j] = hm ? w0 : 0u;
+                m[2 * j + 1] = hm ? w1 : 0u;
             }
         }
     };
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
     };
     float epn = 0.f;                                  // eps of this wave's slot of the next batch (4 or more waves), loaded a batch ahead
-    auto fetch_eps = [&](const int bt, const int par) {
+    auto fetch_eps = [&](const int bt, const int par) __attribute__((always_inline)) {
         if ((!NW8 && nw < 4) || bt >= n_batches) return;
         int s0, s1, step;
         my_slots(par, s0, s1, step);
@@ -319,32 +331,76 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
     };
-    // ---- the first batch's rows (M-tile 0) and noise are requested before anything else: their HBM / TLB latency (the first
-    //      touch of this workgroup's pages) runs under the operand-image build below instead of after it
+    // ---- One-shot requests.
+    // What the start of a launch costs (tools/ms_timing.py, prologue marks; 100 000 x 1 000): every workgroup needs its whole first
+    // batch -- 160 KB, 41 MB over the chip -- before its first tile, the chip's workgroups ask for them within 0.3 us of each other,
+    // and the memory system delivers that burst at ~4.9 TB/s: 8.4 us during which nothing computes, whatever the order of the
+    // requests (rounds 5 and 6 tried: M-tile 1 with M-tile 0, the item sample first).  But the workgroups are not equally
+    // loaded: n_batches % G of them stream one batch more than the others and finish last.  So the others -- `late`, a batch of
+    // slack each -- hold their first row requests back until the long workgroups' burst is through (their item sample and
+    // operand image are built in the meantime): the long ones start computing ~5 us earlier, the launch ends ~5 us earlier.
+    const int rem_wg = n_batches % G;
+    const bool late = rem_wg != 0 && wg >= rem_wg;                         // (wave-uniform)
+    const unsigned long long t_wave_start = late ? realtime_ticks() : 0ull;
     int bt = wg;
     const RowSrc src_first = row_src(bt);
-    if (bt < n_batches) {
-        fetch_idx(bt, ridx);
+    auto first_rows = [&]() __attribute__((always_inline)) {      // the first batch's rows (both M-tiles) and noise; (two call sites)
+        if (bt < n_batches) {
+            fetch_idx(bt, ridx);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_quarter(bt, src_first, 0, j);
-        fetch_eps(bt, 0);
-        fetch_idx(bt + G, ridx_n);
-    }
-
-    auto put_ctab = [&](const float* table) {
-        if (tid < 16) {
-            const int c = tid >> 3, a = tid & 7;
-            float m = 0.f, s = 0.f;
-            if (a < A) { m = table[c * 2 * A + a]; s = table[c * 2 * A + A + a]; }
-            const float es = __expf(s);
-            const float tau = 1.0f / (es + kPoeEps);
-            cl.ctab[(0 * 2 + c) * 8 + a] = tau;
-            cl.ctab[(1 * 2 + c) * 8 + a] = m * tau;
-            cl.ctab[(2 * 2 + c) * 8 + a] = tau * tau * es;
-            cl.ctab[(3 * 2 + c) * 8 + a] = m;
+            for (int j = 0; j < 4; ++j) load_quarter(bt, src_first, 0, j, x, m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_quarter(bt, src_first, 1, j, x2, m2);
+            fetch_eps(bt, 0);
+            fetch_idx(bt + G, ridx_n);
         }
     };
-    put_ctab(p.table);
+    // (rows before the item sample in the long workgroups.  The CU's memory pipeline is one queue for its eight waves and takes
+    //  ~6 k cycles to accept a batch's 256 load instructions: with the item sample requested first, the later waves' 4.6 KB sat
+    //  behind the earlier waves' rows anyway -- it came in at 14-17 k cycles instead of 11-14 k, the first barrier at 17 k
+    //  instead of 14 k: measured both ways, tools/ms_timing.py)
+    if (!late) first_rows();
+    __builtin_amdgcn_sched_barrier(0);
+    // The wave's 128 items x D entries are one contiguous span of the caller's [I][D] item sample: read as that -- lane l takes
+    // floats l, l + 64, ... (whole cache lines per instruction) -- and handed to the item's lane through the wave's own LDS below.
+    // (Rounds 2-5: lane = item, one load per entry, lanes D floats apart: 18 x 18 line requests per wave for the same 4.6 KB, and
+    //  all 2 048 waves of the launch asking the same 36 KB's L2 channels at once -- the item sample took 9-12 k cycles to arrive
+    //  however early it was requested, tools/ms_timing.py.)
+    constexpr int kItemReq = (kMsSpan * (VIBO_MAX_ABILITY_DIM + 2) + 63) / 64;      // loads per lane at D = 10
+    float it_req[kItemReq];
+    const int it_floats = kMsSpan * p.D;                                    // (wave-uniform)
+    {
+        const long long it_base = (long long)(item0 + kMsSpan * q) * p.D;
+        const long long it_last = (long long)(item0 + I) * p.D - 1;         // last entry of this launch's (panel's) items
+#pragma unroll
+        for (int k = 0; k < kItemReq; ++k) {
+            it_req[k] = 0.f;
+            if (64 * k < it_floats) {                                       // (scalar branch; clamped index: always a valid address)
+                const long long f = it_base + min(64 * k + lane, it_floats - 1);
+                it_req[k] = p.item_raw[f < it_last ? f : it_last];
+            }
+        }
+    }
+    float tab_m = 0.f, tab_s = 0.f;                 // (threads 0..15: entry (c, a) of the 2-row expert table, mean | log variance)
+    if (tid < 16) {
+        const int c = tid >> 3, a = min(tid & 7, p.A - 1);
+        tab_m = p.table[c * 2 * p.A + a];
+        tab_s = p.table[c * 2 * p.A + p.A + a];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    MS_P(16, t_entry)                                 // item sample (+ the long workgroups' first rows) requested
+
+    // expert-table constants of the (person, dim) lanes (the two table entries were requested with the item sample)
+    if (tid < 16) {
+        const int c = tid >> 3, a = tid & 7;
+        const float m = a < A ? tab_m : 0.f, s = a < A ? tab_s : 0.f;
+        const float es = __expf(s);
+        const float tau = 1.0f / (es + kPoeEps);
+        cl.ctab[(0 * 2 + c) * 8 + a] = tau;
+        cl.ctab[(1 * 2 + c) * 8 + a] = m * tau;
+        cl.ctab[(2 * 2 + c) * 8 + a] = tau * tau * es;
+        cl.ctab[(3 * 2 + c) * 8 + a] = m;
+    }
     if (p.step_tick && blockIdx.x == 0 && tid == 0) *p.step_tick += 1;
     if constexpr (FLOWS) {
         if (tid < kMsMF * 8) {
@@ -388,6 +444,30 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // silently wrong numbers; VIBO_FLAG_KERNEL_VALU runs such inputs on the fp32 VALU kernel.
     // 3PL: guess probabilities of the wave's items, read back per tile (see kMsGuessFloats)
     float* const gsl = reinterpret_cast<float*>(ms_smem + sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (FLOWS ? sizeof(MsFlowLds) : 0)) + q * kMsGuessFloats;
+    MS_P(17, t_entry)                                 // encoder table in LDS (its loads waited for)
+    // item sample: through the wave's own LDS (the g-piece / operand-image area, not in use yet) to the item's lane
+    float* const it_stage = reinterpret_cast<float*>(&wl.tr[0][0][0]);
+    static_assert(sizeof(wl.tr) + sizeof(wl.img) >= (size_t)kMsSpan * (VIBO_MAX_ABILITY_DIM + 2) * sizeof(float), "item staging area");
+#pragma unroll
+    for (int k = 0; k < kItemReq; ++k)
+        if (64 * k < it_floats) it_stage[64 * k + lane] = it_req[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS writes, in order: visible to its reads)
+    float a_req[2][8], b_req[2];
+    float g_raw[2][4];                                      // 3PL: guess logits of the lane's items of tile (u, t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float* src = it_stage + (64 * h + lane) * p.D;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) a_req[h][kk] = IRT != 1 ? src[min(kk, A - 1)] : 0.f;
+        b_req[h] = src[IRT == 1 ? 0 : A];
+    }
+    if constexpr (IRT == 3) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g_raw[u][t] = it_stage[(64 * u + 4 * i16 + t) * p.D + A + 1];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (all read before the operand image overwrites the area)
     float na_raw[2][8], nb_raw[2];
     float amax = 0.f, bmax = 0.f;
 #pragma unroll
@@ -395,16 +475,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const int xl = 64 * h + lane;                                   // item of the wave, one per lane and pass
         const int il = kMsSpan * q + xl;
         const bool ok = il < I;
-        const size_t ir = (size_t)(item0 + (ok ? il : 0)) * p.D;     // (entry index into the caller's item sample)
-        // All of the lane's entries are asked for at once, from clamped (always valid) indices, and masked afterwards: written
-        // as `if (ok && kk < A) na = item_raw[..]` each load sat in its own branch behind an s_waitcnt vmcnt(0) -- 18 memory
-        // round trips in a row at the start of every workgroup (cold TLB, cold L2), most of the kernel's one-shot prologue.
-        float a_raw[8];
-        if constexpr (IRT != 1) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) a_raw[kk] = p.item_raw[ir + min(kk, A - 1)];
-        }
-        const float b_raw = p.item_raw[ir + (IRT == 1 ? 0 : A)];
+        const float (&a_raw)[8] = a_req[h];
+        const float b_raw = b_req[h];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float na = 0.f;
@@ -427,7 +499,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         mb = fmaxf(mb, __shfl_xor(mb, 16)); mb = fmaxf(mb, __shfl_xor(mb, 32));
         if (lane == 0) { wl.red[1] = ma; wl.red[2] = mb; }
     }
+    MS_P(18, t_entry)                                 // item sample in, wave maxima
     __syncthreads();
+    MS_P(19, t_entry)
     float wg_amax = 0.f, wg_bmax = 0.f;
     for (int w = 0; w < nw; ++w) { wg_amax = fmaxf(wg_amax, wls[w].red[1]); wg_bmax = fmaxf(wg_bmax, wls[w].red[2]); }
     // frexp exponents e: max < 2^e
@@ -462,14 +536,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         *reinterpret_cast<half8*>(dst + 16) = half8{b0, b1, b2, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     }
     if constexpr (IRT == 3) {
-        float g_raw[2][4];                  // (all eight loads first, clamped and unconditional, as above)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int il = kMsSpan * q + 64 * u + 4 * i16 + t;
-                g_raw[u][t] = p.item_raw[(size_t)(item0 + (il < I ? il : 0)) * p.D + A + 1];
-            }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -498,7 +564,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     float s_log = 0.f;
     int unobs = 0;
     bool sat3 = false;                  // 3PL: this wave met a probability past the clamp in this batch (wave-uniform: see the tile)
+    MS_P(20, t_entry)                                 // operand image written
     __syncthreads();
+    MS_P(21, t_entry)
 
     // LDS image offsets (halfs): producer row 16 t + i16, piece g; consumer rows 32 kt + 4 g + (i16 >> 2) (+ 16), piece i16 & 3
     const int wofs = 16 * i16 + 4 * (g ^ (i16 >> 2));
@@ -514,7 +582,8 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     bool need_in = RM != 0 || !have_mask;
     if constexpr (RM == 2) need_in = true;
     // pk[j]: 8-bit fields nobs | nobs of M-tile 1 | n1 | n1 of M-tile 1 of persons j and 4 + j (each <= 8 per lane)
-    auto pack_quarter = [&](auto inc, const int left, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4]) {
+    auto pack_quarter = [&](auto inc, const int left, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
+                            const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8]) {
         constexpr bool IN = decltype(inc)::value;
         uint32_t k0 = tm0, k1 = tm1;
         if constexpr (IN) {
@@ -534,14 +603,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         // (pinned here: hipcc otherwise sinks the whole pack to the end of the batch, and the next loads take new registers)
         asm volatile("" : "+v"(cw0[4 * h + j]), "+v"(cw1[4 * h + j]), "+v"(pk[j]));
     };
-    auto pack_half = [&](const int bt, const int h, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4]) {
+    auto pack_half = [&](const int bt, const int h, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
+                         const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8]) {
         const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
         if (need_in && left < R) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk);
+            for (int j = 0; j < 4; ++j) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk);
+            for (int j = 0; j < 4; ++j) pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m);
         }
     };
     // packed counts of the lane's 8 persons (both u-steps) -> 16-lane sums -> wl.cnt
@@ -1173,10 +1243,19 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     if (bt < n_batches) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = 0;
-        pack_half(bt, 0, cwA0, cwA1, pk);             // (M-tile 0 was requested at the top of the kernel)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) load_quarter(bt, src_first, 1, j);
-        pack_half(bt, 1, cwA0, cwA1, pk);
+        if (late) {
+            // (a batch of slack: the rows are asked for once the long workgroups' first batches -- rem_wg x the bytes of a batch at
+            //  ~5 TB/s, + 1 us of latency -- are through, 6 us at most; ticks of 10 ns)
+            const long long batch_bytes = (long long)R * n4 * (CODES ? 4 : 20);
+            long long wait_ticks = (long long)rem_wg * batch_bytes / 50000 + 100;
+            wait_ticks = wait_ticks > 600 ? 600 : wait_ticks;
+            while ((long long)(realtime_ticks() - t_wave_start) < wait_ticks) __builtin_amdgcn_s_sleep(8);
+            first_rows();
+        }
+        pack_half(bt, 0, cwA0, cwA1, pk, x, m);
+        MS_P(22, t_entry)
+        pack_half(bt, 1, cwA0, cwA1, pk, x2, m2);
+        MS_P(23, t_entry)
         put_counts(pk, true);
         asm volatile("" : "+v"(epn));                 // (in before the loop: no wait on it behind the loop's own loads)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
@@ -1187,8 +1266,6 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     half8 bopA = item_op(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     half8 bopB = item_op(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
 #ifdef VIBO_MS_TIMING
-    long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
     tacc[12] = tlast - t_entry;                      // kernel prologue (operand images, first batch)
     tacc[14] = t_real_entry;                         // wall clock (100 MHz) at entry
@@ -1220,15 +1297,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         auto burst_a = [&]() {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 0, j);
+            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 0, j, x, m);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto pack_a_burst_b = [&]() {
-            pack_half(nxt, 0, cwB0, cwB1, pk);
+            pack_half(nxt, 0, cwB0, cwB1, pk, x, m);
             fetch_eps(nxt, par ^ 1);                  // (complete by the second pack: free to carry across the back edge)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 1, j);
+            for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 1, j, x, m);
             __builtin_amdgcn_sched_barrier(0);
         };
         burst_a();
@@ -1265,7 +1342,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1, bopB, bopA);     // (... of the next batch's (0, 0) into bopA)
         tile(IC1{}, IC3{}, db0, db1, da0, da1, cwA1, bopA, bopB);     // (not used: last; reads (0, 1) into bopB)
         MS_T(2)
-        pack_half(nxt, 1, cwB0, cwB1, pk);
+        pack_half(nxt, 1, cwB0, cwB1, pk, x, m);
         asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
         if constexpr (XCOND && kPrs) asm volatile("" : "+v"(prc));
@@ -1279,20 +1356,21 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { cwA0[k] = cwB0[k]; cwA1[k] = cwB1[k]; }
     }
+#ifdef VIBO_MS_TIMING
+    long long t_loop_end;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop_end) :: "memory");
+#endif
     if constexpr (GRAD) {
         // backward of the workgroup's last batch
         __syncthreads();
         if (bt >= G + wg) person_backward(bt - G, par ^ 1);
     }
 
-#ifdef VIBO_MS_TIMING
-    long long t_loop_end;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop_end) :: "memory");
-#endif
     // ================= workgroup reduction -> partial record =================
     // The lane-derived indices are formed afresh here (from an opaque copy of the thread id): shared with the prologue's, the ones
     // the batch loop has no use for stayed live across it -- in the instantiations at the 256-register limit they were spilled
     // to scratch (the kernel trace's `scratch` column), however rarely reloaded.
+    MS_P(24, t_loop_end)
     int tid_e = (int)threadIdx.x;
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, i16_e = lane_e & 15, g_e = lane_e >> 4;
@@ -1303,6 +1381,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if (lane_e == 0) wl.red[0] = range_fault ? __builtin_nanf("") : ll;      // (operands beyond the rescaling range: loud)
     }
     __syncthreads();
+    MS_P(25, t_loop_end)
     // scalars: 0 ll | 1 kl | 2 logq0 | 3 logp | 4 ladj | 5 nobs
     if (tid_e == 0) {
         float t = 0.f;
@@ -1327,14 +1406,24 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         const float t = wave_total(v);
         if (lane_e == 0) out[k == 8 ? 1 : k == 9 ? 2 : k == 10 ? 3 : 5] = t;
     }
+    MS_P(26, t_loop_end)
     if constexpr (GRAD) {
-        if (tid_e < 8 * A) {
-            const int a = tid_e >> 3, k = tid_e & 7;
-            float t = 0.f;
+        // table gradient: term k (< 8) of ability dim a = the sum of the 2 x 32 (person, dim a) pairs' running sums.  Wave q takes
+        // terms q, q + nw, ...: every lane adds its eight values (pairs e = lane + 64 j keep the lane's dim, e & 7), then the eight
+        // lanes of a dim fold (fixed order: bitwise reproducible).  (Rounds 2-5: 8 A threads of wave 0 walked 64 LDS values each,
+        // ~6 k cycles on the critical path of every workgroup's exit -- tools/ms_timing.py, end-code marks.)
+        for (int k = q; k < 8; k += nw) {
+            float v = 0.f;
+#pragma unroll
             for (int par2 = 0; par2 < 2; ++par2)
-                for (int e = a; e < 256; e += 8) t += cl.tacc[par2][k][e];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v += cl.tacc[par2][k][lane_e + 64 * j];
+            v += dpp_f<0x128>(v);               // row_ror 8: lanes l and l + 8 of a row
+            v = xor16_add(v);
+            v = xor32_add(v);
+            const int a = lane_e & 7;
             const int st = k >> 2, c = (k >> 1) & 1, ms = k & 1;
-            out[p.lay.off_table + (st * 2 + c) * 2 * A + ms * A + a] = t;
+            if (lane_e < 8 && a < A) out[p.lay.off_table + (st * 2 + c) * 2 * A + ms * A + a] = v;
         }
         if constexpr (FLOWS) {
             const int per = 2 * A + 1;
@@ -1351,6 +1440,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         // The wave's 128 items x (A + 2) rows go through its own LDS (the operand images are dead by now; nobody else reads
         // them: no barrier) and leave as whole 256-byte rows -- the registers' own layout is 4-byte stores scattered over 32
         // cache lines each, ~5 us at the end of every workgroup.
+        MS_P(27, t_loop_end)
         constexpr int kStage = 130;                  // floats per staged row (128 + 2: the 32 writers of a row group hit 32 banks)
         float* stage = reinterpret_cast<float*>(&wl.tr[0][0][0]);
         static_assert(sizeof(wl.tr) + sizeof(wl.img) >= (size_t)(VIBO_MAX_ABILITY_DIM + 2) * kStage * sizeof(float), "staging area");
@@ -1381,6 +1471,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS writes, in order: visible to its reads)
+        MS_P(28, t_loop_end)
         const int n_rows = IRT == 1 ? 1 : IRT == 2 ? A + 1 : A + 2;
         for (int row = 0; row < n_rows; ++row) {
 #pragma unroll
@@ -1398,7 +1489,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         tacc[13] = t_exit - t_loop_end;              // kernel epilogue (records)
         tacc[15] = t_real_exit;
         if (lane == 0 && blockIdx.x < 1024) {
-            for (int k = 0; k < 16; ++k) g_ms_timing[((size_t)blockIdx.x * 8 + q) * 16 + k] = tacc[k];
+            for (int k = 0; k < kMsTSlots; ++k) g_ms_timing[((size_t)blockIdx.x * 8 + q) * kMsTSlots + k] = tacc[k];
         }
     }
 #endif
