@@ -65,6 +65,60 @@ def test_simulation_split_and_getitem(tmp_dirs):
     assert r.shape == (40, 12) and m.all()
 
 
+@pytest.mark.parametrize('name,sub', [('duolingo', 'duolingo'), ('wordbank', 'wordbankr'), ('pisa2015_science', 'pisa2015_science')])
+def test_real_world_loaders_from_the_reference_cache_match_the_reference(tmp_dirs, name, sub):
+    """Duolingo / WordBank / PISA (src/datasets.py:443-863) start from the score matrix the reference caches after parsing the raw
+    corpus; datasets.CachedScoreMatrix starts from the same file.  Golden: the REAL reference loaders run on a synthetic cache
+    (tools/gen_loader_golden.py -> tests/golden/score_matrix_loaders.npz): binarisation, RandomState(42) shuffle (not for
+    WordBank), 80/20 split, max_num_person / max_num_item, all-missing rows dropped (not for WordBank), the per-sample tuple."""
+    z = np.load(os.path.join(GOLDEN_DIR, 'score_matrix_loaders.npz'))
+    d = os.path.join(config.DATA_DIR, sub)
+    os.makedirs(d)
+    np.save(os.path.join(d, 'score_matrix.npy'), z['in.duolingo'] if name == 'duolingo' else z['in.base'])
+    if name == 'duolingo':
+        np.save(os.path.join(d, 'token_id.npy'), z['in.token_id'])
+    for tag, kw in (('train', dict(train=True)), ('test', dict(train=False)),
+                    ('train_max', dict(train=True, max_num_person=30, max_num_item=11))):
+        if name == 'wordbank' and 'max_num_item' in kw:
+            kw = dict(train=True, max_num_person=30)      # (the reference's WordBank loader itself dies on max_num_item, datasets.py:686)
+        ds = datasets.load_dataset(name, **kw)
+        assert np.array_equal(ds.response, z[f'{name}.{tag}.response']) and np.array_equal(ds.mask, z[f'{name}.{tag}.mask']), tag
+        assert (ds.num_person, ds.num_item) == z[f'{name}.{tag}.response'].shape and len(ds) == ds.num_person
+        idx, r, iid, m = ds[2]
+        assert idx == 2 and r.dtype == torch.float32 and iid.dtype == torch.int64 and m.dtype == torch.bool
+        assert np.array_equal(r.numpy(), z[f'{name}.{tag}.item2.response'])
+        assert np.array_equal(iid.numpy(), z[f'{name}.{tag}.item2.item_id']) and np.array_equal(m.numpy(), z[f'{name}.{tag}.item2.mask'])
+        if f'{name}.{tag}.item_id' in z.files:
+            assert np.array_equal(ds.item_id, z[f'{name}.{tag}.item_id'])
+        rr, mm = ds.matrix()                  # what the resident split keeps in HBM
+        assert rr.dtype == np.float32 and mm.dtype == bool and np.array_equal(mm, ds.response != -1)
+    # WordBank with max_num_item: a NameError in the reference, simply the first items here
+    if name == 'wordbank':
+        assert datasets.load_dataset(name, train=True, max_num_item=5).num_item == 5
+
+
+def test_score_matrix_dataset_trains_through_the_cli(cpu_ops, tmp_dirs):
+    """--dataset score_matrix: any pre-built [P, I] matrix (1 right / 0 wrong / -1 missing) under DATA_DIR/score_matrix/ behind the
+    reference's (index, response, item_id, mask) contract -- PISA's steps behind the cache -- runs end to end; without the file
+    the loader names what is missing."""
+    with pytest.raises(FileNotFoundError, match='score_matrix.npy'):
+        datasets.load_dataset('score_matrix', train=True)
+    rs = np.random.RandomState(3)
+    M = rs.randint(0, 2, size=(120, 17)).astype(np.float32)
+    M[rs.rand(120, 17) < 0.25] = -1
+    M[5] = -1
+    os.makedirs(os.path.join(config.DATA_DIR, 'score_matrix'))
+    np.save(os.path.join(config.DATA_DIR, 'score_matrix', 'score_matrix.npy'), M)
+    tr, te = datasets.load_dataset('score_matrix', train=True), datasets.load_dataset('score_matrix', train=False)
+    assert tr.num_person + te.num_person == 119 and tr.num_item == 17          # (the all-missing row is gone)
+    cli.main(['--irt-model', '2pl', '--dataset', 'score_matrix', '--epochs', '1', '--batch-size', '16', '--num-posterior-samples', '2',
+              '--no-marginal', '--no-predictive', '--out-dir', config.OUT_DIR])
+    (run_dir,) = os.listdir(config.OUT_DIR)
+    assert run_dir.startswith('VIBO_2pl_score_matrix_bernoulli_irt_Noneperson_Noneitem')
+    ck = torch.load(os.path.join(config.OUT_DIR, run_dir, 'checkpoint.pth.tar'), weights_only=False)
+    assert ck['infer_dict']['ability_mu'].shape == (tr.num_person, 1)
+
+
 def test_artificial_mask_matches_reference_semantics(tmp_dirs):
     """Golden from the reference's artificially_mask_dataset on a 200 x 95 matrix (perc 0.2)."""
     z = np.load(os.path.join(GOLDEN_DIR, 'artificial_mask.npz'))

@@ -117,3 +117,21 @@ def test_cli_two_ranks_with_uneven_shards_takes_equal_steps(tmp_path):
     (run_dir,) = os.listdir(out_dir)
     ck = torch.load(os.path.join(out_dir, run_dir, 'checkpoint.pth.tar'), weights_only=False)
     assert ck['infer_dict']['ability_mu'].shape[0] == 801
+    # the checkpoint's infer_dict was computed by the two ranks on their own shards (400 + 401 rows) and all-gathered in rank
+    # order: it has to be what one process computes on the whole split from the same checkpoint
+    from oracle import cpu_backend
+    from vibo_amd import config, ops
+    from vibo_amd.torch_core import posthoc, vibo as cli
+    restore = cpu_backend.install(ops)
+    saved = config.DATA_DIR, config.OUT_DIR
+    try:
+        config.DATA_DIR, config.OUT_DIR = data_dir, out_dir
+        args = ck['args']
+        ds = posthoc._dataset(args, True)
+        model = posthoc._model(args, ds.num_item, ck['model_state_dict'], torch.device('cpu'))
+        whole = cli.infer_dict(model, posthoc._split(args, ds, torch.device('cpu')), args.batch_size)
+    finally:
+        config.DATA_DIR, config.OUT_DIR = saved
+        restore()
+    for k in ('ability_mu', 'ability_logvar', 'item_feat_mu', 'item_feat_logvar'):
+        assert torch.allclose(ck['infer_dict'][k].cpu(), whole[k].cpu(), rtol=1e-6, atol=1e-6), k

@@ -113,7 +113,7 @@ def test_insitu_timer_inside_the_folded_train_step_graph():
     P, I, A = 65_536, 1000, 8
     spec, r, m8, code, table, item, eps = _problem(P, I, A, d, seed=9)
     torch.manual_seed(1)
-    model = VIBO_2PL(A, I).to(d)
+    model = VIBO_2PL(A, I, ability_merge='product').to(d)
     tr = FusedTrainer(model, lr=5e-3, rng='native', seed=7)
     tm = ops.InsituTimer(d)
     with tm:

@@ -8,7 +8,7 @@ configs[0]'s 100 items and configs[3]'s CritLangAcq rows of 95; the planner's ch
 
 The other GPU modules pin one of the row-split kernels per fixture run (vibo_desc.flags), so their shapes never reach this
 kernel; here ops.DESC_FLAGS stays 0 and every case asserts that the planner picked it.
-Tolerances: ELBO <= 1e-4 relative, posterior <= 2e-5, gradients <= 3e-4 of the tensor's max-abs.
+Tolerances: ELBO <= 1e-4 relative, posterior <= 2e-5, gradients <= 1e-4 of the tensor's max-abs.
 """
 import os
 
@@ -160,7 +160,7 @@ def test_narrow_goldens_through_module(golden):
     golden.response, golden.mask = golden.response.to(d), golden.mask.to(d)
     golden.eps_item, golden.eps_ability = golden.eps_item.to(d), golden.eps_ability.to(d)
     outs, loss = run_reference_pattern(model, golden)
-    check_against_golden(model, golden, outs, loss, tol_loss=TOL_ELBO, tol_grad=3e-4, strict=True)
+    check_against_golden(model, golden, outs, loss, tol_loss=TOL_ELBO, tol_grad=1e-4, strict=True)
 
 
 def test_narrow_goldens_adam_trajectory_through_the_fused_trainer(golden):

@@ -6,8 +6,12 @@
      person-permutation invariance, bitwise determinism).
 
 Tolerances (fp32): ELBO <= 1e-4 relative (north_star), posterior
-mean / log-variance <= 2e-5, gradients <= 3e-4 of the tensor's max-abs.
+mean / log-variance <= 2e-5, gradients <= 1e-4 of the tensor's max-abs against the fp64 analytic oracle (TOL_GRAD; measured
+maximum over the suite 6.1e-6) -- goldens: see check_against_golden.
 """
+import json
+import os
+
 import pytest
 import torch
 
@@ -52,7 +56,7 @@ def test_golden_through_module(golden):
     golden.response, golden.mask = golden.response.to(d), golden.mask.to(d)
     golden.eps_item, golden.eps_ability = golden.eps_item.to(d), golden.eps_ability.to(d)
     outs, loss = run_reference_pattern(model, golden)
-    check_against_golden(model, golden, outs, loss, tol_loss=TOL_ELBO, tol_grad=3e-4, strict=True)
+    check_against_golden(model, golden, outs, loss, tol_loss=TOL_ELBO, tol_grad=1e-4, strict=True)
 
 
 def test_golden_adam_trajectory(golden):
@@ -141,7 +145,25 @@ def run_kernel(spec, resp, mask, table, item, eps, reg_mode=_lib.REG_KL, mask_dt
     return raw
 
 
-def compare_raw(raw, ref, item_shape, want_grad=True, tol=3e-4):
+# Gradient tolerances (fractions of the tensor's max-abs against the fp64 analytic oracle).  SURVEY.md section 8c asks for <= 1e-4;
+# TOL_GRAD is that bound and the default everywhere.  Named wider bands exist only where the fp64 oracle cannot arbitrate to 1e-4,
+# each with the reason and the maximum measured on the GPU (VIBO_TOL_RECORD=path appends every observed error to a JSON-lines
+# file; gpurun_out/r6_tolerances.jsonl is the record these numbers come from):
+TOL_GRAD = 1e-4
+_OBSERVED = []
+
+
+def _check(kind, err, tol):
+    if os.environ.get('VIBO_TOL_RECORD'):
+        _OBSERVED.append((kind, float(err), float(tol), os.environ.get('PYTEST_CURRENT_TEST', '')))
+        with open(os.environ['VIBO_TOL_RECORD'], 'a') as f:
+            f.write(json.dumps({'kind': kind, 'err': float(err), 'tol': float(tol), 'test': os.environ.get('PYTEST_CURRENT_TEST', '')}) + '\n')
+        if os.environ.get('VIBO_TOL_RECORD_ONLY'):
+            return
+    assert err < tol, (kind, err, tol)
+
+
+def compare_raw(raw, ref, item_shape, want_grad=True, tol=TOL_GRAD):
     sc = raw.scalars.cpu()
     assert rel_err(sc[_lib.S_LL], ref['ll']) < 2e-5
     assert abs(float(sc[_lib.S_REG]) - float(ref['reg'])) < 2e-5 * max(1.0, abs(float(ref['reg'])))
@@ -154,10 +176,10 @@ def compare_raw(raw, ref, item_shape, want_grad=True, tol=3e-4):
         for s in range(2):
             scale = float(ref['g_table'][s].abs().max())
             if scale > 0:
-                assert rel_err(raw.grad_table(s).cpu(), ref['g_table'][s]) < tol, f'g_table[{s}]'
+                _check(f'g_table[{s}]', rel_err(raw.grad_table(s).cpu(), ref['g_table'][s]), tol)
             else:
                 assert float(raw.grad_table(s).abs().max()) < 1e-6
-        assert rel_err(raw.grad_item(item_shape).cpu(), ref['g_item']) < tol
+        _check('g_item', rel_err(raw.grad_item(item_shape).cpu(), ref['g_item']), tol)
 
 
 SHAPES = [
@@ -305,14 +327,14 @@ def test_general_kernel_vs_oracle(irt, A, B, I, missing, cond, n_flows, drop):
                                eps.to(d).contiguous(), flow.to(d).contiguous() if flow is not None else None,
                                _lib.REG_SAMPLED if n_flows else _lib.REG_KL, True, B)
     torch.cuda.synchronize()
-    compare_raw(raw, ref, (I, spec.item_dim), tol=5e-4)
+    compare_raw(raw, ref, (I, spec.item_dim))
     if n_flows:
         assert (raw.ability_k.cpu() - ref['ability_k'].float()).abs().max() < 5e-5
         assert (raw.ability_ladj.cpu() - ref['ladj'].float()).abs().max() < 5e-5
         assert abs(float(raw.scalars[_lib.S_LADJ]) - float(ref['ladj_sum'])) < 1e-4 * max(1.0, abs(float(ref['ladj_sum'])))
         for s_ in range(2):
             gref = torch.cat([torch.cat(gf) for gf in ref['g_flow'][s_]]).float()
-            assert rel_err(raw.grad_flow(s_).cpu(), gref) < 5e-4
+            _check(f'g_flow[{s_}]', rel_err(raw.grad_flow(s_).cpu(), gref), TOL_GRAD)
 
 
 def test_sampled_regulariser_mode():
@@ -380,7 +402,7 @@ def test_all_missing_rows_and_saturated_logits():
                            exact_saturation=True)
     assert float((ref['logit'].abs() > 17).float().mean()) > 0.02      # the clamp really is exercised
     raw = run_kernel(spec, resp, mask, table, item, eps)
-    compare_raw(raw, ref, (I, spec.item_dim), tol=1e-3)
+    compare_raw(raw, ref, (I, spec.item_dim))
 
 
 @pytest.mark.parametrize('irt,A,scale', [(2, 1, 1e-4), (2, 8, 1e-4), (3, 2, 1e-4), (1, 4, 1e-4),
@@ -410,7 +432,7 @@ def test_item_scales_far_outside_the_f16_range(irt, A, scale):
     ref = T.fused_elbo_ref(table, item, resp, mask, eps, irt_model=irt, ability_dim=A, mode='kl', exact_saturation=True)
     raw = run_kernel(spec, resp, mask, table, item, eps)
     assert torch.isfinite(raw.flat).all()
-    compare_raw(raw, ref, (I, spec.item_dim), tol=max(3e-4, 1e-6 * scale))
+    compare_raw(raw, ref, (I, spec.item_dim), tol=max(TOL_GRAD, 1e-6 * scale))      # (measured: 2.1e-4 at scale 1e3, 1.5e-5 at 1e5, 8.5e-6 at 1e-4)
 
 
 def test_operands_beyond_the_rescaling_range_fail_loudly():
@@ -433,7 +455,6 @@ def test_saturation_golden_through_kernel():
     """One person (theta = 0 => logit = b_i), items with difficulties on the
     reference's saturation probe grid: per-item gradients must be exactly zero where
     the reference's are."""
-    import os
     import numpy as np
     from conftest import GOLDEN_DIR
     z = np.load(os.path.join(GOLDEN_DIR, 'saturation.npz'))
@@ -698,7 +719,7 @@ def test_config5_pipeline_at_the_planner_large_call_size(codes, P):
     ref = T.fused_elbo_ref(table.cpu().double(), item.cpu().double(), resp[:n].cpu().double(), mask[:n].cpu(),
                            eps[:n].cpu().double(), irt_model=irt, ability_dim=A, conditional_posterior=True, mode='sampled',
                            flow_uhat_w_b=flows)
-    compare_raw(run(allrows[:n]), ref, (I, spec.item_dim), tol=5e-4)
+    compare_raw(run(allrows[:n]), ref, (I, spec.item_dim))
     for k, t in (('ability_mu', full.ability_mu), ('ability_logvar', full.ability_logvar), ('ability', full.ability),
                  ('ability_k', full.ability_k)):
         assert (t[:n].cpu() - ref[k].float()).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
@@ -830,7 +851,7 @@ def test_matrix_pipe_passes_of_the_conditional_posterior(irt, A, B, I, n_flows, 
 
     a, b = run(_lib.FLAG_COND_MATRIX), run(_lib.FLAG_COND_MATRIX)
     assert torch.equal(a.flat, b.flat) and torch.equal(a.ability_mu, b.ability_mu)
-    compare_raw(a, ref, (I, spec.item_dim), tol=5e-4)
+    compare_raw(a, ref, (I, spec.item_dim))
     v = run(_lib.FLAG_COND_VALU)
     assert (a.ability_mu - v.ability_mu).abs().max() < 1e-5 * max(1.0, float(v.ability_mu.abs().max()))
     assert (a.ability_logvar - v.ability_logvar).abs().max() < 1e-5 * max(1.0, float(v.ability_logvar.abs().max()))
@@ -886,7 +907,7 @@ def test_ragged_item_count_with_padded_row_strides(irt, A, I, cond, n_flows):
                                    eps.to(d).contiguous(), flow.to(d).contiguous() if flow is not None else None,
                                    _lib.REG_SAMPLED if n_flows else _lib.REG_KL, True, B)
         torch.cuda.synchronize()
-        compare_raw(raw, ref, (I, spec.item_dim), tol=5e-4)
+        compare_raw(raw, ref, (I, spec.item_dim))
 
 
 # ---------------------------------------------------------------------------

@@ -85,10 +85,20 @@ def check_against_golden(model, golden, outs, loss, tol_loss=1e-4, tol_grad=3e-4
                 # tol of the reference's gradient.  No allowance added on top of either.
                 e_truth, e_ref = rel_err(g, truth[name]), rel_err(g, g_ref)
                 ref_off = rel_err(g_ref, truth[name])
-                # (one golden, 3pl_a8_uncond_mean_miss: the reference's own fp32 gradient of the mean-merge encoder's first
-                #  layer is 3 % away from the exact one -- saturated 3PL cells; a tensor the reference gets that wrong is held to
-                #  a tenth of the reference's own error instead)
-                tol = tol_grad if ref_off < 1e-2 else max(tol_grad, 0.1 * ref_off)
+                # (one golden, 3pl_a8_uncond_mean_miss: the reference's own fp32 gradients are 3-18 % away from the exact ones --
+                #  saturated 3PL cells; a tensor the reference gets that wrong is held to 6 % of the reference's own error instead)
+                # Measured on the GPU over all goldens x kernel pins (gpurun_out/r6_tolerances_golden.jsonl, round 6): every tensor of
+                # every golden but one is within 2.9e-5; the one is 3pl_a8_uncond_mean_miss, whose cells sit inside the probability
+                # clamp band -- there the measured distance to the reference is <= 0.053 x the reference's own distance to fp64.
+                clamp_band = ref_off >= 1e-2
+                if clamp_band:
+                    assert m['irt_model'] == 3, (name, 'only the saturated 3PL golden may use the clamp-band allowance', ref_off)
+                tol = tol_grad if not clamp_band else max(tol_grad, 0.06 * ref_off)
+                if os.environ.get('VIBO_TOL_RECORD'):
+                    import json
+                    with open(os.environ['VIBO_TOL_RECORD'], 'a') as f:
+                        f.write(json.dumps({'kind': 'golden:' + name, 'err': min(e_truth, e_ref), 'e_truth': e_truth, 'e_ref': e_ref, 'ref_off': ref_off,
+                                            'tol': tol, 'irt': m['irt_model'], 'test': os.environ.get('PYTEST_CURRENT_TEST', '')}) + '\n')
                 assert min(e_truth, e_ref) < tol, (name, e_truth, e_ref, ref_off)
                 continue
             assert rel_err(g, truth[name]) < tol_truth + rel_err(g_ref, truth[name]), name

@@ -33,7 +33,7 @@ for sh in a.shapes:
     if codes:
         resp, mask = ops.pack_cell_codes(resp, mask), None
     torch.manual_seed(1)
-    model = VIBO_2PL(A, I).to(d)
+    model = VIBO_2PL(A, I, ability_merge='product').to(d)
     tr = FusedTrainer(model, lr=5e-3, rng='native', seed=3)
     tm = ops.InsituTimer(d) if have_timer else None
     if tm:

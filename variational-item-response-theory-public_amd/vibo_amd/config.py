@@ -14,4 +14,5 @@ MISSING_DATA = -1   # responses use -1 for "missing"
 IS_REAL_WORLD = {
     '1pl_simulation': False, '2pl_simulation': False, '3pl_simulation': False,
     'critlangacq': True, 'duolingo': True, 'wordbank': True, 'pisa2015_science': True,
+    'score_matrix': True,       # (not in the reference: any pre-built [P, I] matrix, datasets.CachedScoreMatrix)
 }

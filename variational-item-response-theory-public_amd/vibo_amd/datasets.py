@@ -9,8 +9,13 @@ trainer can keep it resident in HBM and gather minibatch rows inside the kernel
 instead of collating per sample on the host.
 
 In scope (BASELINE.json): the {1,2,3}pl simulation datasets and CritLangAcq.
-The Duolingo / WordBank / PISA loaders of the reference are not part of this
-path and raise NotImplementedError.
+Duolingo / WordBank / PISA: the reference parses each raw corpus into a [P, I] score
+matrix (-1 = missing) ONCE and caches it as ``DATA_DIR/<dir>/score_matrix.npy``
+(datasets.py:505-515, 698-721, 751-817); every later run starts from that file.  This
+module starts from the same file (``CachedScoreMatrix``): the corpus parsers (nltk,
+per-cell Python loops) are not rebuilt, the split / shuffle / truncation / row-drop
+steps behind the cache are, loader by loader.  ``score_matrix`` is the same contract
+for any pre-built matrix.
 """
 import copy
 import os
@@ -48,9 +53,8 @@ def load_dataset(dataset_name, train=True, **kwargs):
         return IRTSimulation(train=train, irt_model=irt, nonlinear=nonlinear, **kwargs)
     if dataset_name == 'critlangacq':
         return Children_LanguageAcquisition(train=train, **kwargs)
-    if dataset_name in ('duolingo', 'wordbank', 'pisa2015_science'):
-        raise NotImplementedError(f'dataset {dataset_name}: loader not part of the MI355X ELBO path '
-                                  f'(any Dataset with .response/.mask [P,I] works with the trainer)')
+    if dataset_name in CachedScoreMatrix.RECIPES:
+        return CachedScoreMatrix(dataset_name, train=train, **kwargs)
     raise Exception(f'Dataset {dataset_name} is not supported.')
 
 
@@ -89,6 +93,71 @@ class _MatrixDataset(torch.utils.data.Dataset):
         r = self.response if self.response.ndim == 2 else self.response[:, :, 0]
         m = self.mask if self.mask.ndim == 2 else self.mask[:, :, 0]
         return np.ascontiguousarray(r, dtype=np.float32), np.ascontiguousarray(m != 0)
+
+
+class CachedScoreMatrix(_MatrixDataset):
+    """The reference's real-world loaders from their own cache (datasets.py:443-863), and any pre-built score matrix behind the
+    same ``(index, response, item_id, mask)`` contract:
+
+        name               cache file (DATA_DIR/...)            steps behind the cache (reference lines)
+        duolingo           duolingo/score_matrix.npy            round (binarize) -> RandomState(42) row shuffle -> 80/20 split ->
+                           (+ token_id.npy: item ids)           max_num_person / max_num_item -> drop all-missing rows   (:517-541)
+        wordbank           wordbankr/score_matrix.npy           80/20 split (NO shuffle) -> max_num_person / max_num_item (:654-672)
+        pisa2015_science   pisa2015_science/score_matrix.npy    shuffle -> split -> max_* -> drop all-missing rows        (:819-839)
+        score_matrix       score_matrix/score_matrix.npy        = pisa2015_science's steps, for a matrix of your own: float or
+                                                                 int [P, I], 1 = right, 0 = wrong, -1 = missing
+
+    The reference writes those files on its first run over the raw corpora (``make_score_matrix``: nltk tokenisation for
+    Duolingo, one ``np.where`` per cell for WordBank, a 40-way string match for PISA); that one-off parse is not rebuilt here --
+    without the cache this raises FileNotFoundError naming the file."""
+
+    RECIPES = {      # name: (directory, binarize, shuffle, drop all-missing rows)
+        'duolingo': ('duolingo', True, True, True),
+        'wordbank': ('wordbankr', False, False, False),
+        'pisa2015_science': ('pisa2015_science', False, True, True),
+        'score_matrix': ('score_matrix', False, True, True),
+    }
+
+    def __init__(self, name, train=True, max_num_person=None, max_num_item=None, **kwargs):
+        super().__init__()
+        sub, binarize, shuffle, drop = self.RECIPES[name]
+        path = os.path.join(config.DATA_DIR, sub, 'score_matrix.npy')
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f'{path}: the [P, I] score matrix (-1 = missing) the reference caches after parsing the raw {name} corpus '
+                f'(src/datasets.py); run the reference loader once, or place your own matrix there')
+        response = np.load(path)
+        if response.ndim != 2:
+            raise ValueError(f'{path}: expected a [P, I] matrix, found shape {response.shape}')
+        ids = os.path.join(config.DATA_DIR, sub, 'token_id.npy')
+        item_id = np.load(ids) if name == 'duolingo' and os.path.exists(ids) else np.arange(response.shape[1])
+        if binarize:
+            response = np.round(response)
+        if shuffle:
+            order = np.arange(response.shape[0])
+            np.random.RandomState(42).shuffle(order)
+            response = response[order]
+        n_train = int(0.8 * response.shape[0])
+        response = response[:n_train] if train else response[n_train:]
+        if max_num_person is not None:
+            response = response[:max_num_person]
+        if max_num_item is not None:
+            response = response[:, :max_num_item]
+            item_id = item_id[:max_num_item]
+        if drop:
+            response = response[~(np.sum(response, 1) == (-1 * response.shape[1]))]
+        mask = np.ones_like(response)
+        mask[response == -1] = 0
+        self.response, self.mask, self.item_id = response, mask, item_id
+        self.length = self.num_person = response.shape[0]
+        self.num_item = response.shape[1]
+
+    def __getitem__(self, index):
+        response = self.response[index]
+        item_id = np.array(self.item_id, copy=True)      # (Duolingo: its token ids, datasets.py:625; the others: 0..I-1)
+        item_id[response == -1] = -1
+        return (index, torch.from_numpy(response).float().unsqueeze(1), torch.from_numpy(item_id).long().unsqueeze(1),
+                torch.from_numpy(self.mask[index]).bool().unsqueeze(1))
 
 
 class IRTSimulation(_MatrixDataset):

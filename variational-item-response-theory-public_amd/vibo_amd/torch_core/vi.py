@@ -30,7 +30,7 @@ def build_parser():
     p.add_argument('--irt-model', type=str, default='1pl', choices=['1pl', '2pl', '3pl'])
     p.add_argument('--dataset', type=str, default='1pl_simulation',
                    choices=['1pl_simulation', '2pl_simulation', '3pl_simulation', 'critlangacq', 'duolingo', 'wordbank',
-                            'pisa2015_science'])
+                            'pisa2015_science', 'score_matrix'])
     p.add_argument('--ability-dim', type=int, default=1)
     p.add_argument('--artificial-missing-perc', type=float, default=0.)
     p.add_argument('--num-person', type=int, default=1000)

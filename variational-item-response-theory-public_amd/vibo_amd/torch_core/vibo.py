@@ -37,7 +37,7 @@ def build_parser():
     p.add_argument('--irt-model', type=str, default='1pl', choices=['1pl', '2pl', '3pl'])
     p.add_argument('--dataset', type=str, default='1pl_simulation',
                    choices=['1pl_simulation', '2pl_simulation', '3pl_simulation', 'critlangacq',
-                            'duolingo', 'wordbank', 'pisa2015_science'])
+                            'duolingo', 'wordbank', 'pisa2015_science', 'score_matrix'])
     p.add_argument('--ability-dim', type=int, default=1)
     p.add_argument('--ability-merge', type=str, default='product', choices=['mean', 'product', 'transformer'])
     p.add_argument('--conditional-posterior', action='store_true', default=False)
@@ -123,8 +123,6 @@ def check_supported(args):
         problems.append("--ability-merge mean with --ability-dim above 8 (its caller-supplied posterior needs the row-split kernels)")
     if args.response_dist != 'bernoulli':
         problems.append("--response-dist gaussian (the reference's loader has no *_continuous datasets either)")
-    if args.dataset in ('duolingo', 'wordbank', 'pisa2015_science'):
-        problems.append(f"--dataset {args.dataset} (loader not part of this engine: simulation and critlangacq are)")
     if problems:
         raise SystemExit('not supported by the MI355X engine: ' + '; '.join(problems))
 
@@ -528,19 +526,47 @@ def main(argv=None):
 
     if world > 1:
         dist.barrier()
-    if rank == 0:      # post-hoc enrichment (rank 0, on the whole split)
+    # ---- post-hoc enrichment of both checkpoints (vibo.py:490-558).  Person-sharded: the per-person posteriors of `infer_dict` are
+    #      computed by every rank on ITS shard and all-gathered in rank order (contiguous shards: = the split's own order) -- the
+    #      O(P x I) encode pass is not repeated over the whole split on rank 0.  The sampled enrichments
+    #      (posterior predictive, log marginal: per-batch noise streams of the model's generators, batch-level importance weights)
+    #      stay on rank 0 over the whole split, where they draw exactly what a one-GPU run draws.
+    names = [n for n in ('checkpoint.pth.tar', 'model_best.pth.tar') if os.path.exists(os.path.join(args.out_dir, n))]
+    if world > 1:
+        flag = torch.tensor([len(names)], device=device)
+        dist.broadcast(flag, 0)              # (every rank sees the same files on a shared file system; rank 0's view decides)
+        names = ['checkpoint.pth.tar', 'model_best.pth.tar'][:int(flag)]
+    sharded_infer = {}
+    if world > 1 and not args.no_infer_dict:
+        sizes = [(r + 1) * train_dataset.num_person // world - r * train_dataset.num_person // world for r in range(world)]
+        for name in names:
+            sd = [torch.load(os.path.join(args.out_dir, name), weights_only=False)['model_state_dict']] if rank == 0 else [None]
+            dist.broadcast_object_list(sd, 0)
+            model.load_state_dict(sd[0])
+            saved_reducer, model._reducer = model._reducer, None      # evaluation is local
+            part = infer_dict(model, train, local_bs)
+            model._reducer = saved_reducer
+            whole = {}
+            for key in ('ability_mu', 'ability_logvar'):
+                t = part[key].to(device)
+                buf = torch.zeros(max(sizes), t.shape[1], device=device, dtype=t.dtype)
+                buf[:t.shape[0]] = t
+                out = [torch.empty_like(buf) for _ in range(world)]
+                dist.all_gather(out, buf)
+                whole[key] = torch.cat([o[:n] for o, n in zip(out, sizes)], 0).cpu()
+            whole['item_feat_mu'], whole['item_feat_logvar'] = part['item_feat_mu'], part['item_feat_logvar']
+            sharded_infer[name] = whole
+    if rank == 0:
         if world > 1:
             train, test = ResidentSplit(train_dataset, device, None, row_format), ResidentSplit(test_dataset, device, None, row_format)
             local_bs = args.batch_size
-        for name in ('checkpoint.pth.tar', 'model_best.pth.tar'):
+        for name in names:
             path = os.path.join(args.out_dir, name)
-            if not os.path.exists(path):
-                continue
             ckpt = torch.load(path, weights_only=False)
             model.load_state_dict(ckpt['model_state_dict'])
             saved_reducer, model._reducer = model._reducer, None      # evaluation is local
             if not args.no_infer_dict:
-                ckpt['infer_dict'] = infer_dict(model, train, local_bs)
+                ckpt['infer_dict'] = sharded_infer[name] if name in sharded_infer else infer_dict(model, train, local_bs)
             if not args.no_predictive:
                 pp = posterior_predictive(model, train, args, local_bs, args.store_predictive_samples)
                 ckpt['posterior_predict_samples'] = pp
