@@ -350,8 +350,45 @@ struct CmRawPiece {        // the 16 cells at items [i0, i0 + 16) of one row
     float4 x[4];
     uint4 m;
 };
-__device__ __forceinline__ uint4 cm_codes_of(const CmRawPiece& r) {
-    return uint4{cell_codes4(r.x[0], r.m.x), cell_codes4(r.x[1], r.m.y), cell_codes4(r.x[2], r.m.z), cell_codes4(r.x[3], r.m.w)};
+// Lane layout of the raw cells (round 6).  A lane's four float4 used to be 64 contiguous bytes of its row: per load instruction the
+// four lanes of a row then touched four different 64-byte blocks -- 64 blocks per wave instruction, a quarter of each used, and
+// the address path of the texture unit handles one 64-byte block per quad and cycle (cm_forward_fp32 streamed 3.6 TB/s where the
+// VALU count-and-emit pass of the same bytes runs 5.4).  Now load k of lane (row, piece) reads the 16 bytes at 64 k + 16 piece of
+// the step's 256-byte row segment: the four lanes of a row share ONE contiguous 64-byte block per instruction.  The lane then
+// holds cells 16 k + 4 piece .. + 3 (k = 0..3) instead of 16 piece .. 16 piece + 15: the four "answered right" byte words are
+// transposed inside the quad (two DPP exchange stages) back to the contiguous layout -- where the mask bytes (one 16-byte
+// load, already contiguous per row), the emitted code row and the operand permutation expect them.
+__device__ __forceinline__ uint32_t cm_answer4(const float4 x) {         // byte b = byte 3 of cell b (0x3F: 1.0, 0x00: 0.0)
+    const uint32_t x0 = __builtin_bit_cast(uint32_t, x.x), x1 = __builtin_bit_cast(uint32_t, x.y);
+    const uint32_t x2 = __builtin_bit_cast(uint32_t, x.z), x3 = __builtin_bit_cast(uint32_t, x.w);
+    return __builtin_amdgcn_perm(x1, x0, 0x0c0c0703u) | __builtin_amdgcn_perm(x3, x2, 0x07030c0cu);
+}
+// 4 x 4 transpose of dwords inside every quad of lanes: lane p, register k  <->  lane k, register p
+__device__ __forceinline__ void cm_quad_transpose4(uint32_t (&a)[4], const bool bit1, const bool bit0) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                    // 2 x 2 blocks across lanes p ^ 2
+        const uint32_t send = bit1 ? a[k] : a[k + 2];
+        const uint32_t recv = (uint32_t)dpp_i<0x4e>((int)send);       // quad_perm [2,3,0,1]
+        a[k] = bit1 ? recv : a[k];
+        a[k + 2] = bit1 ? a[k + 2] : recv;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {                 // inside the blocks across lanes p ^ 1
+        const uint32_t send = bit0 ? a[k] : a[k + 1];
+        const uint32_t recv = (uint32_t)dpp_i<0xb1>((int)send);       // quad_perm [1,0,3,2]
+        a[k] = bit0 ? recv : a[k];
+        a[k + 1] = bit0 ? a[k + 1] : recv;
+    }
+}
+// -> the lane's 16 CONTIGUOUS cell codes (items 16 piece .. 16 piece + 15 of the step; 0 wrong / 1 right / 2 missing: cell_codes4)
+__device__ __forceinline__ uint4 cm_codes_of(const CmRawPiece& r, const bool bit1, const bool bit0) {
+    uint32_t hb[4] = {cm_answer4(r.x[0]), cm_answer4(r.x[1]), cm_answer4(r.x[2]), cm_answer4(r.x[3])};
+    cm_quad_transpose4(hb, bit1, bit0);
+    const uint32_t mm[4] = {r.m.x, r.m.y, r.m.z, r.m.w};
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = (hb[k] & mm[k] & 0x01010101u) | ((mm[k] ^ 0x01010101u) << 1);
+    return uint4{c[0], c[1], c[2], c[3]};
 }
 constexpr int kCmF32MT = 2;            // M-tiles (16 persons) per compute wave of cm_forward_fp32_kernel
 template <bool COUNT, bool MAL /* mask rows 16-byte aligned */>
@@ -414,8 +451,9 @@ __global__ __launch_bounds__(320, 1) void cm_forward_fp32_kernel(const float* __
         const int i0 = 64 * (S < nFull ? S : nFull - 1) + 16 * lpiece;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const float4* xp = reinterpret_cast<const float4*>(rpx[mt] + i0);
-            w[mt].x[0] = xp[0]; w[mt].x[1] = xp[1]; w[mt].x[2] = xp[2]; w[mt].x[3] = xp[3];
+            // (load k: the 16 bytes at 64 k + 16 piece of the step's 256-byte row segment -- see cm_codes_of)
+            const float4* xp = reinterpret_cast<const float4*>(rpx[mt] + (i0 - 12 * lpiece));
+            w[mt].x[0] = xp[0]; w[mt].x[1] = xp[4]; w[mt].x[2] = xp[8]; w[mt].x[3] = xp[12];
             if (mask) {
                 if constexpr (MAL) w[mt].m = *reinterpret_cast<const uint4*>(rpm[mt] + i0);
                 else {
@@ -470,7 +508,7 @@ __global__ __launch_bounds__(320, 1) void cm_forward_fp32_kernel(const float* __
     auto run = [&](const int S, const CmRawPiece (&raw)[MT]) {
         uint4 wl[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) wl[mt] = cm_codes_of(raw[mt]);
+        for (int mt = 0; mt < MT; ++mt) wl[mt] = cm_codes_of(raw[mt], (lane & 2) != 0, (lane & 1) != 0);
         step(S, wl);
     };
     int S = 0;
