@@ -228,6 +228,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // resource has no records (its loads return zeros) and the cells are switched on when they are packed (`fillw`).
     // Gathered rows compute their addresses at the load.  Chunks past the row's end read its last chunk; both cases are
     // masked when the cells are packed.
+    // (Round 6 measured the lane's two chunks ADJACENT -- 2 i16 and 2 i16 + 1, the two mask words one 8-byte load: 24 load
+    //  instructions per batch instead of 32, 8 instead of 16 on cell codes.  Cell codes 670 -> 657 us per 1M x 1k, but fp32 rows
+    //  942-957 -> 972 us: every 16-byte response load then covers 512 bytes of a row at half density.  Not adopted.)
     const int cc0 = min(32 * q + i16, n4 - 1), cc1 = min(32 * q + 16 + i16, n4 - 1);
     const unsigned rstride4 = (unsigned)p.resp_stride * 4u, mstride = (unsigned)p.mask_stride;      // bytes per row
     const unsigned mvo0 = 4u * g * mstride + 4u * cc0, mvo1 = 4u * g * mstride + 4u * cc1;
@@ -979,7 +982,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         // The two waves of a SIMD (q and q + 4) run the same stream; the arbiter favours the older one, which then reaches the
         // batch's barrier ~4 000 cycles early while the other finishes alone at a single wave's issue rate (phase timing:
         // 12.4 k vs 16.2 k cycles per batch).  Swapping the leader every tile keeps the pair within a tile of each other.
-        // (A/B on one box, ability_dim 8: 1.053 ms against 1.076 without; swapping every half tile 1.071, every two tiles 1.065)
+        // (A/B on one box, ability_dim 8: 1.053 ms against 1.076 without; swapping every half tile 1.071, every two tiles 1.065.
+        //  Round 6: the alternation has no restoring force -- a wave one tile ahead of its partner sits in a tile of the SAME
+        //  priority, the tie goes to the older wave -- and waves 0-3 do reach the barrier ~3 k cycles before waves 4-7; a feedback
+        //  form -- every wave publishes its tile counter in LDS, reads its partner's, the one behind takes the priority -- was
+        //  built and measured: 952 -> 1 112 us per 1M x 1k call, the eight extra LDS round trips and scalar compares per batch
+        //  cost far more than the balance wins.)
         // (s_setprio takes an immediate: set one value, skip the other for half of the waves -- one short forward branch)
         if constexpr (((u * 4 + t) & 1) != 0)
             asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio 0\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio 1\n.Lmsprio%=:" :: "s"(q) : "scc");
