@@ -195,7 +195,7 @@ def cpu_baseline(args, irt):
     }
 
 
-PROFILE_FILE = 'r05_bench_profile.txt'      # rocprofv3 summary of this command on this round's build (tools/collect_profile.sh)
+PROFILE_FILE = 'r06_bench_profile.txt'      # rocprofv3 summary of this command on this round's build (tools/collect_profile.sh)
 
 
 def parse_traffic(kernel_tag):
@@ -651,7 +651,7 @@ def main():
                 'ms': ms, 'terms_per_s': Bd * I / (ms * 1e-3), 'algorithmic_TFLOPs': flop / (ms * 1e-3) / 1e12,
                 'bound': 'mfma + valu', 'mfma_issued_TFLOPs': 3 * flop / (ms * 1e-3) / 1e12, 'mfma_peak_f16_dense_TFLOPs': 2500.0,
                 'mfma_issue_frac_of_f16_peak': 3 * flop / (ms * 1e-3) / 1e12 / 2500.0,
-                'mfma_util_profile': 'SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles: profiles/r02_decoder_pmc.txt (17 %)'}
+                'mfma_util_profile': 'SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles: profiles/r06_decoder_pmc.txt (20.9 % on the shipped kernel; round 2: 17.1 %)'}
 
     def config5_probe():
         """BASELINE configs[4] LITERALLY where the GPU's memory allows (3PL, 1 000 000 persons x 10 000 items, conditional posterior, 4
