@@ -346,6 +346,9 @@ __global__ __launch_bounds__(320, NT == 1 ? 4 : 1) void cm_forward_kernel(const 
 // passes that follow (minibatch order) and go on as cm_forward_kernel<1> does.  One N-tile only (2A + 1 <= 16 columns; 8 dims
 // count with the code words).  A compute wave owns 32 persons (two M-tiles) and keeps three steps of raw cells in flight
 // (3 x 40 registers: at five waves per workgroup a wave has 256).
+// (Round 6: two steps in flight at 136 registers = TWO workgroups per CU measured the same 1.38 ms per 1M x 1k x 8 dims as three steps
+//  and one workgroup (1.36): the pass is not latency-bound per CU.  It moves 5 GB in + 1 GB out at 4.4 TB/s where the VALU
+//  count-and-emit pass -- whole rows per wave -- reaches 5.4: a wave here touches 16 rows x 256 bytes per step.)
 struct CmRawPiece {        // the 16 cells at items [i0, i0 + 16) of one row
     float4 x[4];
     uint4 m;
