@@ -989,7 +989,18 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         //  built and measured: 952 -> 1 112 us per 1M x 1k call, the eight extra LDS round trips and scalar compares per batch
         //  cost far more than the balance wins.)
         // (s_setprio takes an immediate: set one value, skip the other for half of the waves -- one short forward branch)
-        if constexpr (((u * 4 + t) & 1) != 0)
+        if constexpr (CODES) {
+            // Cell-code rows (round 6): priority FALLS with the wave's own progress through the batch (4 levels) -- a wave that has
+            // run ahead of its SIMD partner sits at a lower level than the partner: a restoring force without communication (the
+            // alternation below has none: a wave one tile ahead sits in a tile of the same priority and wins the tie by age).
+            // At equal progress the two staircases are offset by one tile, so the lead still alternates.  Same-box A/B, 1M x 1k:
+            // cell codes 671 -> 645 us (-3.9 %); fp32 rows 817 -> 832 (ability_dim 1), ~930 -> 965 (8): they keep the alternation
+            // (their tiles carry the next batch's row loads; what the ramp does to those was not looked into).
+            constexpr int n = u * 4 + t;
+            constexpr int pa = 3 - ((n + 1) >> 1) < 0 ? 0 : 3 - ((n + 1) >> 1);      // waves 0-3 (the older ones: they win ties)
+            constexpr int pb = 3 - (n >> 1);                                            // waves 4-7
+            asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio %1\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio %2\n.Lmsprio%=:" :: "s"(q), "n"(pa), "n"(pb) : "scc");
+        } else if constexpr (((u * 4 + t) & 1) != 0)
             asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio 0\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio 1\n.Lmsprio%=:" :: "s"(q) : "scc");
         else
             asm volatile("s_bitcmp1_b32 %0, 2\n\ts_setprio 1\n\ts_cbranch_scc0 .Lmsprio%=\n\ts_setprio 0\n.Lmsprio%=:" :: "s"(q) : "scc");
