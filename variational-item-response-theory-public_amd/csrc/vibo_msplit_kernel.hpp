@@ -995,7 +995,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             // alternation below has none: a wave one tile ahead sits in a tile of the same priority and wins the tie by age).
             // At equal progress the two staircases are offset by one tile, so the lead still alternates.  Same-box A/B, 1M x 1k:
             // cell codes 671 -> 645 us (-3.9 %); fp32 rows 817 -> 832 (ability_dim 1), ~930 -> 965 (8): they keep the alternation
-            // (their tiles carry the next batch's row loads; what the ramp does to those was not looked into).
+            // (their tiles carry the next batch's row loads).  Three more staircases were measured on fp32 rows -- restarting per
+            // u-step 840 / 984 us, the offset given to the older waves 823 / 957, two levels 822 / 954, against 818 / 960 for the
+            // alternation (ability_dim 1 / 8): none wins there.
             constexpr int n = u * 4 + t;
             constexpr int pa = 3 - ((n + 1) >> 1) < 0 ? 0 : 3 - ((n + 1) >> 1);      // waves 0-3 (the older ones: they win ties)
             constexpr int pb = 3 - (n >> 1);                                            // waves 4-7
