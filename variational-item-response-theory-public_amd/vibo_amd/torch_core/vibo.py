@@ -80,7 +80,9 @@ def build_parser():
                         "the library's Philox generator drawn inside the prologue kernel (two launches fewer per step)")
     p.add_argument('--graph-module-step', action='store_true', default=False,
                    help='replay the module + autograd + Adam step of the configurations outside the fused trainer (conditional '
-                        'posterior, flows, mean merge, MLP decoders) from a hipGraph too; verified for small problems only (DESIGN.md 4)')
+                        'posterior, flows, mean merge, MLP decoders) from a hipGraph too; verified for small problems only: on this '
+                        'PyTorch-ROCm stack a replayed autograd backward returns wrong bias gradients once a dense layer has a few '
+                        'thousand rows (pure-PyTorch repro: tools/repro_graph_replay_bias_grad.py; DESIGN.md 4)')
     p.add_argument('--no-graph', action='store_true', default=False,
                    help='launch every fused train step eagerly instead of replaying a hipGraph (single-GPU runs)')
     p.add_argument('--store-predictive-samples', action='store_true', default=False,
@@ -491,7 +493,9 @@ def main(argv=None):
     # step exactly in every configuration tests/test_gpu_trainer.py replays 60-150 times, but on this PyTorch / ROCm stack a
     # replayed autograd backward starts returning a wrong 64-float bias gradient after 7-15 replays once a dense PyTorch
     # layer in the step has a few thousand rows (the conditional posterior's 2 x I-row encoder table from 2 048 rows, the
-    # `deep` decoder's item network at 1 500) -- DESIGN.md section 4.  Until that is understood the default is the eager step.
+    # `deep` decoder's item network at 1 500) -- DESIGN.md section 4.  Round 6 isolated it: pure PyTorch shows the same fault
+    # (tools/repro_graph_replay_bias_grad.py: 8 192 rows wrong from replay 22 on, also with frozen parameters) -- a fault of the
+    # PyTorch-ROCm hipGraph stack, not of this library's launches.  The default stays the eager step.
     module_graph = trainer is None and args.cuda and world == 1 and not args.no_graph and args.graph_module_step
     # (capturable: Adam's step counter and bias corrections stay on the device -- required inside a captured graph)
     # (fused: one multi-tensor launch for all parameters instead of ~40 small ones; same update rule)
