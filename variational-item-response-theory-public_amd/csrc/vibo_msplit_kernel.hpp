@@ -606,6 +606,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         // (pinned here: hipcc otherwise sinks the whole pack to the end of the batch, and the next loads take new registers)
         asm volatile("" : "+v"(cw0[4 * h + j]), "+v"(cw1[4 * h + j]), "+v"(pk[j]));
     };
+    auto pack_one = [&](const int bt, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
+                        const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8]) __attribute__((always_inline)) {
+        const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
+        if (need_in && left < R) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m);
+        else pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m);
+    };
     auto pack_half = [&](const int bt, const int h, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
                          const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8]) {
         const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
@@ -1351,13 +1357,42 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         f32x4 da0, da1, db0, db1;
         logits(bopA, da0, da1);
-        tile(IC0{}, IC0{}, da0, da1, db0, db1, cwA0, bopB, bopA);     // (reads the operand of (0, 2) into bopA, ...)
-        tile(IC0{}, IC1{}, db0, db1, da0, da1, cwA0, bopA, bopB);
-        tile(IC0{}, IC2{}, da0, da1, db0, db1, cwA0, bopB, bopA);
-        tile(IC0{}, IC3{}, db0, db1, da0, da1, cwA0, bopA, bopB);
-        MS_T(0)
-        pack_a_burst_b();
-        MS_T(1)
+        if constexpr (!CODES) {
+            // fp32 rows (round 6): the next batch's M-tile 0 quarter j is packed, and its M-tile 1 quarter j requested into the
+            // registers that frees, IN FRONT OF tile (0, j) -- four load instructions per tile instead of a burst of sixteen behind
+            // tile (0, 3).  The CU's address path takes a load instruction per ~16 cycles: when the eight waves' bursts meet there,
+            // each wave sits in its burst for 1.3-2.6 k cycles (tools/ms_timing.py, `pack0`; under a priority scheme that keeps
+            // the wave pairs level: 3.3 k) and cannot issue anything else meanwhile.  Same-box A/B, 1M x 1k: ability_dim 8
+            // 876 -> 861 / 950 -> 916 us (two boxes), ability_dim 1 822 -> 800; 125 000 x 1 000 124.5 -> 120.4.  Cell codes
+            // (4-byte loads) measured the other way round, 645 -> 691 us, and keep the burst.  Also measured: the M-tile 0 requests
+            // spread over tiles (1, j) as well -- loads in flight across the loop's back edge -- +-0 against this (885 vs 884,
+            // 809 vs 803); the slower wave group (4-7) issuing its M-tile 0 burst behind the first barrier: 863 vs 858, 810 vs 805.
+            auto side = [&](const int j) __attribute__((always_inline)) {
+                pack_one(nxt, 0, j, cwB0, cwB1, pk, x, m);
+                __builtin_amdgcn_sched_barrier(0);
+                load_quarter(nxt, sn, 1, j, x, m);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            side(0);
+            tile(IC0{}, IC0{}, da0, da1, db0, db1, cwA0, bopB, bopA);     // (reads the operand of (0, 2) into bopA, ...)
+            side(1);
+            tile(IC0{}, IC1{}, db0, db1, da0, da1, cwA0, bopA, bopB);
+            side(2);
+            tile(IC0{}, IC2{}, da0, da1, db0, db1, cwA0, bopB, bopA);
+            side(3);
+            tile(IC0{}, IC3{}, db0, db1, da0, da1, cwA0, bopA, bopB);
+            MS_T(0)
+            fetch_eps(nxt, par ^ 1);                  // (complete by the second pack: free to carry across the back edge)
+            MS_T(1)
+        } else {
+            tile(IC0{}, IC0{}, da0, da1, db0, db1, cwA0, bopB, bopA);
+            tile(IC0{}, IC1{}, db0, db1, da0, da1, cwA0, bopA, bopB);
+            tile(IC0{}, IC2{}, da0, da1, db0, db1, cwA0, bopB, bopA);
+            tile(IC0{}, IC3{}, db0, db1, da0, da1, cwA0, bopA, bopB);
+            MS_T(0)
+            pack_a_burst_b();
+            MS_T(1)
+        }
         tile(IC1{}, IC0{}, da0, da1, db0, db1, cwA1, bopB, bopA);
         tile(IC1{}, IC1{}, db0, db1, da0, da1, cwA1, bopA, bopB);
         tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1, bopB, bopA);     // (... of the next batch's (0, 0) into bopA)
