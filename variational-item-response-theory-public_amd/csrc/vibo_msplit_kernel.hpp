@@ -1357,15 +1357,16 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         f32x4 da0, da1, db0, db1;
         logits(bopA, da0, da1);
-        if constexpr (RM == 0) {
-            // fp32 rows in order (round 6): the next batch's M-tile 0 quarter j is packed, and its M-tile 1 quarter j requested into the
+        if constexpr (RM == 0 && IRT != 3) {
+            // fp32 rows in order, 1PL / 2PL (round 6): the next batch's M-tile 0 quarter j is packed, and its M-tile 1 quarter j requested into the
             // registers that frees, IN FRONT OF tile (0, j) -- four load instructions per tile instead of a burst of sixteen behind
             // tile (0, 3).  The CU's address path takes a load instruction per ~16 cycles: when the eight waves' bursts meet there,
             // each wave sits in its burst for 1.3-2.6 k cycles (tools/ms_timing.py, `pack0`; under a priority scheme that keeps
             // the wave pairs level: 3.3 k) and cannot issue anything else meanwhile.  Same-box A/B, 1M x 1k: ability_dim 8
             // 876 -> 861 / 950 -> 916 us (two boxes), ability_dim 1 822 -> 800; 125 000 x 1 000 124.5 -> 120.4.  Cell codes
             // (4-byte loads) and gathered fp32 rows (per-row addresses formed at the load) measured the other way round -- 645 -> 691 us,
-            // 1.23 -> 1.34 ms -- and keep the burst.  Also measured: the M-tile 0 requests
+            // 1.23 -> 1.34 ms -- and keep the burst, as does the 3PL tile (1.248 -> 1.259 ms).  Caller-supplied posterior 1.135 ->
+            // 1.105, forward only 0.970 -> 0.927, wide rows 1.654 -> 1.635.  Also measured: the M-tile 0 requests
             // spread over tiles (1, j) as well -- loads in flight across the loop's back edge -- +-0 against this (885 vs 884,
             // 809 vs 803); the slower wave group (4-7) issuing its M-tile 0 burst behind the first barrier: 863 vs 858, 810 vs 805.
             auto side = [&](const int j) __attribute__((always_inline)) {
