@@ -725,13 +725,28 @@ def main():
                 call()
             e1.record()
             torch.cuda.synchronize()
+            # a second pass with the in-situ timer armed: the fused kernel alone (the hook's own exit atomics -- one line shared by up
+            # to 1 020 workgroups of the narrow kernel -- lengthen the call, not the stamped interval: hence its own pass)
+            tm = ops.InsituTimer(dev)
+            with tm:
+                call()
+                torch.cuda.synchronize()
+                tm.reset()
+                for _ in range(5):
+                    call()
+                torch.cuda.synchronize()
+                ks = tm.read()
             ms = e0.elapsed_time(e1) / 5
             bpt = 5.0 + 12.0 * Ac / Ic
             out[name] = {'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3), 'bytes_per_term': bpt,
                          'roofline_frac': bpt * Pc * Ic / (ms * 1e-3) / 8e12, 'kernel': ops.plan_kernel(spec, Pc, Ic, code, True)}
+            if ks.get('launches') == 5:          # the fused kernel alone, by its own stamps (single-launch calls of the matrix / narrow kernels)
+                out[name]['kernel_ms_insitu'] = ks['mean_ms']
+                out[name]['kernel_roofline_frac'] = bpt * Pc * Ic / (ks['mean_ms'] * 1e-3) / 8e12
             del r, mk, r2, m8
-        out['note'] = ('one fused forward + backward call per shape, inputs resident, HIP events over 5 back-to-back calls (launch gaps '
-                       'included: the 8 000 x 100 call is launch-bound); fractions of the 8 TB/s roofline on 5 + 12 A / I bytes per term')
+        out['note'] = ('one fused forward + backward call per shape, inputs resident, HIP events over 5 back-to-back calls (kernel + the '
+                       'finalize launch + launch gaps: the 8 000 x 100 call is launch-bound); kernel_ms_insitu / kernel_roofline_frac = the fused '
+                       'kernel alone by its own entry / exit stamps; fractions of the 8 TB/s roofline on 5 + 12 A / I bytes per term')
         return out
 
     def conditional_probe():

@@ -124,7 +124,7 @@ const char* vibo_last_error_string(void);
 /*
  * Measurement hook: the fused kernel's own duration, measured by the kernel (no reference counterpart; bench.py's
  * `roofline.kernel_ms_insitu`).  HIP events cannot be recorded inside a replayed hipGraph and a tracer changes what it traces;
- * with a timer block set, every matrix row-split launch (VIBO_KERNEL_MATRIX) enqueued FROM THIS HOST THREAD afterwards -- eagerly
+ * with a timer block set, every matrix row-split or narrow-row launch (VIBO_KERNEL_MATRIX, VIBO_KERNEL_NARROW) enqueued FROM THIS HOST THREAD afterwards -- eagerly
  * or while a stream capture records it into a graph -- stamps its earliest workgroup entry and its latest workgroup exit on the
  * chip-wide 100 MHz clock (s_memrealtime) and the last workgroup to leave adds the difference to the block:
  *   block[3] sum of the launches' durations | block[4] launches | block[5] shortest | block[6] longest | block[7] the last one

@@ -105,6 +105,25 @@ def test_insitu_timer_counts_launches_and_matches_events():
     assert tm.read() == {'launches': 0}
 
 
+def test_insitu_timer_counts_narrow_kernel_launches():
+    """The narrow-row kernel (BASELINE configs[0] / [3] widths) carries the same stamps."""
+    d = dev()
+    P, I, A = 100_000, 96, 1
+    spec, r, m8, code, table, item, eps = _problem(P, I, A, d, seed=5)
+    assert ops.plan_kernel(spec, P, I, code, True).startswith('narrow')
+    call = lambda: ops._hip_launch_elbo(spec, r, m8, code, None, table, item, eps, None, _lib.REG_KL, True, P)
+    ref = call()
+    torch.cuda.synchronize()
+    tm = ops.InsituTimer(d)
+    with tm:
+        for _ in range(6):
+            got = call()
+        torch.cuda.synchronize()
+        k = tm.read()
+    assert k['launches'] == 6 and 0.002 < k['min_ms'] <= k['max_ms'] < 1.0
+    assert torch.equal(ref.flat.view(torch.int32), got.flat.view(torch.int32))
+
+
 def test_insitu_timer_inside_the_folded_train_step_graph():
     """The benchmark's use: the folded step captured as one hipGraph, the timer armed at capture time."""
     from vibo_amd.torch_core.models import VIBO_2PL

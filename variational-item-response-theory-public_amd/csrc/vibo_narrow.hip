@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * kNwWaves, narrow_waves_per_simd(AT, IL, IRT ==
     __shared__ NarrowLds sm;
 
     const int tid = threadIdx.x;
+    insitu_enter(p.insitu);                        // (measurement hook, vibo_set_insitu_timer: null unless a benchmark armed it)
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(64 * kNwWaves, narrow_waves_per_simd(AT, IL, IRT ==
             out[p.lay.off_item + (size_t)row * p.lay.i_pad + il] = t;
         }
     }
+    insitu_exit(p.insitu, gridDim.x);
 }
 
 template <int AT, int IRT, bool GRAD, int RM>
