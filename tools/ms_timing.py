@@ -11,12 +11,13 @@ lib = _lib.load() if hasattr(_lib, 'load') else ctypes.CDLL(os.path.join(ROOT, '
 SLOTS = 32
 n = 1024 * 8 * SLOTS
 buf = (ctypes.c_longlong * n)()
-fn = lib.vibo_debug_ms_timing_c if '--codes' in sys.argv else lib.vibo_debug_ms_timing      # (one buffer per translation unit)
+fn = (lib.vibo_debug_ms_timing_fc if ('--codes' in sys.argv and '--flows' in sys.argv) else
+      lib.vibo_debug_ms_timing_c if '--codes' in sys.argv else lib.vibo_debug_ms_timing)      # (one buffer per translation unit)
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = fn(buf, n)
 raw = np.frombuffer(buf, dtype=np.int64).reshape(1024, 8, SLOTS)[:256]
 t = raw[:, :, :12].astype(np.float64)
-nb = (P + 31) // 32 / 256
+nb = (P + 31) // 32 / (256 // max(1, (I + 1023) // 1024) if I > 1024 else 256)
 names = ['tiles u0', 'pack0', 'tiles u1', 'pack1', 'counts+gth', 'barrier A', 'forward', 'barrier B', 'read ops', 'backward', 'wait loads x2', 'issue loads x2']
 print('rc', rc, 'batches per workgroup %.1f' % nb)
 print('phase           ' + ''.join(f' wave{w:1d}  ' for w in range(8)) + '   (cycles per batch, mean over workgroups)')

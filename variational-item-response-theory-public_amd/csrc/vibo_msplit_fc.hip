@@ -6,3 +6,8 @@ hipError_t launch_elbo_msplit_fc(const ElboParams& p, int irt, bool grad, int nw
     return launch_msplit_rm<2, true>(p, irt, grad, nw, grid, s);
 }
 }  // namespace vibo
+#ifdef VIBO_MS_TIMING
+extern "C" int vibo_debug_ms_timing_fc(long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ms_timing), (size_t)n * sizeof(long long));
+}
+#endif
