@@ -1335,6 +1335,10 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             for (int j = 0; j < 4; ++j) load_quarter(nxt, sn, 1, j, x, m);
             __builtin_amdgcn_sched_barrier(0);
         };
+        // (Measured and left alone, round 6: these four requests woven one at a time between
+        // put_counts / put_gtheta / the cell-word moves of the previous iteration's tail, one batch
+        // further ahead -- 843.9 vs 838.7 us at 1M x 1000 A=8, 797 vs 796 at A=1: nothing; the same
+        // with the falling tile priority of the cell-code rows on top -- 858 / 806 us: slower.)
         burst_a();
         MS_T(4)
         __syncthreads();                              // counts of bt and d LL/d theta shares of bt - G are out
