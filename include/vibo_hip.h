@@ -99,7 +99,9 @@ enum { VIBO_FLAG_KERNEL_VALU = 1,     /* row-split work goes to the VALU kernel 
                                        *  narrow-row kernel, vibo_narrow.hip, which the planner picks for them otherwise)            */
        VIBO_FLAG_NO_EMIT_CODES = 4,   /* multi-pass paths re-read the fp32 rows instead of the first pass's cell codes */
        VIBO_FLAG_COND_VALU = 8,       /* conditional posterior: the VALU passes (vibo_cond.hip) instead of the matrix-pipe ones */
-       VIBO_FLAG_COND_MATRIX = 16 };  /* ... the matrix-pipe passes (vibo_cmean.hip) whatever the size, wherever the rows allow  */
+       VIBO_FLAG_COND_MATRIX = 16,    /* ... the matrix-pipe passes (vibo_cmean.hip) whatever the size, wherever the rows allow  */
+       VIBO_FLAG_COND_THREE_PASS = 32 };  /* conditional posterior at ability_dim 1: keep the separate first pass (cond_pre) instead of
+                                         folding it into the matrix row-split kernel */
 
 /* Which fused kernel vibo_elbo_fwd_bwd would launch for `d` (pointers assumed aligned): VIBO_KERNEL_*, or <0 on a bad
  * descriptor.  Lets a benchmark state which kernel its numbers belong to. */

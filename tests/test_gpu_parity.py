@@ -26,8 +26,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=[_lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU,
-                        _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_VALU],
-                ids=['matrix-kernels', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-planned-posterior'])
+                        _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_NO_EMIT_CODES | _lib.FLAG_COND_VALU, _lib.FLAG_KERNEL_VALU,
+                        _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX | _lib.FLAG_COND_THREE_PASS],
+                ids=['matrix-kernels', 'valu-kernels', 'matrix-kernel-fp32-passes', 'valu-kernel-planned-posterior', 'matrix-kernels-three-pass'])
 def row_split_kernel_choice(request, monkeypatch):
     """Every test here runs on both row-split kernels: the library's planner picks the matrix kernel (vibo_msplit_kernel.hpp)
     above 2 048 persons per call and the VALU kernel (vibo_split_kernel.hpp) below; vibo_desc.flags pins one for the whole test
@@ -36,7 +37,15 @@ def row_split_kernel_choice(request, monkeypatch):
     (VIBO_FLAG_NO_EMIT_CODES).  The conditional posterior's two passes have a matrix-pipe form (vibo_cmean.hip, the default
     from a call size that depends on ability_dim when the rows are cell codes, VIBO_FLAG_COND_MATRIX pins it) and a VALU form
     (vibo_cond.hip, VIBO_FLAG_COND_VALU): the first run pins the matrix-pipe form, the second and third the VALU form, the fourth
-    runs the VALU row-split kernel around whatever the planner picks."""
+    runs the VALU row-split kernel around whatever the planner picks.  Fifth run (tests of the conditional posterior only): at
+    ability_dim 1 on fp32 rows the first run's matrix kernel gathers the experts itself (its XM == 3); VIBO_FLAG_COND_THREE_PASS keeps
+    the separate first pass it replaced."""
+    if request.param & _lib.FLAG_COND_THREE_PASS:
+        cs = getattr(request.node, 'callspec', None)
+        params = cs.params if cs is not None else {}
+        about_cond = 'cond' in request.node.name.lower() or bool(params.get('cond')) or 'cond' in str(params.get('golden', ''))
+        if not about_cond:
+            pytest.skip('the three-pass pin only differs for the conditional posterior')
     monkeypatch.setattr(ops, 'DESC_FLAGS', request.param)
 
 TOL_ELBO = 1e-4

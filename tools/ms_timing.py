@@ -11,7 +11,8 @@ lib = _lib.load() if hasattr(_lib, 'load') else ctypes.CDLL(os.path.join(ROOT, '
 SLOTS = 32
 n = 1024 * 8 * SLOTS
 buf = (ctypes.c_longlong * n)()
-fn = (lib.vibo_debug_ms_timing_fc if ('--codes' in sys.argv and '--flows' in sys.argv) else
+fused = '--cond' in sys.argv and '--cond-three-pass' not in sys.argv and '--codes' not in sys.argv and '--flows' not in sys.argv and A == 1
+fn = (lib.vibo_debug_ms_timing_xa if fused else lib.vibo_debug_ms_timing_fc if ('--codes' in sys.argv and '--flows' in sys.argv) else
       lib.vibo_debug_ms_timing_c if '--codes' in sys.argv else lib.vibo_debug_ms_timing)      # (one buffer per translation unit)
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = fn(buf, n)

@@ -27,11 +27,12 @@ ap.add_argument('--given', action='store_true', help='caller-supplied per-person
 ap.add_argument('--codes', action='store_true', help='rows as 1-byte cell codes (VIBO_MASK_CODES, Format P) instead of fp32 + mask')
 ap.add_argument('--kernel', choices=['auto', 'matrix', 'valu'], default='auto', help='pin a row-split kernel (vibo_desc.flags)')
 ap.add_argument('--cond-valu', action='store_true', help='conditional posterior: the VALU passes (VIBO_FLAG_COND_VALU) instead of the matrix-pipe ones')
+ap.add_argument('--cond-three-pass', action='store_true', help='conditional posterior at ability_dim 1: the separate first pass (VIBO_FLAG_COND_THREE_PASS) instead of the one folded into the matrix kernel')
 ap.add_argument('--item-scale', type=float, default=1.0, help='scale of the N(0,1) item sample (larger: more logits past the Bernoulli clamp, i.e. more tiles on the slow path)')
 ap.add_argument('--init-like', action='store_true', help='item sample as a freshly initialised model draws it: mu + exp(.5 logvar) eps with mu, logvar, eps ~ N(0,1)')
 ap.add_argument('--cached-rows', type=int, default=0, help='gather rows from the first N rows only (L2-resident): compute-only timing')
 a = ap.parse_args()
-ops.DESC_FLAGS = {'auto': 0, 'matrix': _lib.FLAG_KERNEL_MATRIX, 'valu': _lib.FLAG_KERNEL_VALU}[a.kernel] | (_lib.FLAG_COND_VALU if a.cond_valu else 0)
+ops.DESC_FLAGS = {'auto': 0, 'matrix': _lib.FLAG_KERNEL_MATRIX, 'valu': _lib.FLAG_KERNEL_VALU}[a.kernel] | (_lib.FLAG_COND_VALU if a.cond_valu else 0) | (_lib.FLAG_COND_THREE_PASS if a.cond_three_pass else 0)
 d = torch.device('cuda:0')
 g = torch.Generator(device=d).manual_seed(0)
 P, I, A = a.persons, a.items, a.ability_dim

@@ -60,7 +60,8 @@ static int check_desc(const vibo_desc* d) {
     if (d->reg_mode != VIBO_REG_KL && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "bad reg_mode");
     if (d->n_flows < 0 || d->n_flows > VIBO_MAX_FLOWS) return fail(-3, "n_flows outside 0..%d", VIBO_MAX_FLOWS);
     if (d->n_flows > 0 && d->reg_mode != VIBO_REG_SAMPLED) return fail(-3, "flows need reg_mode SAMPLED");
-    if (d->flags & ~(VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX | VIBO_FLAG_NO_EMIT_CODES | VIBO_FLAG_COND_VALU | VIBO_FLAG_COND_MATRIX)) return fail(-3, "unknown flags");
+    if (d->flags & ~(VIBO_FLAG_KERNEL_VALU | VIBO_FLAG_KERNEL_MATRIX | VIBO_FLAG_NO_EMIT_CODES | VIBO_FLAG_COND_VALU | VIBO_FLAG_COND_MATRIX |
+                     VIBO_FLAG_COND_THREE_PASS)) return fail(-3, "unknown flags");
     if ((d->flags & VIBO_FLAG_KERNEL_VALU) && (d->flags & VIBO_FLAG_KERNEL_MATRIX)) return fail(-3, "flags pin two kernels");
     if ((d->flags & VIBO_FLAG_COND_VALU) && (d->flags & VIBO_FLAG_COND_MATRIX)) return fail(-3, "flags pin two forms of the conditional passes");
     return 0;
@@ -81,6 +82,7 @@ struct Plan {
     size_t off_cnt;           // panel mode: per-person packed counts of the whole row
     bool cond;                // panel mode with the conditional posterior: cond_pre / split / cond_post per panel
     bool cmat_pre, cmat_post; // ... whose first / last pass runs on the matrix pipe from the cell codes, all items at once (vibo_cmean.hip)
+    bool cond_fused;          // ... whose first pass is folded into the matrix row-split kernel (one panel, ability_dim 1, fp32 rows: its XM == 3)
     bool given;               // panel mode with a caller-supplied per-person posterior (VIBO_POSTERIOR_GIVEN)
     size_t off_pre, off_coef, off_cpart;
     size_t off_codes;         // fp32 rows read by more than one pass: the first pass's 1-byte cell codes [B][codes_stride] (0: not used)
@@ -239,6 +241,7 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
     pl->panels = 0;
     pl->cond = false;
     pl->given = false;
+    pl->cond_fused = false;
     const bool is_cond = d->posterior == VIBO_POSTERIOR_CONDITIONAL;
     const bool is_given = d->posterior == VIBO_POSTERIOR_GIVEN;
     if (is_given && !(I >= 4 && I <= 32767 && rows_chunkable(d) && d->mask_dtype != VIBO_MASK_I64))
@@ -298,6 +301,13 @@ static int make_plan(const vibo_desc* d, Plan* pl, bool allow_msplit = true) {
                 if (pl->split_nblk > per) pl->split_nblk = per;
             }
         }
+        // Conditional posterior, one panel, ability_dim 1, fp32 rows: the matrix kernel gathers the experts itself while it packs the
+        // cells (its XM == 3) and leaves the rows' cell codes behind for the table-gradient pass -- one 5 B/cell stream where
+        // cond_pre read 5 + wrote 1 and the matrix kernel read 1 (1M x 1k: 2.28 -> see DESIGN 8.1).  VIBO_FLAG_COND_THREE_PASS /
+        // VIBO_FLAG_COND_VALU / VIBO_FLAG_NO_EMIT_CODES keep the three passes.
+        pl->cond_fused = is_cond && pl->panels == 1 && A == 1 && pl->msplit && d->n_flows == 0 && d->mask_dtype != VIBO_MASK_CODES &&
+                         !(d->flags & (VIBO_FLAG_COND_THREE_PASS | VIBO_FLAG_COND_VALU)) && (!d->want_grad || emit_codes_wanted(d));
+        if (pl->cond_fused) pl->cmat_pre = false;
         pl->nblk = 0;
         pl->lds_main = 0;
         pl->lay = partial_layout(A, pl->D, 1024, d->n_flows);
@@ -1096,7 +1106,12 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
         cp.coef_panels = pl.panels; cp.rec_stride = pl.cond_rec; cp.coef_in = coef;
         e = hipSuccess;
         const bool given_direct = pl.given && pl.panels == 1;      // one panel: the kernel's slot lanes read / write the posterior themselves
-        if (given_direct) {
+        if (pl.cond_fused) {
+            // no first pass: the matrix kernel gathers the experts itself (XM == 3) and writes the cell codes the gradient pass reads
+            p.cond_table = table;
+            p.codes_out = (emit && grad) ? code_rows : nullptr;
+            p.codes_stride = pl.codes_stride;
+        } else if (given_direct) {
             p.given_post = table;
             p.given_grad = grad ? grad_table : nullptr;
             p.table = item;               // the 2-row expert table is not used in this mode: any finite floats (>= 4 A of them)
@@ -1167,7 +1182,10 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             e = hipGetLastError();
             p.row_cnt = cnt;
         }
-        if (emit) {                   // from here on the rows are the cell codes just written (in minibatch order)
+        if (emit && pl.cond_fused) {  // (the matrix kernel reads the fp32 rows; the gradient pass the codes it leaves behind)
+            cp.response = nullptr; cp.mask = code_rows; cp.row_index = nullptr;
+            cp.mask_stride = pl.codes_stride; cp.mask_dtype = VIBO_MASK_CODES;
+        } else if (emit) {            // from here on the rows are the cell codes just written (in minibatch order)
             codes = true;
             p.response = nullptr; p.mask = code_rows; p.row_index = nullptr;
             p.mask_stride = pl.codes_stride; p.mask_dtype = VIBO_MASK_CODES;
@@ -1188,7 +1206,11 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             p.partial = partial + (size_t)pn * pl.split_nblk * pl.lay.stride;
             p.post_coef = ((pl.cond || (pl.given && !given_direct)) && grad) ? coef + (size_t)pn * d->num_person * 4 * A : nullptr;
             const int nq = (p.I + 255) / 256;
-            e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s, pl.msplit);
+            if (pl.cond_fused)
+                e = p.row_index ? launch_elbo_msplit_xg(p, d->irt_model, grad, (p.I + 127) / 128, pl.split_nblk, s)
+                                : launch_elbo_msplit_xa(p, d->irt_model, grad, (p.I + 127) / 128, pl.split_nblk, s);
+            else
+                e = launch_split(p, pl.AT, codes, d->irt_model, grad, nq, pl.split_nblk, s, pl.msplit);
         }
         if (pl.cond && grad) {
             if (pl.panels > 1 && e == hipSuccess) {       // the panels' backward coefficients summed once (cond_post reads 1 block, not `panels`)

@@ -182,6 +182,17 @@ __device__ __forceinline__ uint32_t pack_codes4_lut(const float4 x, const uint32
     n1 += __builtin_popcount(xm);
     return __builtin_amdgcn_perm(0u, lut, sel);
 }
+// (the same, also handing out the [observed and right] bytes: the matrix kernel's fused conditional mode forms its indicators from them)
+__device__ __forceinline__ uint32_t pack_codes4_lut_x(const float4 x, const uint32_t m, const uint32_t lut, int& nobs, int& n1, uint32_t& xm_out) {
+    const uint32_t x0 = __builtin_bit_cast(uint32_t, x.x), x1 = __builtin_bit_cast(uint32_t, x.y);
+    const uint32_t x2 = __builtin_bit_cast(uint32_t, x.z), x3 = __builtin_bit_cast(uint32_t, x.w);
+    const uint32_t xm = (__builtin_amdgcn_perm(x1, x0, 0x0c0c0703u) | __builtin_amdgcn_perm(x3, x2, 0x07030c0cu)) & m;
+    const uint32_t sel = (xm << 1) + m;          // 0 missing | 1 wrong | 3 right
+    nobs += __builtin_popcount(m);
+    n1 += __builtin_popcount(xm);
+    xm_out = xm;
+    return __builtin_amdgcn_perm(0u, lut, sel);
+}
 //   cell codes: selector byte = the code itself (0 wrong / 1 right / 2 missing), bytes outside `keep` forced to 2
 __device__ __forceinline__ uint32_t pack_cell_codes4_lut(const uint32_t w, const uint32_t keep, const uint32_t lut, int& nobs, int& n1) {
     const uint32_t sel = (w & keep) | (0x02020202u & ~keep);

@@ -45,6 +45,10 @@ hipError_t launch_elbo_msplit_fa(const ElboParams& p, int irt, bool grad, int nw
 hipError_t launch_elbo_msplit_fg(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 hipError_t launch_elbo_msplit_fc(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
 
+// ... the conditional posterior of one panel at ability_dim 1 with its first pass folded in (p.cond_table / p.codes_out / p.post_coef)
+hipError_t launch_elbo_msplit_xa(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
+hipError_t launch_elbo_msplit_xg(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s);
+
 // narrow-row kernel: waves per SIMD each instantiation is compiled for (registers: items x (parameters + gradient accumulators) + one
 // unit of rows; 3PL with gradients at 8 items per lane: 128 registers were 4-12 short -- spilled, and a spill reload waits behind the
 // row loads).  ONE definition for the kernel's launch bounds (vibo_narrow.hip) and the planner's grid (vibo_capi.hip: workgroups per

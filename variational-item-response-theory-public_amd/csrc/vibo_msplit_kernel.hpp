@@ -89,9 +89,12 @@ struct alignas(16) MsFlowLds {      // planar flows only (appended to the dynami
 // sit in 16 registers per lane (guess and 1 - guess of its 8 items) next to the 8 guess-gradient accumulators, which is what
 // pushed every 3PL instantiation with gradients over the 256-register budget (8..136 B of scratch per lane)
 constexpr int kMsGuessFloats = 2 * 4 * 16;
-inline size_t msplit_lds_bytes(int nw, bool flows = false, bool guess = false) {
+// XM == 3 only (behind the guess block): per wave the experts of its 128 items -- [u-step][tile t][chunk i16] x (tau | mu tau of a
+// wrong answer, tau | mu tau of a right one) -- and its share of the batch's per-person sums [lam | s][row]
+constexpr int kMsFuseFloats = 2 * 4 * 16 * 4 + 2 * kMsRows;
+inline size_t msplit_lds_bytes(int nw, bool flows = false, bool guess = false, bool fuse = false) {
     return sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (flows ? sizeof(MsFlowLds) : 0) +
-           (guess ? (size_t)nw * kMsGuessFloats * sizeof(float) : 0);
+           (guess ? (size_t)nw * kMsGuessFloats * sizeof(float) : 0) + (fuse ? (size_t)nw * kMsFuseFloats * sizeof(float) : 0);
 }
 // sum over the 8 consecutive lanes that hold one person's ability dims (every lane of the group gets it)
 __device__ __forceinline__ float ms_group_sum(float v) {
@@ -131,7 +134,8 @@ __device__ __forceinline__ half8 cat8(const half2v a, const half2v b, const half
 // FLOWS: planar flows on the ability sample (flows.py:21-66, models.py:342-348) in the (person, dim) lanes.
 // NW8: the workgroup has exactly 8 waves (897..1024 items, the benchmark's width): slot ownership and the sums over the
 // waves' LDS records are compile-time.  XM: which hooks the launch uses (0: none -- those branches do not exist in the code;
-// 1: panel / conditional: p.row_cnt, p.pre_stats, p.post_coef, p.primary == 0, p.panel_count; 2: p.given_post / p.given_grad).
+// 1: panel / conditional: p.row_cnt, p.pre_stats, p.post_coef, p.primary == 0, p.panel_count; 2: p.given_post / p.given_grad;
+// 3: conditional posterior with the experts' sums formed HERE (one panel, ability_dim 1, fp32 rows): p.cond_table, p.codes_out, p.post_coef).
 // blockDim.x = 64 nw, dynamic LDS = msplit_lds_bytes(nw, FLOWS).
 // The kernel runs at 2 waves per SIMD, where a wave issues at most one instruction per ~5 cycles whatever its type: every
 // scalar instruction, branch and spill reload in the batch loop costs as much as a vector instruction (round 3: the loop
@@ -142,7 +146,14 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // 2 = the caller-supplied posterior read / written by the slot lanes themselves (p.given_post, p.given_grad; one panel).
     // Two modes instead of one EXTRA flag (round 4): each carries the other's pointers, branches and -- the given mode's expf /
     // logvar loads -- spilled registers no longer.
-    constexpr bool EXTRA = XM != 0, XCOND = XM == 1, XGIVEN = XM == 2;
+    // 3 (round 6) = the conditional posterior q(theta | responses, items) (models.py:664-710) of ONE panel at ability_dim 1 with its
+    // first pass folded in: the lanes that pack a row's cells also gather the experts their codes select (tau, mu tau of the item's
+    // wrong / right row of p.cond_table, kept in LDS) and the 16 lanes of a row group add them up; the slot lanes take lam and s from
+    // those sums instead of from cond_pre_kernel's pre_stats, and the rows' 1-byte cell codes leave through p.codes_out for the
+    // table-gradient pass.  One 5 B/cell stream instead of cond_pre's 5 + 1 and this kernel's 1.
+    constexpr bool EXTRA = XM != 0, XCOND = XM == 1, XGIVEN = XM == 2, XFUSE = XM == 3;
+    constexpr bool XCOEF = XCOND || XFUSE;        // the backward hands per-person coefficients to the table-gradient pass
+    static_assert(!XFUSE || (RM != 2 && !FLOWS), "the fused conditional mode reads fp32 rows and has no flow block");
     // The flow instantiations that spilled (3PL, the hook modes, gathered rows) form their LDS addresses in the slot code
     // instead of keeping them loop-invariant in registers: see backward_slot.  (The others -- 2PL / 1PL flows on rows in
     // order, no spills -- measured 2 % slower with the same pins, so they keep the hoisted addresses.)
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // end code (~18 us) and a 12.2 -> 13-round quantisation once per panel of a 100 000-row call.
     int wg = (int)blockIdx.x, G = (int)gridDim.x, item0 = p.item0, I = p.I, rec = (int)blockIdx.x;
     bool primary = XCOND ? p.primary != 0 : true;
-    float* post_coef = XCOND ? p.post_coef : nullptr;
+    float* post_coef = XCOEF ? p.post_coef : nullptr;
     if constexpr (XCOND) {
         if (p.panel_count > 1) {
             const int panel = wg % p.panel_count;
@@ -237,17 +248,27 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     const unsigned rvo0 = 4u * g * rstride4 + 16u * cc0, rvo1 = 4u * g * rstride4 + 16u * cc1;
     const bool have_mask = CODES || p.mask_dtype == 0;        // (wave-uniform)
     const uint32_t fillw = have_mask ? 0u : 0x01010101u;
-    struct RowSrc { __amdgpu_buffer_rsrc_t r, m; };
+    struct RowSrc { __amdgpu_buffer_rsrc_t r, m, c; };
+    // XM == 3: where the batch's cell codes go (p.codes_out, minibatch order; no records without it or past the last batch: the
+    // stores fall away), and the lane's offsets there -- a chunk past the row's end gets an offset past every record limit
+    const unsigned cstride = XFUSE ? (unsigned)p.codes_stride : 0u;
+    const unsigned cvo0 = (32 * q + i16) < n4 ? 4u * g * cstride + 4u * (32 * q + i16) : 0x40000000u;
+    const unsigned cvo1 = (32 * q + 16 + i16) < n4 ? 4u * g * cstride + 4u * (32 * q + 16 + i16) : 0x40000000u;
     auto row_src = [&](const int bt) {
         const int rows = min(p.B - bt * R, R);                // rows of this batch (<= 0 past the last batch: no records)
         const unsigned br = rows > 0 ? (unsigned)(rows - 1) * rstride4 + 16u * n4 : 0u;
         const unsigned bm = (rows > 0 && have_mask) ? (unsigned)(rows - 1) * mstride + 4u * n4 : 0u;
         RowSrc rs;
+        if constexpr (XFUSE && GRAD) {
+            const unsigned bc = (rows > 0 && p.codes_out) ? (unsigned)(rows - 1) * cstride + 4u * n4 : 0u;
+            rs.c = __builtin_amdgcn_make_buffer_rsrc(p.codes_out + (size_t)bt * R * p.codes_stride, (short)0, (int)bc, 0x00020000);
+        }
         rs.m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(static_cast<const uint8_t*>(p.mask) + (size_t)bt * R * p.mask_stride + item0),
                                                  (short)0, (int)bm, 0x00020000);
         if constexpr (!CODES) rs.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.response + (size_t)bt * R * p.resp_stride + item0),
                                                                        (short)0, (int)br, 0x00020000);
         else rs.r = rs.m;
+        if constexpr (!(XFUSE && GRAD)) rs.c = rs.m;
         return rs;
     };
     // quarter (h, j) = person 4 h + j of the lane (row 4 g + j + 16 h of the batch), both chunks: 2 x 16 B + 2 x 4 B
@@ -384,6 +405,21 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             }
         }
     }
+    // XM == 3: the (mu, logvar) of this wave's items' two experts, [pass h: item 64 h + lane][code]
+    float ct_mu[2][2], ct_lv[2][2];
+    if constexpr (XFUSE) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int il = kMsSpan * q + 64 * h + lane;
+            const int gi = item0 + (il < I ? il : 0);                       // (clamped: always a valid address)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float* te = p.cond_table + ((size_t)c * p.I_total + gi) * 2;
+                ct_mu[h][c] = te[0];
+                ct_lv[h][c] = te[1];
+            }
+        }
+    }
     float tab_m = 0.f, tab_s = 0.f;                 // (threads 0..15: entry (c, a) of the 2-row expert table, mean | log variance)
     if (tid < 16) {
         const int c = tid >> 3, a = min(tid & 7, p.A - 1);
@@ -447,6 +483,22 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     // silently wrong numbers; VIBO_FLAG_KERNEL_VALU runs such inputs on the fp32 VALU kernel.
     // 3PL: guess probabilities of the wave's items, read back per tile (see kMsGuessFloats)
     float* const gsl = reinterpret_cast<float*>(ms_smem + sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (FLOWS ? sizeof(MsFlowLds) : 0)) + q * kMsGuessFloats;
+    // XM == 3: this wave's block behind the guess block: experts [u][t][i16] x float4, then its sums [lam | s][row]
+    float* const xls0 = reinterpret_cast<float*>(ms_smem + sizeof(MsCommonLds) + (size_t)nw * sizeof(MsWaveLds) + (FLOWS ? sizeof(MsFlowLds) : 0)) +
+                        (IRT == 3 ? nw * kMsGuessFloats : 0);
+    float* const xls = xls0 + q * kMsFuseFloats;
+    if constexpr (XFUSE) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool ok = kMsSpan * q + 64 * h + lane < I;
+            float4 e = float4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float t0 = 1.0f / (expf(ct_lv[h][0]) + kPoeEps), t1 = 1.0f / (expf(ct_lv[h][1]) + kPoeEps);      // utils.py:105-113
+                e = float4{t0, ct_mu[h][0] * t0, t1, ct_mu[h][1] * t1};
+            }
+            reinterpret_cast<float4*>(xls)[(h * 4 + (lane & 3)) * 16 + (lane >> 2)] = e;      // item 64 h + 4 i16 + t -> [h][t][i16]
+        }
+    }
     MS_P(17, t_entry)                                 // encoder table in LDS (its loads waited for)
     // item sample: through the wave's own LDS (the g-piece / operand-image area, not in use yet) to the item's lane
     float* const it_stage = reinterpret_cast<float*>(&wl.tr[0][0][0]);
@@ -585,8 +637,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     bool need_in = RM != 0 || !have_mask;
     if constexpr (RM == 2) need_in = true;
     // pk[j]: 8-bit fields nobs | nobs of M-tile 1 | n1 | n1 of M-tile 1 of persons j and 4 + j (each <= 8 per lane)
+    float2v xacc[XFUSE ? 8 : 1];                     // XM == 3: (lam, s) shares of the lane's 8 persons over its 8 items
+#pragma unroll
+    for (int k = 0; k < (XFUSE ? 8 : 1); ++k) xacc[k] = float2v{0.f, 0.f};
     auto pack_quarter = [&](auto inc, const int left, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
-                            const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8]) {
+                            const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs) {
         constexpr bool IN = decltype(inc)::value;
         uint32_t k0 = tm0, k1 = tm1;
         if constexpr (IN) {
@@ -598,6 +653,42 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         if constexpr (CODES) {
             cw0[4 * h + j] = pack_cell_codes4_lut(m[2 * j], k0, kLutCode, nobs, n1);
             cw1[4 * h + j] = pack_cell_codes4_lut(m[2 * j + 1], k1, kLutCode, nobs, n1);
+        } else if constexpr (XFUSE) {
+            // the same words, plus what cond_pre_kernel does with the cells: [right] / [wrong] indicators (exactly 0 / 1) times the
+            // item's two experts, summed per person; and the cells' Format P codes for the table-gradient pass
+            float2v acc = xacc[4 * h + j];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t me = ((u ? m[2 * j + 1] : m[2 * j]) | fillw) & (u ? k1 : k0);      // observed cells (bytes 0 / 1)
+                uint32_t xm;                                                                      // ... answered right
+                const uint32_t cw = pack_codes4_lut_x(x[2 * j + u], me, kLutFp32, nobs, n1, xm);
+                if (u) cw1[4 * h + j] = cw; else cw0[4 * h + j] = cw;
+                const uint32_t p0 = me ^ xm;
+                float wp[4], wn[4];
+                asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(wp[0]) : "v"(xm));
+                asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(wp[1]) : "v"(xm));
+                asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(wp[2]) : "v"(xm));
+                asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(wp[3]) : "v"(xm));
+                asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(wn[0]) : "v"(p0));
+                asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(wn[1]) : "v"(p0));
+                asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(wn[2]) : "v"(p0));
+                asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(wn[3]) : "v"(p0));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 e = reinterpret_cast<const float4*>(xls)[(u * 4 + t) * 16 + i16];
+                    acc = float2v{wn[t], wn[t]} * float2v{e.x, e.y} + acc;
+                    acc = float2v{wp[t], wp[t]} * float2v{e.z, e.w} + acc;
+                }
+                if constexpr (GRAD) {
+                    const uint32_t code = xm | ((me ^ 0x01010101u) << 1);                         // 0 wrong | 1 right | 2 missing
+#ifndef VIBO_MS_NO_EMIT
+                    __builtin_amdgcn_raw_buffer_store_b32(code, rs.c, u ? cvo1 : cvo0, (j + 16 * h) * (int)cstride, 0);
+#else
+                    asm volatile("" :: "v"(code));
+#endif
+                }
+            }
+            xacc[4 * h + j] = acc;
         } else {
             cw0[4 * h + j] = pack_codes4_lut(x[2 * j], (m[2 * j] | fillw) & k0, kLutFp32, nobs, n1);
             cw1[4 * h + j] = pack_codes4_lut(x[2 * j + 1], (m[2 * j + 1] | fillw) & k1, kLutFp32, nobs, n1);
@@ -605,22 +696,46 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         pk[j] += (nobs | (n1 << 16)) << (8 * h);
         // (pinned here: hipcc otherwise sinks the whole pack to the end of the batch, and the next loads take new registers)
         asm volatile("" : "+v"(cw0[4 * h + j]), "+v"(cw1[4 * h + j]), "+v"(pk[j]));
+        if constexpr (XFUSE) asm volatile("" : "+v"(xacc[4 * h + j]));
     };
     auto pack_one = [&](const int bt, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
-                        const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8]) __attribute__((always_inline)) {
+                        const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs) __attribute__((always_inline)) {
         const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
-        if (need_in && left < R) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m);
-        else pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m);
+        if (need_in && left < R) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
+        else pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
     };
     auto pack_half = [&](const int bt, const int h, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
-                         const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8]) {
+                         const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs) {
         const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
         if (need_in && left < R) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m);
+            for (int j = 0; j < 4; ++j) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m);
+            for (int j = 0; j < 4; ++j) pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
+        }
+    };
+    // XM == 3: the lane's 16 sums (8 persons x lam | s) -> the sums over the 16 lanes of its row group, by halving: in each of the four
+    // steps a lane keeps the half of its values its own bit selects and adds the partner's copies of those (fixed order: bitwise
+    // reproducible) -- lane i16 ends with value i16 = 8 kind + 4 h + j and stores it
+    auto put_stats = [&]() {
+        if constexpr (XFUSE) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = xacc[k][0]; v[8 + k] = xacc[k][1]; }
+            const bool b3 = (i16 & 8) != 0, b2 = (i16 & 4) != 0, b1 = (i16 & 2) != 0, b0 = (i16 & 1) != 0;
+            float w8[8], w4[4], w2[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float give = b3 ? v[k] : v[k + 8]; w8[k] = (b3 ? v[k + 8] : v[k]) + dpp_f<0x128>(give); }   // row_ror 8
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float give = b2 ? w8[k] : w8[k + 4]; w4[k] = (b2 ? w8[k + 4] : w8[k]) + dpp_f<0x141>(give); }  // row_half_mirror
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const float give = b1 ? w4[k] : w4[k + 2]; w2[k] = (b1 ? w4[k + 2] : w4[k]) + dpp_f<0x4e>(give); }   // quad_perm [2,3,0,1]
+            const float give = b0 ? w2[0] : w2[1];
+            const float w1 = (b0 ? w2[1] : w2[0]) + dpp_f<0xb1>(give);                                                                     // quad_perm [1,0,3,2]
+            xls[2 * 4 * 16 * 4 + (i16 >> 3) * kMsRows + 4 * g + (i16 & 3) + 16 * ((i16 >> 2) & 1)] = w1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xacc[k] = float2v{0.f, 0.f};
         }
     };
     // packed counts of the lane's 8 persons (both u-steps) -> 16-lane sums -> wl.cnt
@@ -717,6 +832,24 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         if constexpr (EXTRA && !EXT && kPrs) {
             if (XGIVEN || p.pre_stats) { lam = prs0; smu = prs1; nobs = prs2; }
+        }
+        if constexpr (XFUSE) {               // the waves' shares of the experts' sums (put_stats), fixed order
+            lam = 0.f; smu = 0.f;
+            if constexpr (NW8) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const float* st = xls0 + w * kMsFuseFloats + 2 * 4 * 16 * 4;
+                    lam += st[pp];
+                    smu += st[kMsRows + pp];
+                }
+            } else {
+#pragma unroll 1
+                for (int w = 0; w < nw; ++w) {
+                    const float* st = xls0 + w * kMsFuseFloats + 2 * 4 * 16 * 4;
+                    lam += st[pp];
+                    smu += st[kMsRows + pp];
+                }
+            }
         }
         const float nmiss = (float)p.I_total - nobs;
         lam = fmaf(nmiss, prior_w, lam);
@@ -886,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 }
             }
         }
-        if (XCOND && post_coef) {
+        if (XCOEF && post_coef) {
             if (live) {
                 float* pc = post_coef + (size_t)(row0 + pp) * 4 * A;
 #pragma unroll
@@ -1279,11 +1412,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             while ((long long)(realtime_ticks() - t_wave_start) < wait_ticks) __builtin_amdgcn_s_sleep(8);
             first_rows();
         }
-        pack_half(bt, 0, cwA0, cwA1, pk, x, m);
+        pack_half(bt, 0, cwA0, cwA1, pk, x, m, src_first);
         MS_P(22, t_entry)
-        pack_half(bt, 1, cwA0, cwA1, pk, x2, m2);
+        pack_half(bt, 1, cwA0, cwA1, pk, x2, m2, src_first);
         MS_P(23, t_entry)
         put_counts(pk, true);
+        put_stats();
         asm volatile("" : "+v"(epn));                 // (in before the loop: no wait on it behind the loop's own loads)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
         if constexpr (XCOND && kPrs) asm volatile("" : "+v"(prc));
@@ -1328,7 +1462,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             __builtin_amdgcn_sched_barrier(0);
         };
         auto pack_a_burst_b = [&]() {
-            pack_half(nxt, 0, cwB0, cwB1, pk, x, m);
+            pack_half(nxt, 0, cwB0, cwB1, pk, x, m, sn);
             fetch_eps(nxt, par ^ 1);                  // (complete by the second pack: free to carry across the back edge)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1374,7 +1508,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
             // spread over tiles (1, j) as well -- loads in flight across the loop's back edge -- +-0 against this (885 vs 884,
             // 809 vs 803); the slower wave group (4-7) issuing its M-tile 0 burst behind the first barrier: 863 vs 858, 810 vs 805.
             auto side = [&](const int j) __attribute__((always_inline)) {
-                pack_one(nxt, 0, j, cwB0, cwB1, pk, x, m);
+                pack_one(nxt, 0, j, cwB0, cwB1, pk, x, m, sn);
                 __builtin_amdgcn_sched_barrier(0);
                 load_quarter(nxt, sn, 1, j, x, m);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1404,7 +1538,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1, bopB, bopA);     // (... of the next batch's (0, 0) into bopA)
         tile(IC1{}, IC3{}, db0, db1, da0, da1, cwA1, bopA, bopB);     // (not used: last; reads (0, 1) into bopB)
         MS_T(2)
-        pack_half(nxt, 1, cwB0, cwB1, pk, x, m);
+        pack_half(nxt, 1, cwB0, cwB1, pk, x, m, sn);
         asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
         if constexpr (XCOND && kPrs) asm volatile("" : "+v"(prc));
@@ -1414,6 +1548,7 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         MS_T(3)
         put_counts(pk, nxt < n_batches);
+        put_stats();
         if constexpr (GRAD) put_gtheta(par);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { cwA0[k] = cwB0[k]; cwA1[k] = cwB1[k]; }
@@ -1570,12 +1705,36 @@ static hipError_t launch_msplit_inst(const ElboParams& p, int nw, int grid, hipS
     hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM, FLOWS, NW8, XM>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw, FLOWS, IRT == 3), s, p);
     return hipGetLastError();
 }
+// XM == 3 (p.cond_table): its own translation units (vibo_msplit_xa / xg.hip)
+template <int IRT, bool GRAD, int RM, bool NW8>
+static hipError_t launch_msplit_fused_inst(const ElboParams& p, int nw, int grid, hipStream_t s) {
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msplit_kernel<IRT, GRAD, RM, false, NW8, 3>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)msplit_lds_bytes(8, false, IRT == 3, true));
+        if (e != hipSuccess) return e;
+        lds_opt_in = true;
+    }
+    hipLaunchKernelGGL((msplit_kernel<IRT, GRAD, RM, false, NW8, 3>), dim3(grid), dim3(64 * nw), msplit_lds_bytes(nw, false, IRT == 3, true), s, p);
+    return hipGetLastError();
+}
+template <int RM>
+static hipError_t launch_msplit_fused(const ElboParams& p, int irt, bool grad, int nw, int grid, hipStream_t s) {
+    if (!p.cond_table || p.A != 1 || p.n_flows != 0 || p.row_cnt || p.pre_stats || p.given_post || p.given_grad || !p.primary || p.panel_count > 1 ||
+        (grad && !p.post_coef)) return hipErrorInvalidValue;
+#define VIBO_MSF(IRT_, GRAD_) (nw == 8 ? launch_msplit_fused_inst<IRT_, GRAD_, RM, true>(p, nw, grid, s) : launch_msplit_fused_inst<IRT_, GRAD_, RM, false>(p, nw, grid, s))
+    if (irt == 1) return grad ? VIBO_MSF(1, true) : VIBO_MSF(1, false);
+    if (irt == 2) return grad ? VIBO_MSF(2, true) : VIBO_MSF(2, false);
+    return grad ? VIBO_MSF(3, true) : VIBO_MSF(3, false);
+#undef VIBO_MSF
+}
 template <int IRT, bool GRAD, int RM, bool FLOWS>
 static hipError_t launch_msplit_one(const ElboParams& p, int nw, int grid, hipStream_t s) {
     // XM: the hook mode (see the kernel): 2 = the slot lanes read / write a caller-supplied posterior, 1 = panel / conditional hooks;
     // NW8: exactly 8 waves per workgroup
     const int xm = (p.given_post || p.given_grad) ? 2
                    : (p.row_cnt || p.pre_stats || p.post_coef || !p.primary || p.panel_count > 1) ? 1 : 0;
+    if (p.cond_table) return hipErrorInvalidValue;      // (XM == 3: launch_msplit_fused)
     if (xm == 2 && (!p.given_post || p.row_cnt || p.pre_stats || p.post_coef || !p.primary || p.panel_count > 1)) return hipErrorInvalidValue;
     if (nw == 8) return xm == 2 ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, 2>(p, nw, grid, s)
                       : xm == 1 ? launch_msplit_inst<IRT, GRAD, RM, FLOWS, true, 1>(p, nw, grid, s)

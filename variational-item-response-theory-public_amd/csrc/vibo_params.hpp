@@ -76,6 +76,10 @@ struct ElboParams {
     // the posterior IS (mu, logvar) there) -- no pre_stats / post_coef round trip, two launches less per call
     const float* given_post;  // [B][2A] = mu | logvar, or null
     float* given_grad;        // [2 sets][B][2A], or null
+    // conditional posterior, one panel, ability_dim 1, fp32 rows: the matrix row-split kernel forms the experts' sums itself (its XM == 3)
+    const float* cond_table;  // [2][I_total][2] = mu | logvar per (response code, item), or null
+    uint8_t* codes_out;       // [B][codes_stride] the rows' 1-byte cell codes (minibatch order) for the table-gradient pass, or null
+    long long codes_stride;
     long long resp_stride, mask_stride;
     int B, I, A, D, DP;
     int n_tiles, lds_stride, lds_main;

@@ -15,7 +15,7 @@ POSTERIOR_UNCONDITIONAL, POSTERIOR_CONDITIONAL, POSTERIOR_GIVEN = 0, 1, 2
 MISSING_PRIOR, MISSING_DROP = 0, 1
 MASK_U8, MASK_I64, MASK_NONE, MASK_CODES = 0, 1, 2, 3
 REG_KL, REG_SAMPLED = 0, 1
-FLAG_KERNEL_VALU, FLAG_KERNEL_MATRIX, FLAG_NO_EMIT_CODES, FLAG_COND_VALU, FLAG_COND_MATRIX = 1, 2, 4, 8, 16
+FLAG_KERNEL_VALU, FLAG_KERNEL_MATRIX, FLAG_NO_EMIT_CODES, FLAG_COND_VALU, FLAG_COND_MATRIX, FLAG_COND_THREE_PASS = 1, 2, 4, 8, 16, 32
 KERNEL_NAMES = {1: 'matrix row-split (msplit_kernel)', 2: 'VALU row-split (split_kernel)', 3: 'wave-per-row', 4: 'tiled',
                 5: 'wave-per-person', 6: 'narrow rows (narrow_kernel)'}
 MAX_ABILITY_DIM = 16          # vibo_elbo_fwd_bwd / vibo_encode / vibo_decode (9..16: the wave-per-person kernel)
