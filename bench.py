@@ -752,7 +752,8 @@ def main():
     def conditional_probe():
         """--conditional-posterior on the headline shape (2PL, 1M x 1k): one forward + backward call at ability_dim 1 and 8, on
         fp32 rows and on cell codes (the experts' per-person sums and the table-gradient scatter run as one-hot x table
-        contractions on the matrix pipe from 4 096 persons per call: csrc/vibo_cmean.hip)."""
+        contractions on the matrix pipe from 4 096 persons per call: csrc/vibo_cmean.hip; at ability_dim 1 on fp32 rows
+        the sums are formed inside the matrix row-split kernel)."""
         from vibo_amd import _lib
         from vibo_amd.ops import ElboSpec
         Pc, Ic = min(args.persons, 1_000_000), args.items
@@ -778,7 +779,12 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 3
-                out[f'ability_dim_{Ac}_{name}'] = {'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3)}
+                bytes_per_term = (1.0 if name == 'cell_codes' else 5.0) + 12.0 * Ac / Ic
+                out[f'ability_dim_{Ac}_{name}'] = {'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3),
+                                                   'roofline_frac': bytes_per_term * Pc * Ic / (ms * 1e-3) / 8e12}
+        out['note'] = ('ability_dim 1 on fp32 rows: the matrix kernel gathers the experts itself while it packs the cells (one 5 B/cell stream; '
+                       'VIBO_FLAG_COND_THREE_PASS keeps the separate first pass: 2.2-2.3 ms); every other row: first pass, matrix kernel on the '
+                       'emitted cell codes, table-gradient pass')
         out['workload'] = f'2PL, {Pc} persons x {Ic} items, conditional posterior: one forward + backward call'
         return out
 

@@ -51,7 +51,7 @@ for sh in shapes:
     P, I = (int(v) for v in parts[0].split('x'))
     irt = int(parts[1]) if len(parts) > 1 and parts[1] else 2
     gather = len(parts) > 2 and parts[2] == 'g'
-    iters = max(2, min(20, int(2e9 / (P * I))))
+    iters = max(10, min(50, int(5e9 / (P * I))))
     base = _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX
     for grad in (True, False):
         f, tf = run(P, I, irt, gather, base, iters, grad=grad)

@@ -19,7 +19,7 @@ rc = fn(buf, n)
 raw = np.frombuffer(buf, dtype=np.int64).reshape(1024, 8, SLOTS)[:256]
 t = raw[:, :, :12].astype(np.float64)
 nb = (P + 31) // 32 / (256 // max(1, (I + 1023) // 1024) if I > 1024 else 256)
-names = ['tiles u0', 'pack0', 'tiles u1', 'pack1', 'counts+gth', 'barrier A', 'forward', 'barrier B', 'read ops', 'backward', 'wait loads x2', 'issue loads x2']
+names = ['tiles u0', 'pack0', 'tiles u1', 'pack1', 'counts+gth', 'barrier A', 'forward', 'barrier B', 'read ops', 'backward', 'put_counts', 'put_stats']
 print('rc', rc, 'batches per workgroup %.1f' % nb)
 print('phase           ' + ''.join(f' wave{w:1d}  ' for w in range(8)) + '   (cycles per batch, mean over workgroups)')
 for k, nm in enumerate(names):

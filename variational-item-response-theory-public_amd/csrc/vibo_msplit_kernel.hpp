@@ -640,8 +640,17 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     float2v xacc[XFUSE ? 8 : 1];                     // XM == 3: (lam, s) shares of the lane's 8 persons over its 8 items
 #pragma unroll
     for (int k = 0; k < (XFUSE ? 8 : 1); ++k) xacc[k] = float2v{0.f, 0.f};
+    // (XM == 3: the experts of the lane's 8 items, [4 u + t]; read per quarter in front of the tiles -- nothing can stay live across a
+    //  tile there -- and once for the four quarters packed back to back behind the last tile)
+    struct Experts { float4 e[XFUSE ? 8 : 1]; };
+    auto read_experts = [&](Experts& ex) __attribute__((always_inline)) {
+        if constexpr (XFUSE) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ex.e[k] = reinterpret_cast<const float4*>(xls)[k * 16 + i16];
+        }
+    };
     auto pack_quarter = [&](auto inc, const int left, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
-                            const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs) {
+                            const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs, const Experts& ex) {
         constexpr bool IN = decltype(inc)::value;
         uint32_t k0 = tm0, k1 = tm1;
         if constexpr (IN) {
@@ -675,17 +684,15 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
                 asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(wn[3]) : "v"(p0));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float4 e = reinterpret_cast<const float4*>(xls)[(u * 4 + t) * 16 + i16];
+                    const float4 e = ex.e[u * 4 + t];
                     acc = float2v{wn[t], wn[t]} * float2v{e.x, e.y} + acc;
                     acc = float2v{wp[t], wp[t]} * float2v{e.z, e.w} + acc;
                 }
                 if constexpr (GRAD) {
                     const uint32_t code = xm | ((me ^ 0x01010101u) << 1);                         // 0 wrong | 1 right | 2 missing
-#ifndef VIBO_MS_NO_EMIT
+                    // (the stores themselves: 1.76 -> 1.72 ms per 1M x 1k call without them -- 1 GB leaves at a twentieth of the cost of
+                    //  the pass they replace)
                     __builtin_amdgcn_raw_buffer_store_b32(code, rs.c, u ? cvo1 : cvo0, (j + 16 * h) * (int)cstride, 0);
-#else
-                    asm volatile("" :: "v"(code));
-#endif
                 }
             }
             xacc[4 * h + j] = acc;
@@ -701,18 +708,22 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     auto pack_one = [&](const int bt, const int h, const int j, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
                         const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs) __attribute__((always_inline)) {
         const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
-        if (need_in && left < R) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
-        else pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
+        Experts ex;
+        read_experts(ex);
+        if (need_in && left < R) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m, rs, ex);
+        else pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m, rs, ex);
     };
     auto pack_half = [&](const int bt, const int h, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
                          const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs) {
         const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
+        Experts ex;
+        read_experts(ex);
         if (need_in && left < R) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
+            for (int j = 0; j < 4; ++j) pack_quarter(std::true_type{}, left, h, j, cw0, cw1, pk, x, m, rs, ex);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m, rs);
+            for (int j = 0; j < 4; ++j) pack_quarter(std::false_type{}, left, h, j, cw0, cw1, pk, x, m, rs, ex);
         }
     };
     // XM == 3: the lane's 16 sums (8 persons x lam | s) -> the sums over the 16 lanes of its row group, by halving: in each of the four
@@ -1538,6 +1549,11 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         tile(IC1{}, IC2{}, da0, da1, db0, db1, cwA1, bopB, bopA);     // (... of the next batch's (0, 0) into bopA)
         tile(IC1{}, IC3{}, db0, db1, da0, da1, cwA1, bopA, bopB);     // (not used: last; reads (0, 1) into bopB)
         MS_T(2)
+        // (XM == 3: the rest of the iteration above the partner wave's tiles.  With the experts' sums in the packs, the wave that leaves
+        //  its tiles first -- waves 0-3, see the tile -- has ~3 k cycles of pack and halving sums in front of the batch barrier, at the
+        //  tile's last priority (0) against its partner's tiles: tools/ms_timing.py showed 7.2 k cycles there against the partner's
+        //  4.3 k, and the partner waiting.  1M x 1k: 1.625 -> 1.600 ms.  The falling-priority staircase of the cell-code rows on top: +-0.)
+        if constexpr (XFUSE) __builtin_amdgcn_s_setprio(2);
         pack_half(nxt, 1, cwB0, cwB1, pk, x, m, sn);
         asm volatile("" : "+v"(epn));                 // (eps is in: nothing is pending at the back edge)
         if constexpr (EXTRA && kPrs) asm volatile("" : "+v"(prs0), "+v"(prs1), "+v"(prs2));
@@ -1548,7 +1564,9 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
         }
         MS_T(3)
         put_counts(pk, nxt < n_batches);
+        MS_T(10)
         put_stats();
+        MS_T(11)
         if constexpr (GRAD) put_gtheta(par);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { cwA0[k] = cwB0[k]; cwA1[k] = cwB1[k]; }
