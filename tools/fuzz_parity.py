@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
 ap.add_argument('--seed', type=int, default=0)
 ap.add_argument('--target', choices=['elbo', 'multi', 'module', 'trainer'], default='elbo', help="'multi': vibo_elbo_multi_forward vs one forward launch per sample")
+ap.add_argument('--focus', choices=['', 'cond1'], default='', help="'cond1': conditional posterior at ability_dim 1 on fp32 rows under the matrix-kernel pin -- the mode with the first pass folded into the matrix kernel (its XM == 3)")
 ap.add_argument('--replay', type=str, default='', help='"irt A B I cond flows drop missing pad scale dataseed gather no_mask fwd_only codes given kflag" of a reported failure')
 a = ap.parse_args()
 rng = random.Random(a.seed)
@@ -279,6 +280,11 @@ while time.time() - t0 < a.seconds:
     # which row-split kernel: the planner's choice (the narrow-row kernel for <= 128 items at ability_dim <= 4, else by size), or one
     # pinned through vibo_desc.flags -- at these minibatch sizes the planner alone never picks the matrix kernel (round 5)
     kflag = rng.choice([0, 0, _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX, _lib.FLAG_KERNEL_VALU | _lib.FLAG_COND_VALU])
+    if a.focus == 'cond1':
+        A, cond, n_flows, codes, given = 1, True, 0, False, False
+        B = rng.choice([1, 9, 31, 32, 33, 64, 65, 257, 1000, 4099])
+        I = rng.choice([4, 8, 96, 100, 127, 128, 129, 255, 257, 512, 516, 768, 897, 1000, 1023, 1024])
+        kflag = _lib.FLAG_KERNEL_MATRIX | _lib.FLAG_COND_MATRIX
     if a.replay:
         f = a.replay.split()
         irt, A, B, I, n_flows, dataseed = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[5]), int(f[10])

@@ -716,6 +716,12 @@ __global__ __launch_bounds__(512, 2) void msplit_kernel(const ElboParams p) {
     auto pack_half = [&](const int bt, const int h, uint32_t (&cw0)[8], uint32_t (&cw1)[8], int (&pk)[4],
                          const float4 (&x)[CODES ? 1 : 8], const uint32_t (&m)[8], const RowSrc& rs) {
         const int left = p.B - bt * R;               // (wave-uniform) only the last batch has rows past the end
+        if constexpr (XFUSE && RM != 0) {
+            // (gathered rows carry 16 row numbers: the experts held across four quarters spilled 20-41 registers there)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pack_one(bt, h, j, cw0, cw1, pk, x, m, rs);
+            return;
+        }
         Experts ex;
         read_experts(ex);
         if (need_in && left < R) {
