@@ -735,6 +735,60 @@ def test_config5_pipeline_at_the_planner_large_call_size(codes, P):
     assert (full.ability_ladj[:n].cpu() - ref['ladj'].float()).abs().max() < 5e-5
 
 
+@pytest.mark.parametrize('irt,P,I', [(2, 1_000_000, 1000), (3, 200_003, 998), (1, 70_000, 516)], ids=['2pl-1Mx1000', '3pl-200003x998', '1pl-70000x516'])
+def test_conditional_posterior_one_dim_at_full_size(irt, P, I, monkeypatch):
+    """--conditional-posterior at ability_dim 1 on fp32 rows at the sizes the matrix kernel serves (models.py:664-710): under the
+    first pin the kernel forms the experts' sums itself and emits the rows' cell codes for the table-gradient pass (its XM == 3; 8 waves
+    at 1000 / 998 items, 5 at 516, a ragged last chunk at 998), under the others the separate first pass runs.  Bitwise reproducible,
+    additive over two person shards, invariant under a person permutation (in-kernel gather), equal to the three passes within fp32
+    rounding, and equal to the fp64 oracle on a slice."""
+    A = 1
+    d = dev()
+    spec = ElboSpec(irt_model=irt, ability_dim=A, conditional=True)
+    resp, mask, table, item, eps = _device_problem(irt, A, P, I, 0.2, seed=66, cond=True)
+    rp, mp = ops.pad_rows(resp, mask)
+
+    def run(rows=None, row_index=None, grad=True):
+        r = rp if rows is None else rp[rows]
+        m = mp if rows is None else mp[rows]
+        e = eps if rows is None else eps[rows].contiguous()
+        if row_index is not None:
+            e = eps[row_index].contiguous()
+        r2, m2, code = ops.prepare_rows(r, m)
+        B = int(row_index.numel()) if row_index is not None else r.shape[0]
+        out = ops._hip_launch_elbo(spec, r2, m2, code, row_index, table, item, e, None, _lib.REG_KL, grad, B)
+        torch.cuda.synchronize()
+        return out
+
+    full, again = run(), run()
+    assert torch.equal(full.flat, again.flat) and torch.equal(full.ability_mu, again.ability_mu), 'must be bitwise deterministic'
+    h = P // 2 + 37
+    a, b = run(slice(0, h)), run(slice(h, P))
+    summed = a.flat + b.flat
+    assert rel_err(summed[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(summed[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    assert (torch.cat([a.ability_mu, b.ability_mu]) - full.ability_mu).abs().max() < 1e-6
+    perm = torch.randperm(P, device=d, generator=torch.Generator(device=d).manual_seed(9))
+    pg = run(row_index=perm)
+    assert rel_err(pg.flat[:7].cpu(), full.flat[:7].cpu()) < 1e-5
+    assert rel_err(pg.flat[8:].cpu(), full.flat[8:].cpu()) < 1e-4
+    assert (pg.ability_mu - full.ability_mu[perm]).abs().max() < 1e-6
+    fwd = run(grad=False)                    # forward only: no codes leave the kernel; the same posterior and scalars
+    assert torch.equal(fwd.ability_mu, full.ability_mu) and rel_err(fwd.flat[:7].cpu(), full.flat[:7].cpu()) < 1e-6
+    # the other form of the same call (three passes <-> experts' sums in the kernel)
+    other_flags = ops.DESC_FLAGS ^ _lib.FLAG_COND_THREE_PASS if (ops.DESC_FLAGS & _lib.FLAG_KERNEL_MATRIX) else ops.DESC_FLAGS
+    monkeypatch.setattr(ops, 'DESC_FLAGS', other_flags)
+    other = run()
+    assert rel_err(other.flat[:7].cpu(), full.flat[:7].cpu()) < 2e-6
+    assert rel_err(other.flat[8:].cpu(), full.flat[8:].cpu()) < 2e-5
+    assert (other.ability_mu - full.ability_mu).abs().max() < 2e-6 and (other.ability_logvar - full.ability_logvar).abs().max() < 2e-6
+    n = 64
+    ref = T.fused_elbo_ref(table.cpu().double(), item.cpu().double(), resp[:n].cpu().double(), mask[:n].cpu(),
+                           eps[:n].cpu().double(), irt_model=irt, ability_dim=A, conditional_posterior=True, mode='kl')
+    for k, t in (('ability_mu', full.ability_mu), ('ability_logvar', full.ability_logvar), ('ability', full.ability)):
+        assert (t[:n].cpu() - ref[k].float()).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
+
+
 def test_config4_shape_at_full_size():
     """BASELINE configs[3]'s matrix shape at its full size (CritLangAcq: 535 598 persons x 95 items, 2PL, ability_dim 1,
     --artificial-missing-perc 0.2; datasets.py:283-440, masked log-likelihood models.py:596-629): narrow rows with padded
