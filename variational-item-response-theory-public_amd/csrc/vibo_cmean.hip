@@ -138,6 +138,26 @@ __global__ __launch_bounds__(256) void cm_grad_image_kernel(const float* __restr
     gimg[o + 128] = lo;
 }
 
+// the packed form (cm_backward_body's PK): gimg[c32 * 64 + lane] = piece (lane & 15) / ncols of column (lane & 15) % ncols (3 ncols <= 16)
+__global__ __launch_bounds__(256) void cm_grad_image_packed_kernel(const float* __restrict__ G, uint4* __restrict__ gimg, long long B, long long n32,
+                                                                   int ncols) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n32 * 64) return;
+    const int lane = (int)(t & 63);
+    const long long c32 = t >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int piece = n / ncols, col = n % ncols;
+    float v[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const long long p = 32 * c32 + 8 * g + kk;
+        v[kk] = (p < B && piece < kCmNP) ? G[p * ncols + col] : 0.f;
+    }
+    uint4 hi, mid, lo;
+    cm_split3(v, hi, mid, lo);
+    gimg[(size_t)c32 * 64 + lane] = piece == 0 ? hi : piece == 1 ? mid : lo;
+}
+
 // the 16 code bytes at items [i0, i0 + 16) of the row at `rp`.  AL: rows 16-byte aligned (one load), else 4-byte aligned (four).
 // cm_load_full: the 16 bytes lie inside the row (every step below I / 64: no bounds logic anywhere near the pipelined loads);
 // cm_load_tail: the row's last, partial step -- dword by dword (rows are whole dwords), bytes past the row's end read as missing (2)
@@ -580,7 +600,10 @@ __device__ __forceinline__ uint2 cm_lds_tr(const char* p) {
 __device__ __forceinline__ int cm_tile_swz(int person) { return (person & 3) | (((person >> 3) & 1) << 2); }
 // WV = waves per workgroup sharing the tile (1, or 2: each wave builds two of the four M-tiles and owns four of the eight column
 // tiles -- half the accumulators and code-row registers per wave, 8 KB of LDS per wave: 4 waves per SIMD instead of 2.5)
-template <int NT, bool AL, int TAIL /* 0: whole step, 1: partial step of padded rows, 2: partial step */, bool GATHER, int WV, int PS /* persons per step: 64 or 32 */>
+// PK (round 6): the three bf16 pieces of the coefficients sit in three column groups of ONE operand (columns piece * ncols + col; the
+// conditional posterior at ability_dim 1 has 4 coefficient columns: 12 of 16) -- one MFMA per (column tile, K-chunk) instead of three,
+// the finalize adds the groups (cm_cond_finalize_body, CondFinTail::packed_cols).
+template <int NT, bool AL, int TAIL /* 0: whole step, 1: partial step of padded rows, 2: partial step */, bool GATHER, int WV, int PS /* persons per step: 64 or 32 */, bool PK = false>
 __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
                                                  long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
                                                  long long per_r, char* tile, int S, int r, int ntot, int nt0) {
@@ -631,15 +654,15 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
     auto step = [&](const long long p0, const uint4 (&w)[MTW], uint4 (&wnext)[MTW]) {
         const long long c32 = p0 >> 5;
         constexpr bool kBoth = NT <= 2 || NC == 1;   // both 32-person halves' coefficients in registers at once
-        uint4 bg[kBoth ? NC : 1][NT][kCmNP];
+        constexpr int NPC = PK ? 1 : kCmNP;        // operands per coefficient tile
+        uint4 bg[kBoth ? NC : 1][NT][NPC];
 #pragma unroll
         for (int c = 0; c < (kBoth ? NC : 1); ++c)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const uint4* gp = gimg + ((size_t)((c32 + c) * ntot + nt0 + nt) * kCmNP) * 64 + lane;
-                bg[c][nt][0] = gp[0];
-                bg[c][nt][1] = gp[64];
-                bg[c][nt][2] = gp[128];
+                const uint4* gp = gimg + ((size_t)((c32 + c) * ntot + nt0 + nt) * NPC) * 64 + lane;
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) bg[c][nt][pc] = gp[64 * pc];
             }
         __builtin_amdgcn_sched_barrier(0);
         fetch(wnext, p0 + 2 * PS);
@@ -657,10 +680,9 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
                 if (c == 1) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const uint4* gp = gimg + ((size_t)((c32 + 1) * ntot + nt0 + nt) * kCmNP) * 64 + lane;
-                        bg[0][nt][0] = gp[0];
-                        bg[0][nt][1] = gp[64];
-                        bg[0][nt][2] = gp[128];
+                        const uint4* gp = gimg + ((size_t)((c32 + 1) * ntot + nt0 + nt) * NPC) * 64 + lane;
+#pragma unroll
+                        for (int pc = 0; pc < NPC; ++pc) bg[0][nt][pc] = gp[64 * pc];
                     }
                 }
             }
@@ -674,9 +696,13 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
                 const uint4 a = uint4{a0.x, a0.y, a1.x, a1.y};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[T][nt] = cm_mfma(a, bg[cb][nt][2], acc[T][nt]);
-                    acc[T][nt] = cm_mfma(a, bg[cb][nt][1], acc[T][nt]);
-                    acc[T][nt] = cm_mfma(a, bg[cb][nt][0], acc[T][nt]);
+                    if constexpr (PK) {
+                        acc[T][nt] = cm_mfma(a, bg[cb][nt][0], acc[T][nt]);
+                    } else {
+                        acc[T][nt] = cm_mfma(a, bg[cb][nt][2], acc[T][nt]);
+                        acc[T][nt] = cm_mfma(a, bg[cb][nt][1], acc[T][nt]);
+                        acc[T][nt] = cm_mfma(a, bg[cb][nt][0], acc[T][nt]);
+                    }
                 }
             }
         }
@@ -709,18 +735,19 @@ __device__ __forceinline__ void cm_backward_body(const uint8_t* __restrict__ cod
     __shared__ __attribute__((aligned(256))) char tile[PS * 256];                                                                            \
     const int S = blockIdx.x / nR, r = blockIdx.x % nR;                                                                                      \
     const int nt0 = NT * blockIdx.y;                                                                                                         \
-    if (64 * S + 64 <= I) cm_backward_body<NT, AL, 0, GATHER, WV, PS>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);  \
-    else if (64 * S + 64 <= stride) cm_backward_body<NT, AL, 1, GATHER, WV, PS>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0); \
-    else cm_backward_body<NT, AL, 2, GATHER, WV, PS>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
+    if (64 * S + 64 <= I) cm_backward_body<NT, AL, 0, GATHER, WV, PS, PK>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);  \
+    else if (64 * S + 64 <= stride) cm_backward_body<NT, AL, 1, GATHER, WV, PS, PK>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0); \
+    else cm_backward_body<NT, AL, 2, GATHER, WV, PS, PK>(codes, stride, row_index, B, I, gimg, rec, nR, per_r, tile, S, r, ntot, nt0);
 // 4 N-tiles: 128 accumulator + 48 coefficient + 48 code-row registers -- one wave per SIMD with the whole register file
 template <bool AL, bool GATHER>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void cm_backward_wide_kernel(
     const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index, long long B, int I, const uint4* __restrict__ gimg,
     float* __restrict__ rec, int nR, long long per_r, int ntot) {
     constexpr int NT = 4, WV = 1, PS = 64;
+    constexpr bool PK = false;
     CM_BACKWARD_KERNEL_BODY
 }
-template <int NT, bool AL, bool GATHER>
+template <int NT, bool AL, bool GATHER, bool PK = false>
 __global__ __launch_bounds__(64) void cm_backward_kernel(const uint8_t* __restrict__ codes, long long stride, const int64_t* __restrict__ row_index,
                                                              long long B, int I, const uint4* __restrict__ gimg, float* __restrict__ rec, int nR,
                                                              long long per_r, int ntot) {
@@ -802,6 +829,16 @@ static void cm_launch_backward_wide(bool al, dim3 grid, hipStream_t s, const uin
         else hipLaunchKernelGGL((cm_backward_wide_kernel<false, false>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
     }
 }
+static void cm_launch_backward_packed(bool al, dim3 grid, hipStream_t s, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I,
+                                      const uint4* gimg, float* rec, int nR, long long per_r) {
+    if (row_index) {
+        if (al) hipLaunchKernelGGL((cm_backward_kernel<1, true, true, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, 1);
+        else hipLaunchKernelGGL((cm_backward_kernel<1, false, true, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, 1);
+    } else {
+        if (al) hipLaunchKernelGGL((cm_backward_kernel<1, true, false, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, 1);
+        else hipLaunchKernelGGL((cm_backward_kernel<1, false, false, true>), grid, dim3(64), 0, s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, 1);
+    }
+}
 template <int NT>
 static void cm_launch_backward_nt(bool al, dim3 grid, hipStream_t s, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I,
                                   const uint4* gimg, float* rec, int nR, long long per_r, int ntot) {
@@ -815,12 +852,13 @@ static void cm_launch_backward_nt(bool al, dim3 grid, hipStream_t s, const uint8
 }
 // ntot N-tiles in all (1, 2 or a multiple of 4: blockIdx.y slices of 4)
 static hipError_t cm_launch_backward(int ntot, const uint8_t* codes, long long stride, const int64_t* row_index, long long B, int I, int nS,
-                                     const uint4* gimg, float* rec, hipStream_t s, int* nR_out) {
+                                     const uint4* gimg, float* rec, hipStream_t s, int* nR_out, bool packed = false) {
     long long per_r;
     const int nR = cm_ranges(B, nS, &per_r);
     *nR_out = nR;
     const bool al = stride % 16 == 0 && ((uintptr_t)codes & 15) == 0;
-    if (ntot == 1) cm_launch_backward_nt<1>(al, dim3((unsigned)(nS * nR)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
+    if (packed) cm_launch_backward_packed(al, dim3((unsigned)(nS * nR)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r);
+    else if (ntot == 1) cm_launch_backward_nt<1>(al, dim3((unsigned)(nS * nR)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
     else if (ntot == 2) cm_launch_backward_nt<2>(al, dim3((unsigned)(nS * nR)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
     else cm_launch_backward_wide(al, dim3((unsigned)(nS * nR), (unsigned)(ntot / 4)), s, codes, stride, row_index, B, I, gimg, rec, nR, per_r, ntot);
     return hipGetLastError();
@@ -878,14 +916,17 @@ hipError_t launch_cond_post_mfma(const uint8_t* codes, long long stride, const i
     uint4* gimg = reinterpret_cast<uint4*>(base);
     float* rec = reinterpret_cast<float*>(base + cm_gimg_bytes(B, NT));
     const long long n32 = (B + 63) / 64 * 2;
-    hipLaunchKernelGGL(cm_grad_image_kernel, dim3((unsigned)((n32 * NT * 64 + 255) / 256)), dim3(256), 0, s, coef, gimg, B, n32, NT, 4 * A);
+    const bool packed = 3 * 4 * A <= 16;             // ability_dim 1: the three pieces of the 4 coefficient columns in one operand
+    if (packed) hipLaunchKernelGGL(cm_grad_image_packed_kernel, dim3((unsigned)((n32 * 64 + 255) / 256)), dim3(256), 0, s, coef, gimg, B, n32, 4 * A);
+    else hipLaunchKernelGGL(cm_grad_image_kernel, dim3((unsigned)((n32 * NT * 64 + 255) / 256)), dim3(256), 0, s, coef, gimg, B, n32, NT, 4 * A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int nR = 0;
-    e = cm_launch_backward(NT, codes, stride, row_index, B, I, nS, gimg, rec, s, &nR);
+    e = cm_launch_backward(NT, codes, stride, row_index, B, I, nS, gimg, rec, s, &nR, packed);
     if (e != hipSuccess) return e;
     CondFinTail t;
     memset(&t, 0, sizeof(t));
+    t.packed_cols = packed ? 4 * A : 0;
     t.kind = 2; t.gx = nS; t.gy = 4; t.rec = rec; t.table = table; t.grad_table = grad_table; t.I = I; t.A = A; t.nR = nR; t.N = 16 * NT;
     if (defer) { *defer = t; return hipSuccess; }        // (rides in the ELBO finalize launch)
     hipLaunchKernelGGL(cm_cond_finalize_kernel, dim3(nS, 4), dim3(1024), 0, s, t);

@@ -68,11 +68,13 @@ __device__ __forceinline__ void cm_cond_finalize_body(const CondFinTail& t, cons
         const int item = 64 * S + 16 * gq + 4 * (col >> 3) + ((col & 7) >> 1), c = col & 1;
         if (item >= I) continue;
         const float* sp = sum + col * N;
+        const int pc = t.packed_cols;
+        auto val = [&](const int k) { return pc > 0 ? (sp[k] + sp[pc + k]) + sp[2 * pc + k] : sp[k]; };
         const float* te = t.table + ((size_t)c * I + item) * 2 * A;
         const float es = expf(te[A + a]), tau = 1.0f / (es + kPoeEps), mu = te[a];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float s1 = sp[(2 * h) * A + a], s2 = sp[(2 * h + 1) * A + a];
+            const float s1 = val((2 * h) * A + a), s2 = val((2 * h + 1) * A + a);
             float* go = t.grad_table + ((size_t)(h * 2 + c) * I + item) * 2 * A;
             go[a] = s1 * tau;
             go[A + a] = -(s1 * mu + s2) * tau * tau * es;

@@ -99,6 +99,7 @@ struct CondFinTail {
     int I, A;
     int bpp, rec_stride;      // kind 1
     int nR, N;                // kind 2
+    int packed_cols;          // kind 2: > 0 = the records' columns are [piece][packed_cols] (cm_backward_body's PK): the pieces' sums add up
 };
 
 struct FinalizeParams {
