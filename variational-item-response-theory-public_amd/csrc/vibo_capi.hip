@@ -174,6 +174,13 @@ static bool want_msplit(const vibo_desc* d) {
     //    few waves; the VALU kernel's 256-item waves and 2 workgroups per CU do better there
     //  * ability_dim <= 4: the contractions are a small part of the VALU kernel's work, the matrix kernel only wins once every
     //    workgroup streams several batches (65 536 x 1 000: 80 vs 91 us; 16 384 x 1 000: 36 vs 33)
+    // Conditional posterior at ability_dim 1 on fp32 rows: the matrix kernel also replaces the first pass there (its XM == 3), which
+    // moves the break-even down (tools/calibrate_planner.py-style hipGraph replays, round 6: 8 192 x 1 000 49 vs 57 us, 16 384 x 1 000
+    // 59 vs 72, 65 536 x 512 111 vs 165, 65 536 x 256 102 vs 148; 4 096 persons: 42 vs 45 at 1 000 items, 41 vs 40 at 768, 35 vs 31 at 256)
+    if (d->posterior == VIBO_POSTERIOR_CONDITIONAL && d->ability_dim == 1 && d->n_flows == 0 && d->num_item <= 1024 && d->num_item >= 256 &&
+        d->mask_dtype != VIBO_MASK_CODES && d->mask_dtype != VIBO_MASK_I64 && !(d->flags & (VIBO_FLAG_COND_THREE_PASS | VIBO_FLAG_COND_VALU)) &&
+        (!d->want_grad || emit_codes_wanted(d)))
+        return d->num_person >= 8192;
     if (d->num_person < 4096) return false;
     const int width = d->num_item < 1024 ? d->num_item : 1024;
     const bool many = d->num_person >= 32768;
