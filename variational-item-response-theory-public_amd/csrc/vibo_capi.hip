@@ -181,13 +181,15 @@ static bool want_msplit(const vibo_desc* d) {
         d->mask_dtype != VIBO_MASK_CODES && d->mask_dtype != VIBO_MASK_I64 && !(d->flags & (VIBO_FLAG_COND_THREE_PASS | VIBO_FLAG_COND_VALU)) &&
         (!d->want_grad || emit_codes_wanted(d)))
         return d->num_person >= 8192;
-    if (d->num_person < 4096) return false;
     const int width = d->num_item < 1024 ? d->num_item : 1024;
+    // (round 6, profiles/r06_planner_calibration.txt: the kernel's launch got ~9 us shorter -- 2 048 x 1 000 at ability_dim 8 19.4 vs 22.6 us,
+    //  and the 385..512-item exclusion of round 3 -- "2 workgroups per CU with one batch each at 16 384 persons: 48 vs 42 us" -- now
+    //  measures 18.2 vs 21.9 us at 4 096 persons, 36.4 vs 38.8 at 16 384: dropped)
+    if (d->ability_dim >= 5 && width >= 896 && d->num_person >= 2048) return true;
+    if (d->num_person < 4096) return false;
     const bool many = d->num_person >= 32768;
     if (d->ability_dim <= 4) return many && width >= 640;
     if (width < 320) return false;
-    // (4 waves per workgroup = 2 workgroups per CU with one batch each at 16 384 persons: 48 vs 42 us)
-    if (width > 384 && width <= 512 && !many) return false;
     return true;
 }
 // Narrow rows (4..128 items: BASELINE configs[0] and [3]) of the plain model: the kernel that gives a row to 16 lanes instead of a
