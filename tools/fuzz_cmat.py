@@ -5,7 +5,7 @@ multiples, rows through row_index, fp32 rows and cell codes, both row-split kern
    python tools/fuzz_cmat.py [--cases 60] [--seed 0]"""
 import argparse, os, random, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
-for p in (ROOT, os.path.join(ROOT, 'variational-item-response-theory-public_amd')):
+for p in (ROOT, os.path.join(ROOT, 'variational-item-response-theory-public_amd'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import torch
 from vibo_amd import _lib, ops
@@ -73,6 +73,19 @@ for case in range(a.cases):
     worst = max(errs.values())
     ok = worst < 5e-5 and all(v == v for v in errs.values())
     bad += not ok
+    if not ok and grad:
+        # which of the two forms is off: both against the fp64 oracle (test infrastructure)
+        from oracle import vibo_table_ref as T
+        rs, ms = (resp[rows], mask[rows]) if gather else (resp, mask)
+        flows_ = [(f[:A].double().cpu(), f[A:2 * A].double().cpu(), f[2 * A:].double().cpu()) for f in flow] if flows else None
+        ref = T.fused_elbo_ref(table.cpu().double(), item.cpu().double(), rs.cpu().double(), ms.cpu(), eps.cpu().double(), irt_model=irt,
+                               ability_dim=A, conditional_posterior=True, replace_missing_with_prior=not drop,
+                               mode='sampled' if flows else 'kl', flow_uhat_w_b=flows_)
+        for name in ('mfma', 'valu'):
+            for s_ in range(2):
+                if 'g_table' in ref:
+                    gy = ref['g_table'][s_].float().reshape(out[name].grad_table(s_).shape)
+                    print(f'   {name} set {s_} vs the fp64 oracle: {float((out[name].grad_table(s_).cpu() - gy).abs().max() / max(1e-6, float(gy.abs().max()))):.1e}')
     print(f'{"ok " if ok else "BAD"} irt={irt} A={A} B={B} I={I} codes={codes} pad={pad} gather={gather} flows={flows} drop={drop} grad={grad} kern={kern}: '
           + ' '.join(f'{k}={v:.1e}' for k, v in errs.items()))
 print(f'# {bad} of {a.cases} cases disagree')
