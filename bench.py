@@ -699,8 +699,8 @@ def main():
     def shapes_probe():
         """The other BASELINE shapes as one forward + backward call each (kernel path only, HIP events over 5 calls): configs[3]'s
         CritLangAcq matrix shape (535 598 x 95, 20 % missing, padded 16-byte row strides) and configs[0]'s train split (8 000 x 100)
-        on the narrow-row kernel (csrc/vibo_narrow.hip), a wide plain matrix (100 000 x 10 000: count pass + all panels in one
-        launch) and the 3PL link on the headline shape."""
+        on the narrow-row kernel (csrc/vibo_narrow.hip), a wide plain matrix (100 000 x 10 000: all panels in one launch, the rows'
+        counts resident with the data; also the first call that counts them) and the 3PL link on the headline shape."""
         from vibo_amd import _lib
         from vibo_amd.ops import ElboSpec
         out = {}
@@ -717,6 +717,22 @@ def main():
             eps = torch.randn(Pc, Ac, device=dev, generator=g)
             r2, m8, code = ops.prepare_rows(r, mk)
             call = lambda: ops._hip_launch_elbo(spec, r2, m8, code, None, table, item, eps, None, _lib.REG_KL, True, Pc)
+            counting_ms = None
+            if Ic > 1024:
+                # rows of more than 1024 items: a matrix the process calls with again is counted once (ops._resident_row_counts:
+                # the counts depend on the data alone) -- the timed calls below are those of a resident matrix; here the call that
+                # still counts its rows first, for the record
+                ops.ROW_COUNT_CACHE = False
+                for _ in range(2):
+                    call()
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(3):
+                    call()
+                c1.record()
+                torch.cuda.synchronize()
+                counting_ms = c0.elapsed_time(c1) / 3
+                ops.ROW_COUNT_CACHE = True
             for _ in range(3):
                 call()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -740,6 +756,10 @@ def main():
             bpt = 5.0 + 12.0 * Ac / Ic
             out[name] = {'ms': ms, 'terms_per_s': Pc * Ic / (ms * 1e-3), 'bytes_per_term': bpt,
                          'roofline_frac': bpt * Pc * Ic / (ms * 1e-3) / 8e12, 'kernel': ops.plan_kernel(spec, Pc, Ic, code, True)}
+            if counting_ms is not None:
+                out[name]['ms_with_the_count_pass'] = counting_ms
+                out[name]['note'] = ('ms: the matrix is resident -- its whole-row counts were taken once (vibo_row_counts) and are handed to '
+                                     'vibo_elbo_fwd_bwd_counts; ms_with_the_count_pass: a first call on new data (5 B/cell count pass + the panels)')
             if ks.get('launches') == 5:          # the fused kernel alone, by its own stamps (single-launch calls of the matrix / narrow kernels)
                 out[name]['kernel_ms_insitu'] = ks['mean_ms']
                 out[name]['kernel_roofline_frac'] = bpt * Pc * Ic / (ks['mean_ms'] * 1e-3) / 8e12

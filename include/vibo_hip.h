@@ -207,6 +207,23 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * vibo_elbo_fwd_bwd with the rows' whole-row counts supplied: row_counts[r] = vibo_row_counts of SOURCE row r (the row a call
+ * without row_index reads as its row r, the row row_index[k] = r selects) -- statistics of the data alone, which a caller with a
+ * resident matrix computes once.  The paths that would count first (unconditional posterior, more than 1024 items: a 5 B/cell
+ * pass in front of the panels) skip that pass; every other path ignores the argument.  Results are those of vibo_elbo_fwd_bwd bit
+ * for bit.
+ */
+int vibo_elbo_fwd_bwd_counts(const vibo_desc* d,
+                             const float* response, const void* mask, const int64_t* row_index, const int32_t* row_counts,
+                             const float* table, const float* item, const float* eps,
+                             const float* flow,
+                             float* out_scalars,
+                             float* ability_mu, float* ability_logvar, float* ability,
+                             float* ability_k, float* ability_ladj,
+                             float* grad_table, float* grad_item, float* grad_flow,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Forward-only ability posterior q(theta | responses[, items]) for B persons
  * (model.encode under no_grad: vibo.py:363-364, 406-407, 434-435; models.py:356-371).
  * Arguments as above; writes ability_mu / ability_logvar [B][A].  With a workspace of vibo_workspace_bytes(d) and

@@ -789,6 +789,43 @@ def test_conditional_posterior_one_dim_at_full_size(irt, P, I, monkeypatch):
         assert (t[:n].cpu() - ref[k].float()).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
 
 
+@pytest.mark.parametrize('codes', [False, True], ids=['fp32-rows', 'cell-codes'])
+def test_resident_row_counts_change_nothing(codes, monkeypatch):
+    """Rows of more than 1024 items under the unconditional posterior: a matrix the process calls with a second time is counted once
+    (ops._resident_row_counts -> vibo_elbo_fwd_bwd_counts) and the count pass in front of the panels goes away -- the whole matrix and
+    minibatches gathered from it give the bits of the counting call."""
+    irt, A, P, I = 2, 2, 3000, 2500
+    d = dev()
+    spec = ElboSpec(irt_model=irt, ability_dim=A)
+    resp, mask, table, item, eps = _device_problem(irt, A, P, I, 0.2, seed=77, cond=False)
+    if codes:
+        r2 = m2 = ops.pack_cell_codes(resp, mask).codes
+        code = _lib.MASK_CODES
+    else:
+        rp, mp = ops.pad_rows(resp, mask)
+        r2, m2, code = ops.prepare_rows(rp, mp)
+    rows = torch.randperm(P, device=d, generator=torch.Generator(device=d).manual_seed(3))[:700].contiguous()
+
+    def run(row_index=None):
+        e = eps if row_index is None else eps[row_index].contiguous()
+        B = P if row_index is None else int(row_index.numel())
+        out = ops._hip_launch_elbo(spec, r2, m2, code, row_index, table, item, e, None, _lib.REG_KL, True, B)
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', False)
+    full0, mb0 = run(), run(rows)
+    monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', True)
+    ops._ROW_COUNT_CACHE.clear()
+    run()                                        # first sighting: still the counting call
+    assert ops._ROW_COUNT_CACHE and ops._ROW_COUNT_CACHE[-1][4] is None
+    full1, mb1 = run(), run(rows)                # second: counted once, handed over from here on
+    assert ops._ROW_COUNT_CACHE[-1][4] is not None
+    for a, b in ((full0, full1), (mb0, mb1)):
+        assert torch.equal(a.flat, b.flat) and torch.equal(a.ability_mu, b.ability_mu) and torch.equal(a.ability, b.ability)
+    ops._ROW_COUNT_CACHE.clear()
+
+
 def test_config4_shape_at_full_size():
     """BASELINE configs[3]'s matrix shape at its full size (CritLangAcq: 535 598 persons x 95 items, 2PL, ability_dim 1,
     --artificial-missing-perc 0.2; datasets.py:283-440, masked log-likelihood models.py:596-629): narrow rows with padded

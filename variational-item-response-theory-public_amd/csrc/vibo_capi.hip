@@ -1005,11 +1005,18 @@ static bool step_plan_ok(const vibo_desc* d, const Plan& pl) {
            !pl.general && pl.panels == 0 && pl.split_ok;
 }
 
+// counts of the call's rows from the caller's per-source-row counts (vibo_elbo_fwd_bwd_counts with a row_index)
+__global__ __launch_bounds__(256) void gather_counts_kernel(const int32_t* __restrict__ all, const int64_t* __restrict__ row_index,
+                                                            int* __restrict__ out, int B) {
+    const int k = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (k < B) out[k] = all[row_index[k]];
+}
+
 static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_finalize, const float* response, const void* mask,
                              const int64_t* row_index, const float* table, const float* item, const float* eps, const float* flow,
                              float* out_scalars, float* ability_mu, float* ability_logvar, float* ability,
                              float* ability_k, float* ability_ladj, float* grad_table, float* grad_item,
-                             float* grad_flow, void* workspace, size_t workspace_bytes, void* stream) {
+                             float* grad_flow, void* workspace, size_t workspace_bytes, void* stream, const int32_t* row_counts = nullptr) {
     const int num_cu = device_cus();
     int rc = check_desc(d);
     if (rc) return rc;
@@ -1183,13 +1190,24 @@ static int elbo_fwd_bwd_impl(const vibo_desc* d, int32_t* step_count, int skip_f
             }
         } else {
             int* cnt = reinterpret_cast<int*>(wsb + pl.off_cnt);
-            int cgrid = num_cu * 8;
-            if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
-            hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
-                               (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype,
-                               code_rows, (long long)pl.codes_stride);
-            e = hipGetLastError();
-            p.row_cnt = cnt;
+            if (row_counts && !row_index) {
+                // the caller's whole-row counts (vibo_row_counts of the same rows, kept with its resident data: they depend on the
+                // data alone): no count pass -- half of the call on rows of more than 1024 items (100k x 10k: 1.64 -> 0.85 ms)
+                p.row_cnt = row_counts;
+            } else if (row_counts) {
+                hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)((d->num_person + 255) / 256)), dim3(256), 0, s, row_counts, row_index,
+                                   cnt, d->num_person);
+                e = hipGetLastError();
+                p.row_cnt = cnt;
+            } else {
+                int cgrid = num_cu * 8;
+                if (cgrid > (d->num_person + 3) / 4) cgrid = (d->num_person + 3) / 4;
+                hipLaunchKernelGGL(row_count_kernel, dim3(cgrid), dim3(256), 0, s, response, mask, row_index, cnt,
+                                   (long long)d->response_row_stride, (long long)d->mask_row_stride, d->num_person, I, d->mask_dtype,
+                                   code_rows, (long long)pl.codes_stride);
+                e = hipGetLastError();
+                p.row_cnt = cnt;
+            }
         }
         if (emit && pl.cond_fused) {  // (the matrix kernel reads the fp32 rows; the gradient pass the codes it leaves behind)
             cp.response = nullptr; cp.mask = code_rows; cp.row_index = nullptr;
@@ -1301,6 +1319,16 @@ int vibo_elbo_fwd_bwd(const vibo_desc* d, const float* response, const void* mas
                       float* grad_flow, void* workspace, size_t workspace_bytes, void* stream) {
     return elbo_fwd_bwd_impl(d, nullptr, 0, response, mask, row_index, table, item, eps, flow, out_scalars, ability_mu, ability_logvar,
                              ability, ability_k, ability_ladj, grad_table, grad_item, grad_flow, workspace, workspace_bytes, stream);
+}
+
+int vibo_elbo_fwd_bwd_counts(const vibo_desc* d, const float* response, const void* mask, const int64_t* row_index, const int32_t* row_counts,
+                             const float* table, const float* item, const float* eps, const float* flow,
+                             float* out_scalars, float* ability_mu, float* ability_logvar, float* ability,
+                             float* ability_k, float* ability_ladj, float* grad_table, float* grad_item,
+                             float* grad_flow, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!row_counts) return fail(-5, "null row_counts");
+    return elbo_fwd_bwd_impl(d, nullptr, 0, response, mask, row_index, table, item, eps, flow, out_scalars, ability_mu, ability_logvar,
+                             ability, ability_k, ability_ladj, grad_table, grad_item, grad_flow, workspace, workspace_bytes, stream, row_counts);
 }
 
 int vibo_train_step_supported(const vibo_desc* d) {

@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = ('vibo_version', 'vibo_last_error_string', 'vibo_workspace_by
                     'vibo_code_table_scratch_bytes', 'vibo_code_table_sum_forward', 'vibo_code_table_sum_backward',
                     'vibo_train_step_supported', 'vibo_elbo_fwd_bwd_step', 'vibo_train_epilogue_fused', 'vibo_train_prime',
                     'vibo_mtrain_param_floats', 'vibo_mtrain_prologue', 'vibo_mean_encoder_backward_sets', 'vibo_mtrain_epilogue',
-                    'vibo_set_insitu_timer', 'vibo_insitu_timer_reset', 'vibo_selftest_lane_swaps')
+                    'vibo_set_insitu_timer', 'vibo_insitu_timer_reset', 'vibo_selftest_lane_swaps', 'vibo_elbo_fwd_bwd_counts')
 
 _lib = None
 
@@ -109,6 +109,11 @@ def load():
                                       fp, fp, fp, fp, fp, fp,                # scalars + posterior outputs
                                       fp, fp, fp,                            # grads
                                       vp, ctypes.c_size_t, vp]               # workspace, stream
+    lib.vibo_elbo_fwd_bwd_counts.restype = ctypes.c_int
+    lib.vibo_elbo_fwd_bwd_counts.argtypes = [dp, fp, vp, i64p, vp, fp, fp, fp, fp,
+                                             fp, fp, fp, fp, fp, fp,
+                                             fp, fp, fp,
+                                             vp, ctypes.c_size_t, vp]
     lib.vibo_encode.restype = ctypes.c_int
     lib.vibo_encode.argtypes = [dp, fp, vp, i64p, fp, fp, fp, vp, ctypes.c_size_t, vp]
     lib.vibo_decode.restype = ctypes.c_int
