@@ -826,6 +826,43 @@ def test_resident_row_counts_change_nothing(codes, monkeypatch):
     ops._ROW_COUNT_CACHE.clear()
 
 
+def test_resident_row_counts_through_the_module(monkeypatch):
+    """The same through the module path (models.py:337-354 -> elbo): a resident split's tensors come back every step -- the bool mask's
+    uint8 view is one object per mask (ops.prepare_mask), so the second step finds the matrix in ops._resident_row_counts -- and the
+    losses / gradients of minibatch steps are those of the counting calls, bit for bit."""
+    from vibo_amd.torch_core.models import VIBO_2PL
+    A, P, I = 2, 900, 2100
+    d = dev()
+    resp, mask, _, _, _ = _device_problem(2, A, P, I, 0.2, seed=78, cond=False)
+    mask = mask.bool()
+    torch.manual_seed(5)
+    model = VIBO_2PL(A, I, ability_merge='product').to(d)
+    rows = [torch.randperm(P, device=d, generator=torch.Generator(device=d).manual_seed(k))[:256].contiguous() for k in range(3)]
+
+    def steps():
+        out = []
+        for k in range(3):
+            torch.manual_seed(100 + k)
+            model.zero_grad()
+            loss = model.elbo_step(resp, mask, row_index=rows[k])
+            loss.backward()
+            out.append((loss.detach().clone(), [p_.grad.detach().clone() for p_ in model.parameters()]))
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', False)
+    ref = steps()
+    monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', True)
+    ops._ROW_COUNT_CACHE.clear()
+    got = steps()
+    assert any(e[4] is not None for e in ops._ROW_COUNT_CACHE), 'the resident matrix was not recognised'
+    for (l0, g0), (l1, g1) in zip(ref, got):
+        assert torch.equal(l0, l1)
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b)
+    ops._ROW_COUNT_CACHE.clear()
+
+
 def test_config4_shape_at_full_size():
     """BASELINE configs[3]'s matrix shape at its full size (CritLangAcq: 535 598 persons x 95 items, 2PL, ability_dim 1,
     --artificial-missing-perc 0.2; datasets.py:283-440, masked log-likelihood models.py:596-629): narrow rows with padded

@@ -88,6 +88,7 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+_U8_VIEW_CACHE = []        # [(weakref to a bool mask, its uint8 view)], newest last, at most 4; an entry dies with its mask
 _I64_MASK_CACHE = []       # [(weakref to the int64 tensor, its _version, uint8 copy)], newest last, at most 4
 
 
@@ -106,7 +107,18 @@ def prepare_mask(mask, keep_int64=False):
         # rows may be strided (e.g. padded to 16 bytes, see pad_rows); only the cells must be unit-stride
         if mask.stride(-1) != 1:
             mask = mask.contiguous()
-        return (mask if mask.dtype == torch.uint8 else mask.view(torch.uint8)), _lib.MASK_U8
+        if mask.dtype == torch.uint8:
+            return mask, _lib.MASK_U8
+        # the uint8 view of a bool mask is ONE object per caller tensor while that tensor lives (a view is a new tensor object per
+        # call otherwise, and what is kept per resident matrix -- _resident_row_counts -- goes by the objects' identity)
+        for ref, view in _U8_VIEW_CACHE:
+            if ref() is mask:
+                return view, _lib.MASK_U8
+        view = mask.view(torch.uint8)
+        key = weakref.ref(mask, lambda r: _U8_VIEW_CACHE.__setitem__(slice(None), [e for e in _U8_VIEW_CACHE if e[0] is not r]))
+        _U8_VIEW_CACHE[:] = _U8_VIEW_CACHE[-3:]
+        _U8_VIEW_CACHE.append((key, view))
+        return view, _lib.MASK_U8
     if mask.dtype == torch.int64 and keep_int64:
         return mask.contiguous(), _lib.MASK_I64
     if mask.dtype == torch.int64:
