@@ -170,7 +170,7 @@ def fuzz_trainer():
     import copy
     from vibo_amd.torch_core.models import VIBO_1PL, VIBO_2PL, VIBO_3PL
     from vibo_amd.trainer import FusedTrainer
-    t0, n, worst, n_band = time.time(), 0, 0.0, 0
+    t0, n, worst, n_band, n_arb = time.time(), 0, 0.0, 0, 0
     while time.time() - t0 < a.seconds:
         irt = rng.choice([1, 2, 2, 3])
         A = rng.choice([1, 2, 3, 5, 8])
@@ -202,7 +202,7 @@ def fuzz_trainer():
             torch.manual_seed(100)
             with torch.no_grad():
                 out0 = ref.forward(resp, mask, row_index=rows)
-            pr = O.irt_link(3, out0[3].double().cpu(), out0[6].double().cpu())
+            pr = O.irt_link(irt, out0[3].double().cpu(), out0[6].double().cpu())
             mk = ((mask[rows] if rows is not None else mask)[:, :pr.shape[1]] != 0).cpu()
             e32 = 1.1920929e-07
             band = int(((pr > 1.0 - 5 * e32) & mk).sum()) + int(((pr < 5 * e32) & mk).sum())
@@ -230,6 +230,29 @@ def fuzz_trainer():
                 for name, x, y in (('mlp exp_avg', trainer.mlp_m, ref_m), ('item exp_avg', trainer.item_m, ref_im)):
                     em = float((x - y).abs().max()) / max(1e-1, float(y.abs().max()))     # (0.1 g; vanishing gradients: absolute floor)
                     worst = max(worst, em)
+                    if not em < 1e-4 and name == 'mlp exp_avg' and irt != 3 and em < 2e-3:
+                        # two fp32 paths disagree on the encoder's first moment: the fp64 oracle under the SAME noise decides (the noise the
+                        # module drew, recovered from a forward of a freshly constructed -- seeded -- module).  Round 6, seed 645: hidden
+                        # 256 at beta 0 (nothing but the log-likelihood feeds the encoder): torch's fp32 MLP backward 1.1e-4 off the fp64
+                        # gradient, the native epilogue 4.7e-5, 1.6e-4 between them.
+                        torch.manual_seed(seed)
+                        fresh = cls(A, I, hidden_dim=hidden, ability_merge='product').to(d)
+                        torch.manual_seed(100)
+                        with torch.no_grad():
+                            o = fresh.forward(resp, mask, row_index=rows)
+                        e_ab = ((o[3] - o[4]) / torch.exp(0.5 * o[5])).cpu().double()
+                        e_it = ((o[6] - o[7]) / torch.exp(0.5 * o[8])).cpu().double()
+                        rr, mm = (resp[rows], mask[rows]) if rows is not None else (resp, mask)
+                        names = [f'ability_encoder.mlp.{k_}.{w_}' for k_ in (0, 2, 4) for w_ in ('weight', 'bias')]
+                        _, g64 = O.elbo_loss_and_grads({k_: v_.detach().cpu().double() for k_, v_ in fresh.state_dict().items()}, rr[:, :I].cpu().double(),
+                                                       mm[:, :I].cpu(), e_it, e_ab, irt_model=irt, ability_dim=A, annealing_factor=beta)
+                        t64 = torch.cat([g64[n_].reshape(-1) for n_ in names]) * 0.1
+                        e64 = float((x.cpu().double() - t64).abs().max()) / max(1e-1, float(t64.abs().max()))
+                        e64m = float((y.cpu().double() - t64).abs().max()) / max(1e-1, float(t64.abs().max()))
+                        print(f'  (mlp exp_avg, module vs native step {em:.2e} at irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} seed={seed}: against the fp64 '
+                              f'oracle the native step is off by {e64:.2e}, the module path by {e64m:.2e})')
+                        n_arb += 1
+                        em = e64
                     if not em < 1e-4:
                         print(f'FAIL trainer {name} irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed}: {em}  (cells in the clamp band: {band})')
                         sys.exit(1)
@@ -242,7 +265,7 @@ def fuzz_trainer():
                 print(f'FAIL trainer param {k} irt={irt} A={A} B={B} I={I} hidden={hidden} beta={beta} lr={lr} gather={gather} seed={seed}: {e}')
                 sys.exit(1)
         n += 1
-    print(f'fuzz trainer ok: {n} random configurations, worst error {worst:.2e} ({n_band} of them 3PL with cells in the clamp band)')
+    print(f'fuzz trainer ok: {n} random configurations, worst error {worst:.2e} ({n_band} of them 3PL with cells in the clamp band; {n_arb} first-moment disagreements of the two fp32 paths settled by the fp64 oracle)')
 
 
 if a.target == 'multi':
