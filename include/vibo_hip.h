@@ -113,8 +113,9 @@ enum { VIBO_KERNEL_MATRIX = 1,        /* msplit_kernel: contractions as f16 hi/l
        VIBO_KERNEL_NARROW = 6 };      /* narrow_kernel: 4..128 items, ability_dim <= 4, plain model: a row per 16 lanes */
 int vibo_plan_kernel(const vibo_desc* d);
 /* Conditional posterior: which of its two extra passes would run on the matrix pipe (csrc/vibo_cmean.hip) for `d` -- bit 0 the
- * experts' per-person sums, bit 1 the scatter of the table gradient; 0 = both on the VALU kernels (csrc/vibo_cond.hip, or not a
- * conditional-posterior call), <0 on a bad descriptor. */
+ * experts' per-person sums, bit 1 the scatter of the table gradient; bit 2: there is no separate first pass at all -- the matrix
+ * row-split kernel forms the experts' sums itself (ability_dim 1, at most 1024 items, fp32 rows; VIBO_FLAG_COND_THREE_PASS clears it);
+ * 0 = both on the VALU kernels (csrc/vibo_cond.hip, or not a conditional-posterior call), <0 on a bad descriptor. */
 int vibo_plan_cond_passes(const vibo_desc* d);
 
 /* Library / ABI version (VIBO_ABI_VERSION of the build). */

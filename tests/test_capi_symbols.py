@@ -63,6 +63,8 @@ def test_planner_reports_its_kernel_and_honours_the_flags():
     assert plan(1_000_000, 1000, 8) == 1 and plan(1_000_000, 1000, 1) == 1          # bench.py's two shapes
     assert plan(4096, 1000, 8) == 1                                                  # ... and its elbo_rel_err sample
     assert plan(16, 1000, 8) == 2
+    # (round 6 calibration: the matrix kernel from 2 048 persons at 896+ items and 5+ dims; no 385..512-item exclusion any more)
+    assert plan(2048, 1000, 8) == 1 and plan(2048, 768, 8) == 2 and plan(4096, 512, 8) == 1 and plan(4096, 256, 8) == 2
     # narrow rows of the plain model (BASELINE configs[0] / [3]: 100 / 95 items) go to the narrow-row kernel at any minibatch size,
     # unless a flag pins a row-split kernel or the posterior is wider than 4 dims
     assert plan(535_598, 96, 1) == 6 and plan(16, 100, 1) == 6 and plan(8000, 95, 4) == 6 and plan(1000, 128, 2) == 6
@@ -83,7 +85,12 @@ def test_planner_reports_its_kernel_and_honours_the_flags():
         return lib.vibo_plan_cond_passes(ctypes.byref(d))
 
     assert cond(1_000_000, 1000, 8, mask=_lib.MASK_CODES) == 3 and cond(1_000_000, 1000, 1, mask=_lib.MASK_CODES) == 3
-    assert cond(1_000_000, 1000, 8) == 3 and cond(1_000_000, 1000, 4) == 2 and cond(1_000_000, 1000, 1) == 2
+    assert cond(1_000_000, 1000, 8) == 3 and cond(1_000_000, 1000, 4) == 2
+    # ability_dim 1 on fp32 rows: no first pass at all where the matrix kernel runs (bit 2: it forms the experts' sums itself) -- from
+    # 8 192 persons at 256..1024 items; the three-pass pin and cell-code rows keep the separate pass
+    assert cond(1_000_000, 1000, 1) == 6 and cond(8192, 1000, 1) == 6 and cond(8192, 256, 1) == 6 and cond(4096, 1000, 1) == 2
+    assert cond(1_000_000, 1000, 1, _lib.FLAG_COND_THREE_PASS) == 2 and cond(1_000_000, 1000, 1, grad=0) == 4
+    assert cond(1_000_000, 1000, 2) == 2 and cond(1_000_000, 1000, 1, _lib.FLAG_NO_EMIT_CODES) == 0
     assert cond(16, 1000, 8, mask=_lib.MASK_CODES) == 3 and cond(16, 1000, 8) == 3       # 5+ dims: at any size
     assert cond(16, 1000, 1, mask=_lib.MASK_CODES) == 0 and cond(4095, 1000, 1, mask=_lib.MASK_CODES) == 0
     assert cond(16, 1000, 1, _lib.FLAG_COND_MATRIX, _lib.MASK_CODES) == 3 and cond(16, 1000, 1, _lib.FLAG_COND_MATRIX) == 2

@@ -72,7 +72,7 @@ if a.cond:
                 import ctypes
                 pk = lib.vibo_plan_cond_passes(ctypes.byref(dd))
                 best = 'matrix' if t['default'] < t['valu'] else 'valu'
-                print(f'{P:8d} {I:6d} {A:2d} {t["valu"]:9.1f} {t["default"]:10.1f}  faster: {best:6s}  planner puts on the matrix pipe: {"pre " if pk & 1 else ""}{"post" if pk & 2 else ""}{"nothing" if pk == 0 else ""}')
+                print(f'{P:8d} {I:6d} {A:2d} {t["valu"]:9.1f} {t["default"]:10.1f}  faster: {best:6s}  planner puts on the matrix pipe: {"pre " if pk & 1 else ""}{"post" if pk & 2 else ""}{" (first pass folded into the matrix kernel)" if pk & 4 else ""}{"nothing" if pk == 0 else ""}')
     sys.exit(0)
 print(f'# device: {torch.cuda.get_device_name(0)}; rows: {"cell codes" if a.codes else "fp32 + mask"}; 2PL, 10 % missing, forward + backward')
 print(f'{"persons":>8s} {"items":>6s} {"A":>2s} {"valu us":>9s} {"matrix us":>10s} {"faster":>7s} {"planner":>8s}  note')

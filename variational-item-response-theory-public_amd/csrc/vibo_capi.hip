@@ -949,7 +949,7 @@ int vibo_plan_cond_passes(const vibo_desc* d) {
     rc = make_plan(d, &pl);
     if (rc < 0) return rc;
     if (pl.general || !pl.cond) return 0;
-    return (pl.cmat_pre ? 1 : 0) | (pl.cmat_post ? 2 : 0);
+    return (pl.cmat_pre ? 1 : 0) | (pl.cmat_post ? 2 : 0) | (pl.cond_fused ? 4 : 0);
 }
 
 int vibo_plan_kernel(const vibo_desc* d) {
