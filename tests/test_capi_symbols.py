@@ -87,8 +87,8 @@ def test_planner_reports_its_kernel_and_honours_the_flags():
     assert cond(1_000_000, 1000, 8, mask=_lib.MASK_CODES) == 3 and cond(1_000_000, 1000, 1, mask=_lib.MASK_CODES) == 3
     assert cond(1_000_000, 1000, 8) == 3 and cond(1_000_000, 1000, 4) == 2
     # ability_dim 1 on fp32 rows: no first pass at all where the matrix kernel runs (bit 2: it forms the experts' sums itself) -- from
-    # 8 192 persons at 256..1024 items; the three-pass pin and cell-code rows keep the separate pass
-    assert cond(1_000_000, 1000, 1) == 6 and cond(8192, 1000, 1) == 6 and cond(8192, 256, 1) == 6 and cond(4096, 1000, 1) == 2
+    # 8 192 persons at 256..1024 items (4 096 at 896+); the three-pass pin and cell-code rows keep the separate pass
+    assert cond(1_000_000, 1000, 1) == 6 and cond(8192, 1000, 1) == 6 and cond(8192, 256, 1) == 6 and cond(4096, 1000, 1) == 6 and cond(4096, 768, 1) == 2 and cond(2048, 1000, 1) == 2
     assert cond(1_000_000, 1000, 1, _lib.FLAG_COND_THREE_PASS) == 2 and cond(1_000_000, 1000, 1, grad=0) == 4
     assert cond(1_000_000, 1000, 2) == 2 and cond(1_000_000, 1000, 1, _lib.FLAG_NO_EMIT_CODES) == 0
     assert cond(16, 1000, 8, mask=_lib.MASK_CODES) == 3 and cond(16, 1000, 8) == 3       # 5+ dims: at any size

@@ -180,7 +180,7 @@ static bool want_msplit(const vibo_desc* d) {
     if (d->posterior == VIBO_POSTERIOR_CONDITIONAL && d->ability_dim == 1 && d->n_flows == 0 && d->num_item <= 1024 && d->num_item >= 256 &&
         d->mask_dtype != VIBO_MASK_CODES && d->mask_dtype != VIBO_MASK_I64 && !(d->flags & (VIBO_FLAG_COND_THREE_PASS | VIBO_FLAG_COND_VALU)) &&
         (!d->want_grad || emit_codes_wanted(d)))
-        return d->num_person >= 8192;
+        return d->num_person >= (d->num_item >= 896 ? 4096 : 8192);
     const int width = d->num_item < 1024 ? d->num_item : 1024;
     // (round 6, profiles/r06_planner_calibration.txt: the kernel's launch got ~9 us shorter -- 2 048 x 1 000 at ability_dim 8 19.4 vs 22.6 us,
     //  and the 385..512-item exclusion of round 3 -- "2 workgroups per CU with one batch each at 16 384 persons: 48 vs 42 us" -- now
