@@ -816,14 +816,12 @@ def test_resident_row_counts_change_nothing(codes, monkeypatch):
     monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', False)
     full0, mb0 = run(), run(rows)
     monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', True)
-    ops._ROW_COUNT_CACHE.clear()
     run()                                        # first sighting: still the counting call
-    assert ops._ROW_COUNT_CACHE and ops._ROW_COUNT_CACHE[-1][4] is None
+    assert r2._vibo_row_counts[3] is None
     full1, mb1 = run(), run(rows)                # second: counted once, handed over from here on
-    assert ops._ROW_COUNT_CACHE[-1][4] is not None
+    assert r2._vibo_row_counts[3] is not None
     for a, b in ((full0, full1), (mb0, mb1)):
         assert torch.equal(a.flat, b.flat) and torch.equal(a.ability_mu, b.ability_mu) and torch.equal(a.ability, b.ability)
-    ops._ROW_COUNT_CACHE.clear()
 
 
 def test_resident_row_counts_through_the_module(monkeypatch):
@@ -853,14 +851,12 @@ def test_resident_row_counts_through_the_module(monkeypatch):
     monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', False)
     ref = steps()
     monkeypatch.setattr(ops, 'ROW_COUNT_CACHE', True)
-    ops._ROW_COUNT_CACHE.clear()
     got = steps()
-    assert any(e[4] is not None for e in ops._ROW_COUNT_CACHE), 'the resident matrix was not recognised'
+    assert getattr(resp, '_vibo_row_counts', None) is not None and resp._vibo_row_counts[3] is not None, 'the resident matrix was not recognised'
     for (l0, g0), (l1, g1) in zip(ref, got):
         assert torch.equal(l0, l1)
         for a, b in zip(g0, g1):
             assert torch.equal(a, b)
-    ops._ROW_COUNT_CACHE.clear()
 
 
 def test_config4_shape_at_full_size():

@@ -332,7 +332,6 @@ def _require_device(*tensors):
                                'there is no CPU path' % t.device)
 
 
-_ROW_COUNT_CACHE = []      # [[weakref(response), its _version, weakref(mask) | None, its _version, counts | None]], newest last, at most 4
 ROW_COUNT_CACHE = True     # (tests / A-B runs switch it off)
 
 
@@ -342,28 +341,29 @@ def _resident_row_counts(spec, response, mask, mask_code):
     Rows of more than 1024 items under the unconditional posterior are counted in a pass of their own in front of the panels
     (half of the call: 5 B/cell).  The counts depend on the data alone, so a matrix seen a second time (same tensors, unchanged
     since: the resident training / evaluation split) is counted once, over all of its rows, and every later call -- the whole
-    matrix or minibatches gathered from it through row_index -- hands them to vibo_elbo_fwd_bwd_counts."""
+    matrix or minibatches gathered from it through row_index -- hands them to vibo_elbo_fwd_bwd_counts.
+    The record lives ON the response tensor (`_vibo_row_counts`): the counts are freed with the data they describe and never
+    before -- a captured hipGraph that holds the data's address holds the counts' too."""
     I = response.shape[1]
     if (not ROW_COUNT_CACHE or spec.conditional or getattr(spec, 'given', False) or I <= 1024 or I > 32767
             or mask_code not in (_lib.MASK_NONE, _lib.MASK_U8, _lib.MASK_CODES)):
         return None
     mv = mask._version if mask is not None else 0
-    for ent in _ROW_COUNT_CACHE:
-        if ent[0]() is response and ent[1] == response._version and (ent[2]() if ent[2] is not None else None) is mask and ent[3] == mv:
-            if ent[4] is None:           # second sighting: count now
-                if torch.cuda.is_current_stream_capturing():
-                    return None          # (a count recorded into a hipGraph would not have run when the next eager call reads it)
-                lib = _lib.load()
-                P = response.shape[0]
-                d = _make_desc(spec, P, I, mask_code, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, False, response.stride(0),
-                               mask.stride(0) if mask is not None else 0)
-                counts = torch.empty(P, dtype=torch.int32, device=response.device)
-                stream = ctypes.c_void_p(torch.cuda.current_stream(response.device).cuda_stream)
-                _lib.check(lib.vibo_row_counts(ctypes.byref(d), _ptr(response), _ptr(mask), ctypes.c_void_p(0), _ptr(counts), stream), 'vibo_row_counts')
-                ent[4] = counts
-            return ent[4]
-    _ROW_COUNT_CACHE[:] = [e for e in _ROW_COUNT_CACHE if e[0]() is not None and e[0]() is not response][-3:]
-    _ROW_COUNT_CACHE.append([weakref.ref(response), response._version, weakref.ref(mask) if mask is not None else None, mv, None])
+    rec = getattr(response, '_vibo_row_counts', None)      # [response version, weakref(mask) | None, mask version, counts | None]
+    if rec is not None and rec[0] == response._version and (rec[1]() if rec[1] is not None else None) is mask and rec[2] == mv:
+        if rec[3] is None:               # second sighting: count now
+            if torch.cuda.is_current_stream_capturing():
+                return None              # (a count recorded into a hipGraph would not have run when the next eager call reads it)
+            lib = _lib.load()
+            P = response.shape[0]
+            d = _make_desc(spec, P, I, mask_code, _lib.REG_SAMPLED if spec.n_flows else _lib.REG_KL, False, response.stride(0),
+                           mask.stride(0) if mask is not None else 0)
+            counts = torch.empty(P, dtype=torch.int32, device=response.device)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(response.device).cuda_stream)
+            _lib.check(lib.vibo_row_counts(ctypes.byref(d), _ptr(response), _ptr(mask), ctypes.c_void_p(0), _ptr(counts), stream), 'vibo_row_counts')
+            rec[3] = counts
+        return rec[3]
+    response._vibo_row_counts = [response._version, weakref.ref(mask) if mask is not None else None, mv, None]
     return None
 
 
