@@ -524,6 +524,10 @@ def row_counts(response, mask, row_index=None):
         _COUNTS_SEEN[:] = [weakref.ref(key_r)]
         return _BACKEND['counts'](response, mask, code, row_index)
     cnt = _BACKEND['counts'](response, mask, code, None)
+    try:
+        key_r._vibo_counts_keepalive = cnt      # (alive as long as the data: a captured hipGraph that reads the data reads these too)
+    except AttributeError:
+        pass
     _COUNTS_CACHE[:] = [e for e in _COUNTS_CACHE if e[0]() is not None and (e[2] is None or e[2]() is not None)][-3:]
     _COUNTS_CACHE.append((weakref.ref(key_r), key_r._version, weakref.ref(key_m) if key_m is not None else None,
                           key_m._version if key_m is not None else 0, cnt))
